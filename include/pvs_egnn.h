@@ -1,0 +1,192 @@
+/*
+ * pvs_egnn.h - C ABI of libpvs_egnn.so: the MI355X (gfx950) implementation of the PointVS EGNN
+ * message-passing hot path (forward and backward).
+ *
+ * The reference has no native code at all: the boundary it offers for this path is
+ * the Python nn.Module surface.  Each entry point below therefore names the reference Python
+ * function whose body it replaces.  The host side that keeps the reference's class surface
+ * (`pointvs_amd/egnn_satorras.py` etc.) binds these with ctypes; see INTEGRATION.md for the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to caller-owned memory (torch allocations); the library
+ *     never allocates, frees or synchronises; all work is enqueued on `stream` (hipGraph-capturable)
+ *   - floating point is fp32, indices int32 inside the library (the int64 COO / int64 one-hot the
+ *     reference hands over is converted once per batch by pvs_graph_prepare)
+ *   - row-major, dense; "[E,H] sorted" means edge rows in the CSR order produced by
+ *     pvs_graph_prepare (use pvs_rows_to_input_order to get the reference's input edge order)
+ *   - return value: 0 = ok, <0 = error; pvs_last_error() gives the message (thread-local)
+ *   - stateless and re-entrant
+ */
+#ifndef PVS_EGNN_H
+#define PVS_EGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pvs_stream_t; /* hipStream_t */
+
+/* ---- layer flags: one bit per EGNNLayer.__init__ switch (egnn_satorras.py:26-46) ---- */
+enum {
+    PVS_RESIDUAL        = 1u << 0,
+    PVS_EDGE_RESIDUAL   = 1u << 1,  /* applied only when m_prev != NULL (egnn_satorras.py:194) */
+    PVS_EDGE_ATTENTION  = 1u << 2,
+    PVS_NORMALIZE       = 1u << 3,
+    PVS_TANH            = 1u << 4,
+    PVS_GRAPHNORM       = 1u << 5,
+    PVS_UPDATE_COORDS   = 1u << 6,
+    PVS_PERM_INVARIANT  = 1u << 7,
+    PVS_NODE_ATTENTION  = 1u << 8,
+    PVS_GATED_RESIDUAL  = 1u << 9,
+    PVS_REZERO          = 1u << 10,
+    PVS_SOFTMAX_ATT     = 1u << 11
+};
+
+/* attention_activation_fn (egnn_satorras.py:66-71); IDENTITY is what softmax_attention selects */
+enum { PVS_ACT_SIGMOID = 0, PVS_ACT_TANH = 1, PVS_ACT_RELU = 2, PVS_ACT_SILU = 3, PVS_ACT_IDENTITY = 4 };
+
+typedef struct PvsLayerDesc {
+    int32_t  hidden;       /* H = input_nf = hidden_nf = output_nf (always k,k,k in build_net) */
+    int32_t  n_edge_attr;  /* A = edges_in_d: number of one-hot edge classes (0 = no edge_attr) */
+    uint32_t flags;        /* PVS_* bits */
+    int32_t  att_act;      /* PVS_ACT_* */
+} PvsLayerDesc;
+
+/* Graph in the library's layout, filled by pvs_graph_prepare. Rows = edge_index[0] (aggregation
+ * target, egnn_satorras.py:135,171), cols = edge_index[1]. */
+typedef struct PvsGraph {
+    int32_t n_nodes;
+    int32_t n_edges;
+    const int32_t* rowptr;   /* [N+1] CSR offsets by row                                        */
+    const int32_t* row;      /* [E]   row of each sorted edge                                   */
+    const int32_t* col;      /* [E]   col of each sorted edge (stable order within a row)       */
+    const uint8_t* etype;    /* [E]   one-hot class of each sorted edge (NULL when A == 0)      */
+    const int32_t* perm;     /* [E]   sorted position -> input edge id                          */
+    const int32_t* colptr;   /* [N+1] CSC offsets by col                                        */
+    const int32_t* cedge;    /* [E]   sorted positions of the edges grouped by col (stable)     */
+    const float*   inv_deg;  /* [N]   1 / max(deg_row, 1)  (unsorted_segment_mean's clamp)      */
+} PvsGraph;
+
+/* Parameters of one EGNNLayer, torch nn.Linear layout W[out][in] (state_dict keys in comments). */
+typedef struct PvsLayerParams {
+    const float* edge_w1;   /* edge_mlp.0.weight  [H, (perm_inv?H:2H)+1+A] */
+    const float* edge_b1;   /* edge_mlp.0.bias    [H]      */
+    const float* edge_w2;   /* edge_mlp.2.weight  [H,H]    */
+    const float* edge_b2;   /* edge_mlp.2.bias    [H]      */
+    const float* coord_w1;  /* coord_mlp.0.weight [H,H]    */
+    const float* coord_b1;  /* coord_mlp.0.bias   [H]      */
+    const float* coord_w2;  /* coord_mlp.2.weight [1,H]    */
+    const float* att_w;     /* att_mlp.0.weight   [1,H]    (edge attention) */
+    const float* att_b;     /* att_mlp.0.bias     [1]      */
+    const float* node_w1;   /* node_mlp.0.weight  [H,2H]   */
+    const float* node_b1;   /* node_mlp.0.bias    [H]      */
+    const float* node_w2;   /* node_mlp.3.weight  [H,H]    */
+    const float* node_b2;   /* node_mlp.3.bias    [H]      */
+    const float* gn_weight; /* node_mlp.1.weight  [H]      (graphnorm) */
+    const float* gn_bias;   /* node_mlp.1.bias    [H]      */
+    const float* gn_mean_scale; /* node_mlp.1.mean_scale [H] */
+    const float* node_att_w;    /* node_att_mlp.0.weight [1,H] */
+    const float* node_att_b;    /* node_att_mlp.0.bias   [1]   */
+    const float* edge_gate;     /* edge_gate_parameter [1] */
+    const float* node_gate;     /* node_gate_parameter [1] */
+} PvsLayerParams;
+
+/* Gradients, same shapes; every non-NULL member is OVERWRITTEN with this call's gradient. */
+typedef struct PvsLayerGrads {
+    float *edge_w1, *edge_b1, *edge_w2, *edge_b2;
+    float *coord_w1, *coord_b1, *coord_w2;
+    float *att_w, *att_b;
+    float *node_w1, *node_b1, *node_w2, *node_b2;
+    float *gn_weight, *gn_bias, *gn_mean_scale;
+    float *node_att_w, *node_att_b;
+    float *edge_gate, *node_gate;
+} PvsLayerGrads;
+
+const char* pvs_last_error(void);
+int pvs_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Graph preparation: int64 COO (arbitrary order, duplicates allowed - SURVEY Q6) + int64 one-hot
+ * edge_attr, as PygPointCloudDataset emits them (data_loaders.py:359-370), to CSR/CSC.
+ * Replaces nothing in the reference (torch indexes the COO directly, egnn_satorras.py:190-193);
+ * it is the once-per-batch price of atomics-free, deterministic segment reductions.
+ *   edge_index [2,E] int64, edge_attr [E,A] int64 one-hot or NULL.
+ *   status: device int32[1], 0 on success, bit0 = index out of range, bit1 = edge_attr row not
+ *   one-hot; checked by the caller whenever it next synchronises.
+ * Output arrays are the members of PvsGraph (caller-allocated with the sizes given there).
+ */
+size_t pvs_graph_prepare_workspace_bytes(int32_t n_nodes, int32_t n_edges);
+int pvs_graph_prepare(const int64_t* edge_index, const int64_t* edge_attr, int32_t n_edge_attr,
+                      int32_t n_nodes, int32_t n_edges,
+                      int32_t* rowptr, int32_t* row, int32_t* col, uint8_t* etype, int32_t* perm,
+                      int32_t* colptr, int32_t* cedge, float* inv_deg, int32_t* status,
+                      void* workspace, size_t workspace_bytes, pvs_stream_t stream);
+
+/* dst[perm[e], :] = src[e, :]  (sorted -> input edge order), width floats per row.
+ * Gives EGNNLayer.forward's 4th return value `edge_feat` and `att_val` in the reference's order. */
+int pvs_rows_to_input_order(const float* src, float* dst, const int32_t* perm, int32_t n_edges,
+                            int32_t width, pvs_stream_t stream);
+/* dst[e, :] = src[perm[e], :]  (input -> sorted edge order): incoming edge_messages and their grads. */
+int pvs_rows_to_sorted_order(const float* src, float* dst, const int32_t* perm, int32_t n_edges,
+                             int32_t width, pvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * EGNNLayer.forward (egnn_satorras.py:189-206): coord2radial :178-187, edge_model :123-132,
+ * edge-residual :194-202, coord_model :168-176 (+unsorted_segment_mean :340-347),
+ * node_model :134-166 (+unsorted_segment_sum :332-337).
+ *   h [N,H], x [N,3] inputs; m_prev [E,H] sorted or NULL (edge_messages of the previous layer)
+ *   h_out [N,H], x_out [N,3] (never aliases x: the reference's in-place `coord += agg` is the
+ *   caller's business), m_out [E,H] sorted or NULL (skip materialising edge_feat),
+ *   att_out [E] sorted (required when PVS_EDGE_ATTENTION: also consumed by the backward),
+ *   node_att_out [N] or NULL, saved: pvs_egnn_layer_saved_floats() floats kept for the backward.
+ */
+size_t pvs_egnn_layer_saved_floats(const PvsLayerDesc* desc, int32_t n_nodes, int32_t n_edges);
+size_t pvs_egnn_layer_workspace_bytes(const PvsLayerDesc* desc, int32_t n_nodes, int32_t n_edges,
+                                      int32_t backward);
+int pvs_egnn_layer_fwd(const PvsLayerDesc* desc, const PvsGraph* graph, const PvsLayerParams* params,
+                       const float* h, const float* x, const float* m_prev,
+                       float* h_out, float* x_out, float* m_out, float* att_out,
+                       float* node_att_out, float* saved,
+                       void* workspace, size_t workspace_bytes, pvs_stream_t stream);
+
+/* Backward of the above (what autograd replays for the reference, SURVEY.md §8a "Backward spec").
+ *   g_h_out [N,H]; g_x_out [N,3] or NULL (=0: the last layer's x is unused);
+ *   g_m_out [E,H] sorted or NULL (=0); att [E] sorted as written by the forward.
+ *   g_h [N,H], g_x [N,3] (NULL to skip), g_m_prev [E,H] sorted (required iff edge residual applied)
+ *   grads: members may be NULL to skip (coord_* MUST be NULL-safe: they are None for the last layer).
+ */
+int pvs_egnn_layer_bwd(const PvsLayerDesc* desc, const PvsGraph* graph, const PvsLayerParams* params,
+                       const float* h, const float* x, const float* m_prev, const float* att,
+                       const float* saved,
+                       const float* g_h_out, const float* g_x_out, const float* g_m_out,
+                       float* g_h, float* g_x, float* g_m_prev, const PvsLayerGrads* grads,
+                       void* workspace, size_t workspace_bytes, pvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The thin callers either side of the layer stack.
+ * y = x W^T + b: PygLinearPass.forward (pnn_geometric_base.py:83-94) and each nn.Linear of the
+ * feats_linear_layers head (egnn_satorras.py:304-316, egnn_multitask.py:141-146).
+ */
+int pvs_linear_fwd(const float* x, const float* w, const float* b /*NULL if no bias*/, float* y,
+                   int32_t n_rows, int32_t n_in, int32_t n_out, pvs_stream_t stream);
+size_t pvs_linear_bwd_workspace_bytes(int32_t n_rows, int32_t n_in, int32_t n_out);
+int pvs_linear_bwd(const float* x, const float* w, const float* g_y,
+                   float* g_x /*NULL to skip*/, float* g_w, float* g_b /*NULL if no bias*/,
+                   int32_t n_rows, int32_t n_in, int32_t n_out,
+                   void* workspace, size_t workspace_bytes, pvs_stream_t stream);
+
+/* global_mean_pool(feats, batch, size) (pnn_geometric_base.py:29-33, egnn_multitask.py:158-161):
+ * nodes of one graph are contiguous (PyG collation); graph_ptr [B+1] int32 node offsets. */
+int pvs_mean_pool_fwd(const float* h, const int32_t* graph_ptr, float* pooled,
+                      int32_t n_graphs, int32_t width, pvs_stream_t stream);
+int pvs_mean_pool_bwd(const float* g_pooled, const int32_t* graph_ptr, float* g_h,
+                      int32_t n_graphs, int32_t n_nodes, int32_t width, pvs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVS_EGNN_H */

@@ -1,0 +1,102 @@
+// Shared host/device helpers for libpvs_egnn.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/pvs_egnn.h"
+
+#define PVS_WAVE 64
+
+void pvs_set_error(const char* fmt, ...);
+
+#define PVS_CHECK_HIP(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            pvs_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                          __LINE__);                                                     \
+            return -2;                                                                   \
+        }                                                                                \
+    } while (0)
+
+#define PVS_CHECK_LAUNCH() PVS_CHECK_HIP(hipGetLastError())
+
+#define PVS_REQUIRE(cond, ...)                \
+    do {                                      \
+        if (!(cond)) {                        \
+            pvs_set_error(__VA_ARGS__);       \
+            return -1;                        \
+        }                                     \
+    } while (0)
+
+static inline size_t pvs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Bump allocator over the caller's workspace (256-B aligned pieces).
+struct PvsArena {
+    char* base;
+    size_t cap;
+    size_t off;
+    PvsArena(void* p, size_t bytes) : base((char*)p), cap(bytes), off(0) {}
+    template <typename T>
+    T* take(size_t count) {
+        off = pvs_align_up(off, 256);
+        T* r = (T*)(base ? base + off : nullptr);
+        off += count * sizeof(T);
+        return r;
+    }
+    bool ok() const { return off <= cap; }
+};
+
+// ---- device math: SiLU / sigmoid and their derivatives ----
+__device__ __forceinline__ float pvs_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float pvs_silu(float v) { return v * pvs_sigmoid(v); }
+// d/dv [v*sigmoid(v)] given s = sigmoid(v)
+__device__ __forceinline__ float pvs_silu_grad(float v, float s) { return s * (1.0f + v * (1.0f - s)); }
+__device__ __forceinline__ float pvs_tanh(float v) {
+    // tanh(v) = 1 - 2/(exp(2v)+1); exact limits at +-inf, no cancellation blow-up near 0 beyond 1 ulp of 1
+    float a = fabsf(v);
+    float t;
+    if (a < 0.35f) {  // odd series region: keep relative accuracy for small |v|
+        float v2 = v * v;
+        t = v * (1.0f + v2 * (-0.33333334f + v2 * (0.13333334f + v2 * (-0.053968254f + v2 * 0.021869488f))));
+    } else {
+        float e = __expf(2.0f * a);
+        t = copysignf(1.0f - 2.0f / (e + 1.0f), v);
+    }
+    return t;
+}
+
+// attention activation (PVS_ACT_*) and derivative wrt its logit, given logit l and value a
+__device__ __forceinline__ float pvs_att_act(int act, float l) {
+    switch (act) {
+        case PVS_ACT_SIGMOID: return pvs_sigmoid(l);
+        case PVS_ACT_TANH: return pvs_tanh(l);
+        case PVS_ACT_RELU: return l > 0.f ? l : 0.f;
+        case PVS_ACT_SILU: return pvs_silu(l);
+        default: return l;
+    }
+}
+__device__ __forceinline__ float pvs_att_act_grad(int act, float l, float a) {
+    switch (act) {
+        case PVS_ACT_SIGMOID: return a * (1.0f - a);
+        case PVS_ACT_TANH: return 1.0f - a * a;
+        case PVS_ACT_RELU: return l > 0.f ? 1.0f : 0.f;
+        case PVS_ACT_SILU: { float s = pvs_sigmoid(l); return pvs_silu_grad(l, s); }
+        default: return 1.0f;
+    }
+}
+
+// Same-wave LDS hand-off: order this wave's LDS writes before its later LDS reads.
+__device__ __forceinline__ void pvs_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Sum over aligned groups of W consecutive lanes (W power of two <= 64); every lane gets the total.
+template <int W>
+__device__ __forceinline__ float pvs_group_sum(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

@@ -1,0 +1,25 @@
+// Node-level dense helpers (N rows x <=256 channels): small, deterministic, atomics-free.
+#pragma once
+#include "common.h"
+
+// y[n*ldy + c] (=|+=) b[c] + sum_k x[n*ldx+k] * W[c*swc + k*swk] + sum_k2 x2[n*ldx2+k2] * W2[c*swc2 + k2*swk2]
+int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx, const float* W,
+                      int swc, int swk, const float* b, const float* x2, int ldx2, const float* W2,
+                      int swc2, int swk2, int N, int K, int K2, int C, bool accumulate);
+
+// number of float slabs a column reduction / tsgemm over N rows needs: slabs * width floats
+int pvs_reduce_blocks(int N);
+
+// out[c*ldo + k] (=|+=) sum_n A[n*lda + c] * B[n*ldb + k]   (weight gradients), C*K <= 8192
+int pvs_launch_tsgemm_tn(hipStream_t s, float* out, int ldo, const float* A, int lda, const float* B,
+                         int ldb, int N, int C, int K, float* slabs, bool accumulate);
+
+enum { PVS_COL_SUM_A = 0, PVS_COL_SUM_AB = 1, PVS_COL_SUMSQ_SHIFT = 2 };
+// out[c] (=|+=) scale * sum_n f(A[n*lda+c], B[n*ldb+c] | shift[c])
+int pvs_launch_colreduce(hipStream_t s, int mode, float* out, const float* A, int lda, const float* B,
+                         int ldb, const float* shift, int N, int C, float scale, float* slabs,
+                         bool accumulate);
+
+// out[map(o)] (=|+=) sum_g slabs[g*width + o], o < width; map(o) = (o / inner) * ldo + o % inner
+int pvs_launch_reduce_slabs(hipStream_t s, float* out, int ldo, int inner, const float* slabs,
+                            int n_slabs, int width, bool accumulate);

@@ -1,0 +1,301 @@
+#include "dense_ops.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kRowsPerBlock = 512;   // rows one block reduces in tsgemm / colreduce
+constexpr int kMaxBlocks = 512;
+
+__global__ void __launch_bounds__(kThreads)
+k_linear(float* __restrict__ y, int ldy, const float* __restrict__ x, int ldx,
+         const float* __restrict__ W, int swc, int swk, const float* __restrict__ b,
+         const float* __restrict__ x2, int ldx2, const float* __restrict__ W2, int swc2, int swk2,
+         int N, int K, int K2, int C, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int KK = K + K2;
+    float* Wt = smem;             // [KK][C]  transposed: lanes over c read consecutive words
+    float* xs = smem + KK * C;    // [NB][KK]
+    const int tid = threadIdx.x;
+    const int NB = kThreads / C > 0 ? kThreads / C : 1;
+    for (int i = tid; i < KK * C; i += kThreads) {
+        int k = i / C, c = i % C;
+        Wt[i] = k < K ? W[(size_t)c * swc + (size_t)k * swk]
+                      : W2[(size_t)c * swc2 + (size_t)(k - K) * swk2];
+    }
+    for (int n0 = blockIdx.x * NB; n0 < N; n0 += gridDim.x * NB) {
+        __syncthreads();
+        for (int i = tid; i < NB * KK; i += kThreads) {
+            int nn = i / KK, k = i % KK, n = n0 + nn;
+            float v = 0.f;
+            if (n < N) v = k < K ? x[(size_t)n * ldx + k] : x2[(size_t)n * ldx2 + (k - K)];
+            xs[i] = v;
+        }
+        __syncthreads();
+        for (int o = tid; o < NB * C; o += kThreads) {
+            int nn = o / C, c = o % C, n = n0 + nn;
+            if (n >= N) continue;
+            float acc = b ? b[c] : 0.f;
+            const float* xr = xs + nn * KK;
+            for (int k = 0; k < KK; ++k) acc = fmaf(xr[k], Wt[k * C + c], acc);
+            float* dst = y + (size_t)n * ldy + c;
+            *dst = accumulate ? *dst + acc : acc;
+        }
+    }
+}
+
+// Each block owns a contiguous row range and every output (c,k); outputs are dealt to threads in
+// chunks of 256; partial results go to slabs[block][C*K] and are summed in block order afterwards.
+template <int MAXCH>
+__global__ void __launch_bounds__(kThreads)
+k_tsgemm_tn(float* __restrict__ slabs, const float* __restrict__ A, int lda,
+            const float* __restrict__ B, int ldb, int N, int C, int K, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = 16;
+    float* As = smem;            // [NT][C]
+    float* Bs = smem + NT * C;   // [NT][K]
+    const int tid = threadIdx.x;
+    const int CK = C * K;
+    float acc[MAXCH];
+    int oc[MAXCH], ok[MAXCH];
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        acc[j] = 0.f;
+        int o = j * kThreads + tid;
+        oc[j] = o < CK ? o / K : 0;
+        ok[j] = o < CK ? o % K : 0;
+    }
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(N, r0 + rows_per_block);
+    for (int n0 = r0; n0 < r1; n0 += NT) {
+        __syncthreads();
+        for (int i = tid; i < NT * C; i += kThreads) {
+            int nn = i / C, c = i % C, n = n0 + nn;
+            As[i] = n < r1 ? A[(size_t)n * lda + c] : 0.f;
+        }
+        for (int i = tid; i < NT * K; i += kThreads) {
+            int nn = i / K, k = i % K, n = n0 + nn;
+            Bs[i] = n < r1 ? B[(size_t)n * ldb + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            if (j * kThreads < CK) {
+                float a = acc[j];
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn) a = fmaf(As[nn * C + oc[j]], Bs[nn * K + ok[j]], a);
+                acc[j] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        int o = j * kThreads + tid;
+        if (o < CK) slabs[(size_t)blockIdx.x * CK + o] = acc[j];
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_colreduce(int mode, float* __restrict__ slabs, const float* __restrict__ A, int lda,
+            const float* __restrict__ B, int ldb, const float* __restrict__ shift, int N, int C,
+            int rows_per_block) {
+    __shared__ float part[kThreads];
+    const int tid = threadIdx.x;
+    const int R = kThreads / C;          // row lanes per column (C <= 256)
+    const int c = tid % C, r = tid / C;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(N, r0 + rows_per_block);
+    float acc = 0.f;
+    if (r < R) {
+        const float sh = (mode == PVS_COL_SUMSQ_SHIFT) ? shift[c] : 0.f;
+        for (int n = r0 + r; n < r1; n += R) {
+            float a = A[(size_t)n * lda + c];
+            if (mode == PVS_COL_SUM_A) acc += a;
+            else if (mode == PVS_COL_SUM_AB) acc = fmaf(a, B[(size_t)n * ldb + c], acc);
+            else { float d = a - sh; acc = fmaf(d, d, acc); }
+        }
+    }
+    part[tid] = acc;
+    __syncthreads();
+    if (tid < C) {
+        float s = 0.f;
+        for (int rr = 0; rr < R; ++rr) s += part[rr * C + tid];
+        slabs[(size_t)blockIdx.x * C + tid] = s;
+    }
+}
+
+__global__ void k_reduce_slabs(float* __restrict__ out, int ldo, int inner,
+                               const float* __restrict__ slabs, int n_slabs, int width, float scale,
+                               int accumulate) {
+    int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= width) return;
+    float s = 0.f;
+    for (int g = 0; g < n_slabs; ++g) s += slabs[(size_t)g * width + o];
+    s *= scale;
+    float* dst = out + (size_t)(o / inner) * ldo + (o % inner);
+    *dst = accumulate ? *dst + s : s;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_mean_pool_fwd(const float* __restrict__ h, const int32_t* __restrict__ gptr,
+                float* __restrict__ pooled, int width) {
+    __shared__ float part[kThreads];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int n0 = gptr[g], n1 = gptr[g + 1];
+    const int R = kThreads / width;
+    const int c = tid % width, r = tid / width;
+    float acc = 0.f;
+    if (r < R)
+        for (int n = n0 + r; n < n1; n += R) acc += h[(size_t)n * width + c];
+    part[tid] = acc;
+    __syncthreads();
+    if (tid < width) {
+        float s = 0.f;
+        for (int rr = 0; rr < R; ++rr) s += part[rr * width + tid];
+        int cnt = n1 - n0;
+        pooled[(size_t)g * width + tid] = s / (float)(cnt > 1 ? cnt : 1);
+    }
+}
+
+__global__ void k_mean_pool_bwd(const float* __restrict__ gp, const int32_t* __restrict__ gptr,
+                                float* __restrict__ gh, int B, int N, int width) {
+    long long total = (long long)N * width;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int n = (int)(i / width), c = (int)(i % width);
+        int lo = 0, hi = B;  // largest g with gptr[g] <= n
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (gptr[mid] <= n) lo = mid; else hi = mid;
+        }
+        int cnt = gptr[lo + 1] - gptr[lo];
+        gh[i] = gp[(size_t)lo * width + c] / (float)(cnt > 1 ? cnt : 1);
+    }
+}
+
+int grid_for(long long work_items, int per_block) {
+    long long b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+}  // namespace
+
+int pvs_reduce_blocks(int N) {
+    int b = (N + kRowsPerBlock - 1) / kRowsPerBlock;
+    if (b < 1) b = 1;
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    return b;
+}
+
+static int rows_per_block_for(int N, int blocks) { return (N + blocks - 1) / blocks; }
+
+int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx, const float* W,
+                      int swc, int swk, const float* b, const float* x2, int ldx2, const float* W2,
+                      int swc2, int swk2, int N, int K, int K2, int C, bool accumulate) {
+    PVS_REQUIRE(C >= 1 && C <= kThreads, "linear: n_out %d unsupported (1..256)", C);
+    if (N <= 0) return 0;
+    const int KK = K + K2;
+    const int NB = kThreads / C > 0 ? kThreads / C : 1;
+    size_t lds = (size_t)(KK * C + NB * KK) * sizeof(float);
+    PVS_REQUIRE(lds <= 160 * 1024, "linear: %d x %d weights do not fit LDS", KK, C);
+    if (lds > 48 * 1024)
+        PVS_CHECK_HIP(hipFuncSetAttribute((const void*)k_linear,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int blocks = grid_for(N, NB * 4);
+    k_linear<<<blocks, kThreads, lds, s>>>(y, ldy, x, ldx, W, swc, swk, b, x2, ldx2, W2, swc2, swk2,
+                                           N, K, K2, C, accumulate ? 1 : 0);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+int pvs_launch_reduce_slabs(hipStream_t s, float* out, int ldo, int inner, const float* slabs,
+                            int n_slabs, int width, bool accumulate) {
+    k_reduce_slabs<<<(width + 255) / 256, 256, 0, s>>>(out, ldo, inner, slabs, n_slabs, width, 1.0f,
+                                                       accumulate ? 1 : 0);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+int pvs_launch_tsgemm_tn(hipStream_t s, float* out, int ldo, const float* A, int lda, const float* B,
+                         int ldb, int N, int C, int K, float* slabs, bool accumulate) {
+    const int CK = C * K;
+    PVS_REQUIRE(CK <= 32 * kThreads, "tsgemm: %d x %d outputs unsupported", C, K);
+    const int blocks = pvs_reduce_blocks(N);
+    const int rpb = rows_per_block_for(N, blocks);
+    size_t lds = (size_t)16 * (C + K) * sizeof(float);
+    if (CK <= 8 * kThreads)
+        k_tsgemm_tn<8><<<blocks, kThreads, lds, s>>>(slabs, A, lda, B, ldb, N, C, K, rpb);
+    else
+        k_tsgemm_tn<32><<<blocks, kThreads, lds, s>>>(slabs, A, lda, B, ldb, N, C, K, rpb);
+    PVS_CHECK_LAUNCH();
+    return pvs_launch_reduce_slabs(s, out, ldo, K, slabs, blocks, CK, accumulate);
+}
+
+int pvs_launch_colreduce(hipStream_t s, int mode, float* out, const float* A, int lda, const float* B,
+                         int ldb, const float* shift, int N, int C, float scale, float* slabs,
+                         bool accumulate) {
+    PVS_REQUIRE(C >= 1 && C <= kThreads, "colreduce: width %d unsupported", C);
+    const int blocks = pvs_reduce_blocks(N);
+    const int rpb = rows_per_block_for(N, blocks);
+    k_colreduce<<<blocks, kThreads, 0, s>>>(mode, slabs, A, lda, B, ldb, shift, N, C, rpb);
+    PVS_CHECK_LAUNCH();
+    k_reduce_slabs<<<(C + 255) / 256, 256, 0, s>>>(out, C, C, slabs, blocks, C, scale,
+                                                   accumulate ? 1 : 0);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int pvs_linear_fwd(const float* x, const float* w, const float* b, float* y, int32_t N,
+                              int32_t K, int32_t C, pvs_stream_t stream) {
+    return pvs_launch_linear((hipStream_t)stream, y, C, x, K, w, K, 1, b, nullptr, 0, nullptr, 0, 0,
+                             N, K, 0, C, false);
+}
+
+extern "C" size_t pvs_linear_bwd_workspace_bytes(int32_t N, int32_t K, int32_t C) {
+    return (size_t)pvs_reduce_blocks(N) * (size_t)C * (size_t)(K > 1 ? K : 1) * sizeof(float) + 256;
+}
+
+extern "C" int pvs_linear_bwd(const float* x, const float* w, const float* g_y, float* g_x,
+                              float* g_w, float* g_b, int32_t N, int32_t K, int32_t C,
+                              void* workspace, size_t workspace_bytes, pvs_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    PVS_REQUIRE(workspace_bytes >= pvs_linear_bwd_workspace_bytes(N, K, C) - 256,
+                "pvs_linear_bwd: workspace too small");
+    float* slabs = (float*)workspace;
+    int rc;
+    if (g_x) {  // g_x[n,k] = sum_c g_y[n,c] W[c,k]
+        rc = pvs_launch_linear(s, g_x, K, g_y, C, w, 1, K, nullptr, nullptr, 0, nullptr, 0, 0, N, C,
+                               0, K, false);
+        if (rc) return rc;
+    }
+    if (g_w) {
+        rc = pvs_launch_tsgemm_tn(s, g_w, K, g_y, C, x, K, N, C, K, slabs, false);
+        if (rc) return rc;
+    }
+    if (g_b) {
+        rc = pvs_launch_colreduce(s, PVS_COL_SUM_A, g_b, g_y, C, nullptr, 0, nullptr, N, C, 1.0f,
+                                  slabs, false);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int pvs_mean_pool_fwd(const float* h, const int32_t* graph_ptr, float* pooled,
+                                 int32_t B, int32_t width, pvs_stream_t stream) {
+    PVS_REQUIRE(width >= 1 && width <= kThreads, "mean_pool: width %d unsupported", width);
+    if (B <= 0) return 0;
+    k_mean_pool_fwd<<<B, kThreads, 0, (hipStream_t)stream>>>(h, graph_ptr, pooled, width);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pvs_mean_pool_bwd(const float* g_pooled, const int32_t* graph_ptr, float* g_h,
+                                 int32_t B, int32_t N, int32_t width, pvs_stream_t stream) {
+    if (N <= 0) return 0;
+    int blocks = grid_for((long long)N * width, 256);
+    k_mean_pool_bwd<<<blocks, 256, 0, (hipStream_t)stream>>>(g_pooled, graph_ptr, g_h, B, N, width);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}

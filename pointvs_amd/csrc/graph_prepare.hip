@@ -1,0 +1,179 @@
+// pvs_graph_prepare: int64 COO + int64 one-hot edge_attr  ->  CSR (by row) + CSC (by col).
+// Once per batch; every layer's forward and backward reuse the result.
+#include "common.h"
+#include <hipcub/hipcub.hpp>
+
+namespace {
+
+__global__ void k_extract(const int64_t* __restrict__ ei, const int64_t* __restrict__ ea, int A,
+                          int N, int E, int32_t* row32, int32_t* col32, int32_t* ids,
+                          uint8_t* etype_in, int32_t* status) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int64_t r = ei[e], c = ei[(size_t)E + e];
+    int bad = 0;
+    if (r < 0 || r >= N || c < 0 || c >= N) { bad |= 1; r = 0; c = 0; }
+    row32[e] = (int32_t)r;
+    col32[e] = (int32_t)c;
+    ids[e] = e;
+    if (A > 0) {
+        int hot = -1, ones = 0, other = 0;
+        for (int a = 0; a < A; ++a) {
+            int64_t v = ea[(size_t)e * A + a];
+            if (v == 1) { ones++; hot = a; }
+            else if (v != 0) other = 1;
+        }
+        if (ones != 1 || other) { bad |= 2; if (hot < 0) hot = 0; }
+        etype_in[e] = (uint8_t)hot;
+    }
+    if (bad) atomicOr(status, bad);
+}
+
+__global__ void k_gather_sorted(const int32_t* __restrict__ perm, const int32_t* __restrict__ col32,
+                                const uint8_t* __restrict__ etype_in, int E, int32_t* col,
+                                uint8_t* etype, int32_t* iota) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= E) return;
+    int e = perm[p];
+    col[p] = col32[e];
+    if (etype) etype[p] = etype_in[e];
+    iota[p] = p;
+}
+
+// ptr[r] = first position p with keys[p] >= r  (keys ascending), r in [0, N]
+__global__ void k_lower_bounds(const int32_t* __restrict__ keys, int E, int N, int32_t* ptr,
+                               float* inv_deg) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > N) return;
+    auto lb = [&](int key) {
+        int lo = 0, hi = E;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    int p0 = lb(r);
+    ptr[r] = p0;
+    if (inv_deg && r < N) {
+        int deg = lb(r + 1) - p0;
+        inv_deg[r] = 1.0f / (float)(deg > 1 ? deg : 1);
+    }
+}
+
+int key_bits(int n) {
+    int b = 1;
+    while ((1ll << b) < (long long)n) ++b;
+    return b;
+}
+
+size_t sort_temp_bytes(int E, int bits) {
+    size_t bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr,
+                                       (const int32_t*)nullptr, (int32_t*)nullptr, E, 0, bits, 0);
+    return bytes;
+}
+
+struct PrepWs {
+    int32_t *row32, *col32, *ids, *iota, *keys_tmp;
+    uint8_t* etype_in;
+    void* sort_tmp;
+    size_t sort_bytes;
+};
+
+size_t carve(PvsArena& a, int N, int E, PrepWs* w) {
+    size_t e = (size_t)(E > 0 ? E : 1);
+    PrepWs t;
+    t.row32 = a.take<int32_t>(e);
+    t.col32 = a.take<int32_t>(e);
+    t.ids = a.take<int32_t>(e);
+    t.iota = a.take<int32_t>(e);
+    t.keys_tmp = a.take<int32_t>(e);
+    t.etype_in = a.take<uint8_t>(e);
+    t.sort_bytes = sort_temp_bytes(E > 0 ? E : 1, key_bits(N > 1 ? N : 2));
+    t.sort_tmp = a.take<char>(t.sort_bytes);
+    if (w) *w = t;
+    return a.off;
+}
+
+}  // namespace
+
+extern "C" size_t pvs_graph_prepare_workspace_bytes(int32_t n_nodes, int32_t n_edges) {
+    PvsArena a(nullptr, 0);
+    return carve(a, n_nodes, n_edges, nullptr) + 256;
+}
+
+extern "C" int pvs_graph_prepare(const int64_t* edge_index, const int64_t* edge_attr,
+                                 int32_t n_edge_attr, int32_t N, int32_t E, int32_t* rowptr,
+                                 int32_t* row, int32_t* col, uint8_t* etype, int32_t* perm,
+                                 int32_t* colptr, int32_t* cedge, float* inv_deg, int32_t* status,
+                                 void* workspace, size_t workspace_bytes, pvs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PVS_REQUIRE(N > 0 && E >= 0, "pvs_graph_prepare: bad sizes N=%d E=%d", N, E);
+    PVS_REQUIRE(n_edge_attr >= 0 && n_edge_attr <= 255, "pvs_graph_prepare: bad n_edge_attr %d",
+                n_edge_attr);
+    PVS_REQUIRE(n_edge_attr == 0 || (edge_attr && etype), "pvs_graph_prepare: edge_attr/etype NULL");
+    PvsArena arena(workspace, workspace_bytes);
+    PrepWs w;
+    carve(arena, N, E, &w);
+    PVS_REQUIRE(arena.ok(), "pvs_graph_prepare: workspace too small (%zu < %zu)", workspace_bytes,
+                arena.off);
+    PVS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), stream));
+    const int bits = key_bits(N > 1 ? N : 2);
+    const int T = 256;
+    if (E > 0) {
+        k_extract<<<(E + T - 1) / T, T, 0, stream>>>(edge_index, edge_attr, n_edge_attr, N, E,
+                                                     w.row32, w.col32, w.ids, w.etype_in, status);
+        PVS_CHECK_LAUNCH();
+        size_t tb = w.sort_bytes;
+        PVS_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(w.sort_tmp, tb, w.row32, row, w.ids, perm,
+                                                         E, 0, bits, stream));
+        k_gather_sorted<<<(E + T - 1) / T, T, 0, stream>>>(perm, w.col32, w.etype_in, E, col,
+                                                           n_edge_attr ? etype : nullptr, w.iota);
+        PVS_CHECK_LAUNCH();
+        tb = w.sort_bytes;
+        PVS_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(w.sort_tmp, tb, col, w.keys_tmp, w.iota,
+                                                         cedge, E, 0, bits, stream));
+    }
+    k_lower_bounds<<<(N + 1 + T - 1) / T, T, 0, stream>>>(row, E, N, rowptr, inv_deg);
+    PVS_CHECK_LAUNCH();
+    k_lower_bounds<<<(N + 1 + T - 1) / T, T, 0, stream>>>(w.keys_tmp, E, N, colptr, nullptr);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+namespace {
+template <bool TO_INPUT>
+__global__ void k_permute_rows(const float* __restrict__ src, float* __restrict__ dst,
+                               const int32_t* __restrict__ perm, int E, int width) {
+    // one thread per float4 (or scalar tail) of a row
+    long long total = (long long)E * width;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int e = (int)(i / width), c = (int)(i % width);
+        int o = perm[e];
+        if (TO_INPUT) dst[(size_t)o * width + c] = src[i];
+        else dst[i] = src[(size_t)o * width + c];
+    }
+}
+}  // namespace
+
+extern "C" int pvs_rows_to_input_order(const float* src, float* dst, const int32_t* perm,
+                                       int32_t E, int32_t width, pvs_stream_t stream) {
+    if (E <= 0) return 0;
+    long long total = (long long)E * width;
+    int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    k_permute_rows<true><<<blocks, 256, 0, (hipStream_t)stream>>>(src, dst, perm, E, width);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pvs_rows_to_sorted_order(const float* src, float* dst, const int32_t* perm,
+                                        int32_t E, int32_t width, pvs_stream_t stream) {
+    if (E <= 0) return 0;
+    long long total = (long long)E * width;
+    int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    k_permute_rows<false><<<blocks, 256, 0, (hipStream_t)stream>>>(src, dst, perm, E, width);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}

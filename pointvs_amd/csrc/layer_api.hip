@@ -1,0 +1,355 @@
+// C ABI of one EGNNLayer forward / backward: sequences the kernels on the caller's stream.
+// Reference: EGNNLayer.forward, /root/reference/point_vs/models/geometric/egnn_satorras.py:189-206.
+#include "common.h"
+#include "dense_ops.h"
+#include "edge_kernels.h"
+#include "node_ops.h"
+
+namespace {
+
+struct Dims {
+    int N, E, H, A, ld1, off_rho, off_q;
+    bool perm;
+};
+
+Dims make_dims(const PvsLayerDesc* d, const PvsGraph* g) {
+    Dims m;
+    m.N = g->n_nodes; m.E = g->n_edges; m.H = d->hidden; m.A = d->n_edge_attr;
+    m.perm = d->flags & PVS_PERM_INVARIANT;
+    m.off_rho = m.perm ? m.H : 2 * m.H;
+    m.off_q = m.perm ? 0 : m.H;
+    m.ld1 = m.off_rho + 1 + m.A;
+    return m;
+}
+
+PvsEdgeW make_edge_w(const Dims& m, const PvsLayerParams* p) {
+    PvsEdgeW w;
+    w.w1 = p->edge_w1; w.ld1 = m.ld1; w.off_rho = m.off_rho;
+    w.w2 = p->edge_w2; w.b2 = p->edge_b2;
+    w.wc1 = p->coord_w1; w.bc1 = p->coord_b1; w.wc2 = p->coord_w2;
+    w.wa = p->att_w; w.ba = p->att_b; w.edge_gate = p->edge_gate; w.n_attr = m.A;
+    return w;
+}
+
+PvsNodeW make_node_w(const PvsLayerDesc* d, const PvsLayerParams* p) {
+    PvsNodeW w;
+    const bool gn = d->flags & PVS_GRAPHNORM, na = d->flags & PVS_NODE_ATTENTION;
+    w.gn_w = gn ? p->gn_weight : nullptr;
+    w.gn_b = gn ? p->gn_bias : nullptr;
+    w.gn_ms = gn ? p->gn_mean_scale : nullptr;
+    w.natt_w = na ? p->node_att_w : nullptr;
+    w.natt_b = na ? p->node_att_b : nullptr;
+    w.node_gate = p->node_gate;
+    return w;
+}
+
+int check_desc(const PvsLayerDesc* d, const PvsGraph* g, const PvsLayerParams* p) {
+    PVS_REQUIRE(d && g && p, "NULL descriptor/graph/params");
+    PVS_REQUIRE(pvs_edge_v0_supported(d->hidden),
+                "hidden size %d unsupported by this build (8, 16, 32, 64)", d->hidden);
+    PVS_REQUIRE(d->n_edge_attr >= 0 && d->n_edge_attr <= PVS_MAX_EDGE_ATTR,
+                "n_edge_attr %d unsupported (0..%d)", d->n_edge_attr, PVS_MAX_EDGE_ATTR);
+    PVS_REQUIRE(!((d->flags & PVS_GATED_RESIDUAL) && (d->flags & PVS_REZERO)),
+                "gated_residual and rezero are incompatible");
+    PVS_REQUIRE(g->n_nodes > 0 && g->n_edges >= 0, "bad graph sizes");
+    PVS_REQUIRE(d->n_edge_attr == 0 || g->etype, "graph has no edge types but layer expects %d",
+                d->n_edge_attr);
+    PVS_REQUIRE(p->edge_w1 && p->edge_b1 && p->edge_w2 && p->edge_b2 && p->node_w1 && p->node_b1 &&
+                p->node_w2 && p->node_b2, "missing edge/node MLP parameters");
+    if (d->flags & PVS_UPDATE_COORDS)
+        PVS_REQUIRE(p->coord_w1 && p->coord_b1 && p->coord_w2, "missing coord MLP parameters");
+    if (d->flags & PVS_EDGE_ATTENTION) PVS_REQUIRE(p->att_w && p->att_b, "missing att_mlp");
+    if (d->flags & PVS_NODE_ATTENTION)
+        PVS_REQUIRE(p->node_att_w && p->node_att_b, "missing node_att_mlp");
+    if (d->flags & PVS_GRAPHNORM)
+        PVS_REQUIRE(p->gn_weight && p->gn_bias && p->gn_mean_scale, "missing graphnorm parameters");
+    if ((d->flags & PVS_RESIDUAL) && (d->flags & (PVS_REZERO | PVS_GATED_RESIDUAL)))
+        PVS_REQUIRE(p->node_gate, "missing node_gate_parameter");
+    return 0;
+}
+
+struct FwdWs {
+    float *PQ, *y1, *u, *o, *smax, *ssum, *shift, *slabs;
+};
+
+size_t carve_fwd(PvsArena& a, const Dims& m, FwdWs* w) {
+    const size_t NH = (size_t)m.N * m.H;
+    FwdWs t;
+    t.PQ = a.take<float>(2 * NH);
+    t.y1 = a.take<float>(NH);
+    t.u = a.take<float>(NH);
+    t.o = a.take<float>(NH);
+    t.smax = a.take<float>(m.N);
+    t.ssum = a.take<float>(m.N);
+    t.shift = a.take<float>(m.H);
+    t.slabs = a.take<float>((size_t)pvs_reduce_blocks(m.N) * m.H);
+    if (w) *w = t;
+    return a.off;
+}
+
+struct BwdWs {
+    float *PQ, *y1, *u, *o, *g_o, *g_u, *gM, *t1, *tg, *gl, *gxagg, *softD, *gPQ, *gz1, *gd, *gx_row;
+    float *eslabs, *gsum, *dslabs, *S1, *S2, *coefs, *gvec;
+};
+
+size_t carve_bwd(PvsArena& a, const Dims& m, BwdWs* w) {
+    const size_t NH = (size_t)m.N * m.H;
+    const PvsSlabLayout L = pvs_slab_layout(m.H);
+    BwdWs t;
+    t.PQ = a.take<float>(2 * NH);
+    t.y1 = a.take<float>(NH);
+    t.u = a.take<float>(NH);
+    t.o = a.take<float>(NH);
+    t.g_o = a.take<float>(NH);
+    t.g_u = a.take<float>(NH);
+    t.gM = a.take<float>(NH);
+    t.t1 = a.take<float>(NH);
+    t.tg = a.take<float>(NH);
+    t.gl = a.take<float>(m.N);
+    t.gxagg = a.take<float>(3 * (size_t)m.N);
+    t.softD = a.take<float>(m.N);
+    t.gPQ = a.take<float>(2 * NH);
+    t.gz1 = a.take<float>((size_t)(m.E > 0 ? m.E : 1) * m.H);
+    t.gd = a.take<float>(3 * (size_t)(m.E > 0 ? m.E : 1));
+    t.gx_row = a.take<float>(3 * (size_t)m.N);
+    t.eslabs = a.take<float>((size_t)512 * L.total);
+    t.gsum = a.take<float>(L.total);
+    t.dslabs = a.take<float>((size_t)pvs_reduce_blocks(m.N) * m.H * m.H);
+    t.S1 = a.take<float>(m.H);
+    t.S2 = a.take<float>(m.H);
+    t.coefs = a.take<float>(3 * (size_t)m.H);
+    t.gvec = a.take<float>(m.H);
+    if (w) *w = t;
+    return a.off;
+}
+
+// scatter the reduced edge-kernel slab into the parameter gradients
+__global__ void k_finalize_edge_grads(const float* __restrict__ gsum, PvsSlabLayout L, int H, int A,
+                                      int ld1, int off_rho, PvsLayerGrads gr, int has_coord,
+                                      int has_att, int has_gate) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = tid; i < H * H; i += stride) {
+        if (gr.edge_w2) gr.edge_w2[i] = gsum[L.w2 + i];
+        if (has_coord && gr.coord_w1) gr.coord_w1[i] = gsum[L.wc1 + i];
+    }
+    for (int c = tid; c < H; c += stride) {
+        if (gr.edge_b2) gr.edge_b2[c] = gsum[L.b2 + c];
+        if (has_coord && gr.coord_b1) gr.coord_b1[c] = gsum[L.bc1 + c];
+        if (has_coord && gr.coord_w2) gr.coord_w2[c] = gsum[L.wc2 + c];
+        if (has_att && gr.att_w) gr.att_w[c] = gsum[L.wa + c];
+        if (gr.edge_w1) {
+            gr.edge_w1[(size_t)c * ld1 + off_rho] = gsum[L.wrho + c];
+            for (int t = 0; t < A; ++t)
+                gr.edge_w1[(size_t)c * ld1 + off_rho + 1 + t] = gsum[L.wattr + t * H + c];
+        }
+    }
+    if (tid == 0) {
+        if (has_att && gr.att_b) gr.att_b[0] = gsum[L.ba];
+        if (has_gate && gr.edge_gate) gr.edge_gate[0] = gsum[L.gate];
+    }
+}
+
+#define PVS_TRY(call)             \
+    do {                          \
+        int _rc = (call);         \
+        if (_rc) return _rc;      \
+    } while (0)
+
+// y1 = [h | Magg] Wn1^T + bn1 ; (graphnorm stats) ; u = SiLU(GN(y1)) ; o = u Wn2^T + bn2
+int node_mlp_forward(hipStream_t s, const Dims& m, const PvsLayerDesc* d, const PvsLayerParams* p,
+                     const PvsNodeW& nw, const float* h, const float* Magg, float* y1, float* u,
+                     float* o, float* stats, bool compute_stats, float* shift_tmp, float* slabs) {
+    const int H = m.H;
+    PVS_TRY(pvs_launch_linear(s, y1, H, h, H, p->node_w1, 2 * H, 1, p->node_b1, Magg, H,
+                              p->node_w1 + H, 2 * H, 1, m.N, H, H, H, false));
+    if ((d->flags & PVS_GRAPHNORM) && compute_stats)
+        PVS_TRY(pvs_graphnorm_stats(s, y1, p->gn_mean_scale, m.N, H, stats, shift_tmp, slabs));
+    PVS_TRY(pvs_node_tail_fwd(s, y1, stats, nw, m.N, H, u));
+    PVS_TRY(pvs_launch_linear(s, o, H, u, H, p->node_w2, H, 1, p->node_b2, nullptr, 0, nullptr, 0, 0,
+                              m.N, H, 0, H, false));
+    return 0;
+}
+
+int node_pre_forward(hipStream_t s, const Dims& m, const PvsLayerParams* p, const float* h,
+                     float* PQ) {
+    const int H = m.H;
+    // P = W1[:, 0:H] h + b1 (row part), Q = W1[:, off_q:off_q+H] h (col part)
+    PVS_TRY(pvs_launch_linear(s, PQ, 2 * H, h, H, p->edge_w1, m.ld1, 1, p->edge_b1, nullptr, 0,
+                              nullptr, 0, 0, m.N, H, 0, H, false));
+    PVS_TRY(pvs_launch_linear(s, PQ + H, 2 * H, h, H, p->edge_w1 + m.off_q, m.ld1, 1, nullptr,
+                              nullptr, 0, nullptr, 0, 0, m.N, H, 0, H, false));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t pvs_egnn_layer_saved_floats(const PvsLayerDesc* d, int32_t N, int32_t E) {
+    (void)E;
+    return (size_t)N * d->hidden + 2 * (size_t)d->hidden;
+}
+
+extern "C" size_t pvs_egnn_layer_workspace_bytes(const PvsLayerDesc* d, int32_t N, int32_t E,
+                                                 int32_t backward) {
+    PvsGraph g{};
+    g.n_nodes = N; g.n_edges = E;
+    Dims m = make_dims(d, &g);
+    PvsArena a(nullptr, 0);
+    return (backward ? carve_bwd(a, m, nullptr) : carve_fwd(a, m, nullptr)) + 256;
+}
+
+extern "C" int pvs_egnn_layer_fwd(const PvsLayerDesc* d, const PvsGraph* g, const PvsLayerParams* p,
+                                  const float* h, const float* x, const float* m_prev, float* h_out,
+                                  float* x_out, float* m_out, float* att_out, float* node_att_out,
+                                  float* saved, void* workspace, size_t workspace_bytes,
+                                  pvs_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    PVS_TRY(check_desc(d, g, p));
+    PVS_REQUIRE(h && x && h_out && x_out && saved, "pvs_egnn_layer_fwd: NULL tensor");
+    PVS_REQUIRE(x_out != x, "pvs_egnn_layer_fwd: x_out must not alias x");
+    const bool eatt = d->flags & PVS_EDGE_ATTENTION;
+    PVS_REQUIRE(!eatt || att_out, "pvs_egnn_layer_fwd: att_out required with edge attention");
+    const Dims m = make_dims(d, g);
+    PvsArena arena(workspace, workspace_bytes);
+    FwdWs w;
+    carve_fwd(arena, m, &w);
+    PVS_REQUIRE(arena.ok(), "pvs_egnn_layer_fwd: workspace too small (%zu < %zu)", workspace_bytes,
+                arena.off);
+    const int H = m.H;
+    float* Magg = saved;
+    float* stats = saved + (size_t)m.N * H;
+    const PvsEdgeW ew = make_edge_w(m, p);
+    const PvsNodeW nw = make_node_w(d, p);
+
+    PVS_TRY(node_pre_forward(s, m, p, h, w.PQ));
+    PvsEdgeFwdIO io;
+    io.PQ = w.PQ; io.x = x; io.m_prev = m_prev; io.Magg = Magg; io.x_out = x_out; io.m_out = m_out;
+    io.att_out = att_out; io.smax = w.smax; io.ssum = w.ssum;
+    PVS_TRY(pvs_launch_edge_fwd_v0(s, H, *g, ew, d->flags, d->att_act, io));
+    if (!(d->flags & PVS_UPDATE_COORDS))
+        PVS_CHECK_HIP(hipMemcpyAsync(x_out, x, sizeof(float) * 3 * (size_t)m.N,
+                                     hipMemcpyDeviceToDevice, s));
+    PVS_TRY(node_mlp_forward(s, m, d, p, nw, h, Magg, w.y1, w.u, w.o, stats, true, w.shift, w.slabs));
+    PVS_TRY(pvs_node_out_fwd(s, H, w.o, h, nw, d->flags, d->att_act, m.N, h_out, node_att_out));
+    return 0;
+}
+
+extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, const PvsLayerParams* p,
+                                  const float* h, const float* x, const float* m_prev,
+                                  const float* att, const float* saved, const float* g_h_out,
+                                  const float* g_x_out, const float* g_m_out, float* g_h, float* g_x,
+                                  float* g_m_prev, const PvsLayerGrads* gr_, void* workspace,
+                                  size_t workspace_bytes, pvs_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    PVS_TRY(check_desc(d, g, p));
+    PVS_REQUIRE(h && x && saved && g_h_out && g_h && gr_, "pvs_egnn_layer_bwd: NULL tensor");
+    const uint32_t F = d->flags;
+    const bool eatt = F & PVS_EDGE_ATTENTION, soft = F & PVS_SOFTMAX_ATT;
+    const bool eres = (F & PVS_EDGE_RESIDUAL) && m_prev;
+    PVS_REQUIRE(!eatt || att, "pvs_egnn_layer_bwd: att required with edge attention");
+    PVS_REQUIRE(!eres || g_m_prev, "pvs_egnn_layer_bwd: g_m_prev required with edge residual");
+    const PvsLayerGrads gr = *gr_;
+    const Dims m = make_dims(d, g);
+    PvsArena arena(workspace, workspace_bytes);
+    BwdWs w;
+    carve_bwd(arena, m, &w);
+    PVS_REQUIRE(arena.ok(), "pvs_egnn_layer_bwd: workspace too small (%zu < %zu)", workspace_bytes,
+                arena.off);
+    const int H = m.H, N = m.N;
+    const float* Magg = saved;
+    float* stats = const_cast<float*>(saved) + (size_t)N * H;   // read-only here
+    const PvsEdgeW ew = make_edge_w(m, p);
+    const PvsNodeW nw = make_node_w(d, p);
+    const bool gn = F & PVS_GRAPHNORM, natt = F & PVS_NODE_ATTENTION;
+    const bool gates = (F & PVS_RESIDUAL) && (F & (PVS_REZERO | PVS_GATED_RESIDUAL));
+    const bool coord_bwd = (F & PVS_UPDATE_COORDS) && g_x_out;
+
+    // ---- recompute the node-level forward (cheap: N rows) ----
+    PVS_TRY(node_pre_forward(s, m, p, h, w.PQ));
+    PVS_TRY(node_mlp_forward(s, m, d, p, nw, h, Magg, w.y1, w.u, w.o, stats, false, nullptr, nullptr));
+
+    // ---- node_model backward ----
+    PVS_TRY(pvs_node_out_bwd(s, H, g_h_out, w.o, h, nw, F, d->att_act, N, w.g_o, g_h, w.gl, w.t1,
+                             w.tg));
+    if (natt) {
+        if (gr.node_att_w)
+            PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.node_att_w, w.t1, H, nullptr, 0, nullptr,
+                                         N, H, 1.f, w.dslabs, false));
+        if (gr.node_att_b)
+            PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.node_att_b, w.gl, 1, nullptr, 0, nullptr,
+                                         N, 1, 1.f, w.dslabs, false));
+    }
+    if (gates && gr.node_gate) {
+        PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, w.gvec, w.tg, H, nullptr, 0, nullptr, N, H, 1.f,
+                                     w.dslabs, false));
+        PVS_TRY(pvs_sum_vec(s, w.gvec, H, gr.node_gate));
+    }
+    // o = u Wn2^T + bn2
+    PVS_TRY(pvs_launch_linear(s, w.g_u, H, w.g_o, H, p->node_w2, 1, H, nullptr, nullptr, 0, nullptr, 0,
+                              0, N, H, 0, H, false));
+    if (gr.node_w2)
+        PVS_TRY(pvs_launch_tsgemm_tn(s, gr.node_w2, H, w.g_o, H, w.u, H, N, H, H, w.dslabs, false));
+    if (gr.node_b2)
+        PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.node_b2, w.g_o, H, nullptr, 0, nullptr, N, H,
+                                     1.f, w.dslabs, false));
+    // u = SiLU(GN(y1)) ; g_u becomes g_yn then g_y1 in place
+    PVS_TRY(pvs_node_tail_bwd1(s, w.g_u, w.y1, stats, nw, N, H, w.g_u));
+    if (gn) {
+        PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, w.S1, w.g_u, H, nullptr, 0, nullptr, N, H, 1.f,
+                                     w.dslabs, false));
+        PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_AB, w.S2, w.g_u, H, w.y1, H, nullptr, N, H, 1.f,
+                                     w.dslabs, false));
+        PVS_TRY(pvs_graphnorm_bwd_coefs(s, w.S1, w.S2, stats, nw, N, H, gr.gn_weight, gr.gn_bias,
+                                        gr.gn_mean_scale, w.coefs));
+        PVS_TRY(pvs_node_tail_bwd2(s, w.g_u, w.y1, stats, nw, w.coefs, N, H, w.g_u));
+    }
+    float* g_y1 = w.g_u;
+    // y1 = h Wn1[:, :H]^T + Magg Wn1[:, H:]^T + bn1
+    PVS_TRY(pvs_launch_linear(s, g_h, H, g_y1, H, p->node_w1, 1, 2 * H, nullptr, nullptr, 0, nullptr,
+                              0, 0, N, H, 0, H, true));
+    PVS_TRY(pvs_launch_linear(s, w.gM, H, g_y1, H, p->node_w1 + H, 1, 2 * H, nullptr, nullptr, 0,
+                              nullptr, 0, 0, N, H, 0, H, false));
+    if (gr.node_w1) {
+        PVS_TRY(pvs_launch_tsgemm_tn(s, gr.node_w1, 2 * H, g_y1, H, h, H, N, H, H, w.dslabs, false));
+        PVS_TRY(pvs_launch_tsgemm_tn(s, gr.node_w1 + H, 2 * H, g_y1, H, Magg, H, N, H, H, w.dslabs,
+                                     false));
+    }
+    if (gr.node_b1)
+        PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.node_b1, g_y1, H, nullptr, 0, nullptr, N, H,
+                                     1.f, w.dslabs, false));
+
+    // ---- edge backward ----
+    PVS_TRY(pvs_prep_edge_bwd(s, g_x_out, g->inv_deg, Magg, w.gM, N, H,
+                              coord_bwd ? w.gxagg : nullptr, (eatt && soft) ? w.softD : nullptr));
+    PvsEdgeBwdIO io;
+    io.PQ = w.PQ; io.x = x; io.m_prev = m_prev; io.att = att; io.gM = w.gM;
+    io.gxagg = coord_bwd ? w.gxagg : nullptr;
+    io.softD = (eatt && soft) ? w.softD : nullptr;
+    io.g_m_out = g_m_out; io.gPQ = w.gPQ; io.gz1 = w.gz1; io.gd = w.gd; io.gx_row = w.gx_row;
+    io.g_m_prev = eres ? g_m_prev : nullptr; io.slabs = w.eslabs;
+    int n_slabs = 0;
+    PVS_TRY(pvs_launch_edge_bwd_v0(s, H, *g, ew, F, d->att_act, io, &n_slabs));
+    PVS_TRY(pvs_launch_col_gather(s, H, *g, w.gz1, w.gd, w.gx_row, g_x_out, w.gPQ, g_x));
+    const PvsSlabLayout L = pvs_slab_layout(H);
+    PVS_TRY(pvs_launch_reduce_slabs(s, w.gsum, L.total, L.total, w.eslabs, n_slabs, L.total, false));
+
+    // ---- first edge-MLP layer at node level: P = W1a h + b1, Q = W1b h ----
+    PVS_TRY(pvs_launch_linear(s, g_h, H, w.gPQ, 2 * H, p->edge_w1, 1, m.ld1, nullptr, nullptr, 0,
+                              nullptr, 0, 0, N, H, 0, H, true));
+    PVS_TRY(pvs_launch_linear(s, g_h, H, w.gPQ + H, 2 * H, p->edge_w1 + m.off_q, 1, m.ld1, nullptr,
+                              nullptr, 0, nullptr, 0, 0, N, H, 0, H, true));
+    if (gr.edge_w1) {
+        PVS_TRY(pvs_launch_tsgemm_tn(s, gr.edge_w1, m.ld1, w.gPQ, 2 * H, h, H, N, H, H, w.dslabs,
+                                     false));
+        PVS_TRY(pvs_launch_tsgemm_tn(s, gr.edge_w1 + m.off_q, m.ld1, w.gPQ + H, 2 * H, h, H, N, H, H,
+                                     w.dslabs, m.perm));
+    }
+    if (gr.edge_b1)
+        PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.edge_b1, w.gPQ, 2 * H, nullptr, 0, nullptr,
+                                     N, H, 1.f, w.dslabs, false));
+    k_finalize_edge_grads<<<4, 256, 0, s>>>(w.gsum, L, H, m.A, m.ld1, m.off_rho, gr,
+                                            coord_bwd ? 1 : 0, eatt ? 1 : 0,
+                                            (eres && (F & (PVS_REZERO | PVS_GATED_RESIDUAL))) ? 1 : 0);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,296 @@
+#include "node_ops.h"
+
+namespace {
+
+constexpr float kGnEps = 1e-5f;   // torch_geometric GraphNorm default eps
+
+__global__ void k_gn_shift(const float* mean, const float* ms, int H, float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < H) shift[c] = mean[c] * ms[c];
+}
+
+__device__ __forceinline__ float gn_apply(float y, int c, const float* stats, const PvsNodeW& w, int H) {
+    if (!w.gn_w) return y;
+    const float shift = stats[c] * w.gn_ms[c];
+    const float rstd = 1.0f / sqrtf(stats[H + c] + kGnEps);
+    return w.gn_w[c] * (y - shift) * rstd + w.gn_b[c];
+}
+
+__global__ void k_node_tail_fwd(const float* __restrict__ y1, const float* __restrict__ stats,
+                                PvsNodeW w, int N, int H, float* __restrict__ u) {
+    long long total = (long long)N * H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % H);
+        u[i] = pvs_silu(gn_apply(y1[i], c, stats, w, H));
+    }
+}
+
+template <int H>
+__global__ void __launch_bounds__(256)
+k_node_out_fwd(const float* __restrict__ o, const float* __restrict__ h, PvsNodeW w, uint32_t flags,
+               int att_act, int N, float* __restrict__ h_out, float* __restrict__ natt_out) {
+    constexpr int NPW = 64 / H;
+    const int lane = threadIdx.x & 63;
+    const int c = lane % H, sub = lane / H;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    const bool natt = flags & PVS_NODE_ATTENTION;
+    const float wna = natt ? w.natt_w[c] : 0.f;
+    const float bna = natt ? w.natt_b[0] : 0.f;
+    float gate = 1.f;
+    if ((flags & PVS_RESIDUAL) && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
+        gate = w.node_gate[0];
+        if (flags & PVS_GATED_RESIDUAL) gate = fmaxf(gate, 0.f);
+    }
+    for (int nb = wave * NPW; nb < N; nb += n_waves * NPW) {
+        const int n = nb + sub;
+        const bool valid = n < N;
+        const int nn = valid ? n : N - 1;
+        float ov = o[(size_t)nn * H + c];
+        if (natt) {
+            const float l = pvs_group_sum<H>(wna * ov) + bna;
+            const float a = pvs_att_act(att_act, l);
+            ov *= a;
+            if (natt_out && valid && c == 0) natt_out[n] = a;
+        }
+        float r = ov;
+        if (flags & PVS_RESIDUAL) {
+            const float hv = h[(size_t)nn * H + c];
+            if (flags & PVS_REZERO) r = hv + gate * ov;
+            else if (flags & PVS_GATED_RESIDUAL) r = gate * ov + (1.f - gate) * hv;
+            else r = hv + ov;
+        }
+        if (valid) h_out[(size_t)n * H + c] = r;
+    }
+}
+
+template <int H>
+__global__ void __launch_bounds__(256)
+k_node_out_bwd(const float* __restrict__ g_hout, const float* __restrict__ o,
+               const float* __restrict__ h, PvsNodeW w, uint32_t flags, int att_act, int N,
+               float* __restrict__ g_o, float* __restrict__ g_h, float* __restrict__ gl,
+               float* __restrict__ t1, float* __restrict__ tg) {
+    constexpr int NPW = 64 / H;
+    const int lane = threadIdx.x & 63;
+    const int c = lane % H, sub = lane / H;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    const bool natt = flags & PVS_NODE_ATTENTION;
+    const bool res = flags & PVS_RESIDUAL;
+    const float wna = natt ? w.natt_w[c] : 0.f;
+    const float bna = natt ? w.natt_b[0] : 0.f;
+    float gate_raw = 0.f, gate = 1.f;
+    const bool gated = res && (flags & PVS_GATED_RESIDUAL), rez = res && (flags & PVS_REZERO);
+    if (gated || rez) {
+        gate_raw = w.node_gate[0];
+        gate = gated ? fmaxf(gate_raw, 0.f) : gate_raw;
+    }
+    for (int nb = wave * NPW; nb < N; nb += n_waves * NPW) {
+        const int n = nb + sub;
+        const bool valid = n < N;
+        const int nn = valid ? n : N - 1;
+        const size_t idx = (size_t)nn * H + c;
+        const float go = g_hout[idx];
+        const float ov = o[idx];
+        float l = 0.f, a = 1.f;
+        if (natt) {
+            l = pvs_group_sum<H>(wna * ov) + bna;
+            a = pvs_att_act(att_act, l);
+        }
+        const float o2 = ov * a;    // value entering the residual
+        // residual
+        float g_o2 = go, g_hres = 0.f, g_gate_el = 0.f;
+        if (res) {
+            if (rez) { g_o2 = gate * go; g_hres = go; g_gate_el = go * o2; }
+            else if (gated) {
+                g_o2 = gate * go; g_hres = (1.f - gate) * go;
+                g_gate_el = gate_raw > 0.f ? go * (o2 - h[idx]) : 0.f;
+            } else { g_hres = go; }
+        }
+        // node attention: o2 = ov * a(l), l = wna . ov + bna
+        float g_ov = g_o2, g_l = 0.f;
+        if (natt) {
+            const float dot = pvs_group_sum<H>(g_o2 * ov);
+            g_l = pvs_att_act_grad(att_act, l, a) * dot;
+            g_ov = g_o2 * a + g_l * wna;
+        }
+        if (valid) {
+            g_o[idx] = g_ov;
+            g_h[idx] = g_hres;
+            if (natt) { t1[idx] = g_l * ov; if (c == 0) gl[n] = g_l; }
+            if (gated || rez) tg[idx] = g_gate_el;
+        }
+    }
+}
+
+__global__ void k_node_tail_bwd1(const float* __restrict__ g_u, const float* __restrict__ y1,
+                                 const float* __restrict__ stats, PvsNodeW w, int N, int H,
+                                 float* __restrict__ g_yn) {
+    long long total = (long long)N * H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % H);
+        const float yn = gn_apply(y1[i], c, stats, w, H);
+        g_yn[i] = g_u[i] * pvs_silu_grad(yn, pvs_sigmoid(yn));
+    }
+}
+
+// yn = gw*cc*rstd + gb, cc = y1 - ms*mean, var = mean(cc^2)
+__global__ void k_gn_bwd_coefs(const float* S1, const float* S2raw, const float* stats, PvsNodeW w,
+                               int N, int H, float* g_w, float* g_b, float* g_ms, float* coefs) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= H) return;
+    const float mean = stats[c], var = stats[H + c];
+    const float ms = w.gn_ms[c], gw = w.gn_w[c];
+    const float shift = mean * ms;
+    const float rstd = 1.0f / sqrtf(var + kGnEps);
+    const float s1 = S1[c];                  // sum g_yn
+    const float s2 = S2raw[c] - shift * s1;  // sum g_yn * cc
+    const float g_var = -0.5f * gw * rstd * rstd * rstd * s2;
+    const float sum_cc = (float)N * (mean - shift);
+    const float sum_gc = gw * rstd * s1 + g_var * 2.0f * sum_cc / (float)N;
+    const float g_shift = -sum_gc;
+    if (g_w) g_w[c] = s2 * rstd;
+    if (g_b) g_b[c] = s1;
+    if (g_ms) g_ms[c] = g_shift * mean;
+    const float g_mean = g_shift * ms;
+    coefs[c] = gw * rstd;
+    coefs[H + c] = 2.0f * g_var / (float)N;
+    coefs[2 * H + c] = g_mean / (float)N;
+}
+
+__global__ void k_node_tail_bwd2(const float* __restrict__ g_yn, const float* __restrict__ y1,
+                                 const float* __restrict__ stats, PvsNodeW w,
+                                 const float* __restrict__ coefs, int N, int H,
+                                 float* __restrict__ g_y1) {
+    long long total = (long long)N * H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % H);
+        const float shift = stats[c] * w.gn_ms[c];
+        g_y1[i] = g_yn[i] * coefs[c] + (y1[i] - shift) * coefs[H + c] + coefs[2 * H + c];
+    }
+}
+
+__global__ void k_prep_edge_bwd(const float* __restrict__ g_x_out, const float* __restrict__ inv_deg,
+                                const float* __restrict__ Magg, const float* __restrict__ gM, int N,
+                                int H, float* __restrict__ gxagg, float* __restrict__ softD) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    if (gxagg) {
+        const float inv = inv_deg[n];
+        gxagg[3 * n] = g_x_out[3 * n] * inv;
+        gxagg[3 * n + 1] = g_x_out[3 * n + 1] * inv;
+        gxagg[3 * n + 2] = g_x_out[3 * n + 2] * inv;
+    }
+    if (softD) {
+        float d = 0.f;
+        for (int c = 0; c < H; ++c) d = fmaf(Magg[(size_t)n * H + c], gM[(size_t)n * H + c], d);
+        softD[n] = d;
+    }
+}
+
+__global__ void k_sum_vec(const float* v, int n, float* out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += v[i];
+        out[0] = s;
+    }
+}
+
+int ew_grid(long long total) {
+    long long b = (total + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 4096) b = 4096;
+    return (int)b;
+}
+
+}  // namespace
+
+#include "dense_ops.h"
+
+int pvs_graphnorm_stats(hipStream_t s, const float* y1, const float* gn_ms, int N, int H, float* stats,
+                        float* shift_tmp, float* slabs) {
+    int rc = pvs_launch_colreduce(s, PVS_COL_SUM_A, stats, y1, H, nullptr, 0, nullptr, N, H,
+                                  1.0f / (float)N, slabs, false);
+    if (rc) return rc;
+    k_gn_shift<<<(H + 63) / 64, 64, 0, s>>>(stats, gn_ms, H, shift_tmp);
+    PVS_CHECK_LAUNCH();
+    return pvs_launch_colreduce(s, PVS_COL_SUMSQ_SHIFT, stats + H, y1, H, nullptr, 0, shift_tmp, N, H,
+                                1.0f / (float)N, slabs, false);
+}
+
+int pvs_node_tail_fwd(hipStream_t s, const float* y1, const float* stats, const PvsNodeW& w, int N,
+                      int H, float* u) {
+    k_node_tail_fwd<<<ew_grid((long long)N * H), 256, 0, s>>>(y1, stats, w, N, H, u);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+#define PVS_NODE_DISPATCH_H(H, ...)                                    \
+    switch (H) {                                                       \
+        case 8: { constexpr int HH = 8; __VA_ARGS__; break; }          \
+        case 16: { constexpr int HH = 16; __VA_ARGS__; break; }        \
+        case 32: { constexpr int HH = 32; __VA_ARGS__; break; }        \
+        case 64: { constexpr int HH = 64; __VA_ARGS__; break; }        \
+        default: pvs_set_error("node kernels: hidden size %d unsupported (8,16,32,64)", H); return -1; \
+    }
+
+int pvs_node_out_fwd(hipStream_t s, int H, const float* o, const float* h, const PvsNodeW& w,
+                     uint32_t flags, int att_act, int N, float* h_out, float* natt_out) {
+    const int blocks = ew_grid((long long)N * H);
+    PVS_NODE_DISPATCH_H(H, {
+        k_node_out_fwd<HH><<<blocks, 256, 0, s>>>(o, h, w, flags, att_act, N, h_out, natt_out);
+    });
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+int pvs_node_out_bwd(hipStream_t s, int H, const float* g_hout, const float* o, const float* h,
+                     const PvsNodeW& w, uint32_t flags, int att_act, int N, float* g_o, float* g_h,
+                     float* gl, float* t1, float* tg) {
+    const int blocks = ew_grid((long long)N * H);
+    PVS_NODE_DISPATCH_H(H, {
+        k_node_out_bwd<HH><<<blocks, 256, 0, s>>>(g_hout, o, h, w, flags, att_act, N, g_o, g_h, gl,
+                                                  t1, tg);
+    });
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+int pvs_node_tail_bwd1(hipStream_t s, const float* g_u, const float* y1, const float* stats,
+                       const PvsNodeW& w, int N, int H, float* g_yn) {
+    k_node_tail_bwd1<<<ew_grid((long long)N * H), 256, 0, s>>>(g_u, y1, stats, w, N, H, g_yn);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+int pvs_graphnorm_bwd_coefs(hipStream_t s, const float* S1, const float* S2, const float* stats,
+                            const PvsNodeW& w, int N, int H, float* g_w, float* g_b, float* g_ms,
+                            float* coefs) {
+    k_gn_bwd_coefs<<<(H + 63) / 64, 64, 0, s>>>(S1, S2, stats, w, N, H, g_w, g_b, g_ms, coefs);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+int pvs_node_tail_bwd2(hipStream_t s, const float* g_yn, const float* y1, const float* stats,
+                       const PvsNodeW& w, const float* coefs, int N, int H, float* g_y1) {
+    k_node_tail_bwd2<<<ew_grid((long long)N * H), 256, 0, s>>>(g_yn, y1, stats, w, coefs, N, H, g_y1);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+int pvs_prep_edge_bwd(hipStream_t s, const float* g_x_out, const float* inv_deg, const float* Magg,
+                      const float* gM, int N, int H, float* gxagg, float* softD) {
+    if (!gxagg && !softD) return 0;
+    k_prep_edge_bwd<<<(N + 255) / 256, 256, 0, s>>>(g_x_out, inv_deg, Magg, gM, N, H, gxagg, softD);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+int pvs_sum_vec(hipStream_t s, const float* v, int n, float* out) {
+    k_sum_vec<<<1, 64, 0, s>>>(v, n, out);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,304 @@
+"""EGNN layer and network with the reference's class surface, bodies in HIP.
+
+Mirrors /root/reference/point_vs/models/geometric/egnn_satorras.py:
+  EGNNLayer            :23-206   (constructor signature, forward signature, state_dict keys,
+                                  side attributes att_val / node_att_val / intermediate_coords)
+  SartorrasEGNN        :209-329  (build_net kwargs, .layers Sequential, get_embeddings)
+The nn.Sequential members only hold parameters under the reference's names (so reference
+checkpoints load and seeds give the same init); they are never called. The arithmetic of
+forward/backward is `pvs_egnn_layer_fwd/bwd` in libpvs_egnn.so (include/pvs_egnn.h).
+"""
+import torch
+from torch import nn
+
+from . import _lib
+from . import functional as PF
+from .graph import prepared_for
+from .pnn_geometric_base import PNNGeometricBase, PygLinearPass
+
+
+class GraphNorm(nn.Module):
+    """Parameter holder for torch_geometric.nn.norm.GraphNorm (weight, bias, mean_scale).
+
+    The reference places it inside an nn.Sequential, i.e. calls it without a batch vector, so the
+    statistics run over all nodes of the mini-batch; that is what the node
+    kernels implement (eps = 1e-5).
+    """
+
+    def __init__(self, in_channels, eps=1e-5):
+        super().__init__()
+        self.in_channels, self.eps = in_channels, eps
+        self.weight = nn.Parameter(torch.ones(in_channels))
+        self.bias = nn.Parameter(torch.zeros(in_channels))
+        self.mean_scale = nn.Parameter(torch.ones(in_channels))
+
+
+def _lazy_numpy(value):
+    if value is None:
+        return None
+    return value().detach().cpu().numpy()
+
+
+class EGNNLayer(nn.Module):
+    """E(n)-equivariant message-passing layer (egnn_satorras.py:23-206), HIP-backed."""
+
+    def __init__(self, input_nf, output_nf, hidden_nf, edges_in_d=0, act_fn=nn.SiLU(),
+                 residual=True, edge_residual=False, edge_attention=False, normalize=False,
+                 tanh=False, graphnorm=False, update_coords=True, permutation_invariance=False,
+                 node_attention=False, attention_activation_fn='sigmoid', gated_residual=False,
+                 rezero=False, softmax_attention=False):
+        assert not (gated_residual and rezero), 'gated_residual and rezero are incompatible'
+        super().__init__()
+        if not (input_nf == output_nf == hidden_nf):
+            raise NotImplementedError(
+                'HIP EGNNLayer needs input_nf == output_nf == hidden_nf (build_net always passes '
+                'k, k, k: egnn_satorras.py:283)')
+        if not isinstance(act_fn, nn.SiLU):
+            raise NotImplementedError('HIP EGNNLayer implements SiLU only (the reference never '
+                                      'forwards another act_fn: SURVEY.md §5)')
+        if attention_activation_fn not in ('sigmoid', 'tanh', 'relu', 'silu'):
+            raise KeyError(attention_activation_fn)
+        input_edge = input_nf if permutation_invariance else input_nf * 2
+        self.gated_residual, self.rezero = gated_residual, rezero
+        self.residual, self.edge_residual = residual, edge_residual
+        self.edge_attention, self.normalize, self.tanh = edge_attention, normalize, tanh
+        self.epsilon = 1e-8
+        self.use_coords = update_coords
+        self.permutation_invariance = permutation_invariance
+        self.node_attention = node_attention
+        self.hidden_nf = hidden_nf
+        self.edges_in_d = edges_in_d
+        self.graphnorm = graphnorm
+        self.softmax_attention = softmax_attention
+        self.attention_activation_name = 'identity' if softmax_attention else attention_activation_fn
+        self.attention_activation = {
+            'sigmoid': nn.Sigmoid, 'tanh': nn.Tanh, 'relu': nn.ReLU, 'silu': nn.SiLU,
+            'identity': nn.Identity}[self.attention_activation_name]
+        self._att_src = self._natt_src = self._coords_src = None
+
+        # construction order follows the reference so a given torch seed yields the same init
+        self.edge_mlp = nn.Sequential(
+            nn.Linear(input_edge + 1 + edges_in_d, hidden_nf), act_fn,
+            nn.Linear(hidden_nf, hidden_nf), act_fn)
+        self.node_mlp = nn.Sequential(
+            nn.Linear(hidden_nf + input_nf, hidden_nf),
+            GraphNorm(hidden_nf) if graphnorm else nn.Identity(), act_fn,
+            nn.Linear(hidden_nf, output_nf))
+        last = nn.Linear(hidden_nf, 1, bias=False)
+        torch.nn.init.xavier_uniform_(last.weight, gain=0.001)
+        self.coord_mlp = nn.Sequential(
+            nn.Linear(hidden_nf, hidden_nf), act_fn, last, nn.Tanh() if tanh else nn.Identity())
+        if edge_attention:
+            self.att_mlp = nn.Sequential(nn.Linear(hidden_nf, 1), self.attention_activation())
+        if node_attention:
+            self.node_att_mlp = nn.Sequential(nn.Linear(hidden_nf, 1), self.attention_activation())
+        if rezero:
+            if edge_residual:
+                self.edge_gate_parameter = nn.Parameter(torch.zeros(1))
+            if residual:
+                self.node_gate_parameter = nn.Parameter(torch.zeros(1))
+        elif gated_residual:
+            if edge_residual:
+                self.edge_gate_parameter = nn.Parameter(0.5 * torch.ones(1))
+            if residual:
+                self.node_gate_parameter = nn.Parameter(0.5 * torch.ones(1))
+
+    # ---- side attributes: numpy on access, no device sync in forward ----
+    @property
+    def att_val(self):
+        return _lazy_numpy(self._att_src)
+
+    @att_val.setter
+    def att_val(self, value):
+        self._att_src = None if value is None else (lambda: torch.as_tensor(value))
+
+    @property
+    def node_att_val(self):
+        return _lazy_numpy(self._natt_src)
+
+    @node_att_val.setter
+    def node_att_val(self, value):
+        self._natt_src = None if value is None else (lambda: torch.as_tensor(value))
+
+    @property
+    def intermediate_coords(self):
+        return _lazy_numpy(self._coords_src)
+
+    @intermediate_coords.setter
+    def intermediate_coords(self, value):
+        self._coords_src = None if value is None else (lambda: torch.as_tensor(value))
+
+    # ---- C ABI plumbing ----
+    def _flags(self):
+        f = 0
+        for on, bit in ((self.residual, _lib.RESIDUAL), (self.edge_residual, _lib.EDGE_RESIDUAL),
+                        (self.edge_attention, _lib.EDGE_ATTENTION), (self.normalize, _lib.NORMALIZE),
+                        (self.tanh, _lib.TANH), (self.graphnorm, _lib.GRAPHNORM),
+                        (self.use_coords, _lib.UPDATE_COORDS),
+                        (self.permutation_invariance, _lib.PERM_INVARIANT),
+                        (self.node_attention, _lib.NODE_ATTENTION),
+                        (self.gated_residual, _lib.GATED_RESIDUAL), (self.rezero, _lib.REZERO),
+                        (self.softmax_attention, _lib.SOFTMAX_ATT)):
+            if on:
+                f |= bit
+        return f
+
+    def _desc(self):
+        return (self.hidden_nf, self.edges_in_d, self._flags(),
+                _lib.ACT_CODES[self.attention_activation_name])
+
+    def _params(self):
+        gn = self.node_mlp[1] if self.graphnorm else None
+        att = self.att_mlp[0] if self.edge_attention else None
+        natt = self.node_att_mlp[0] if self.node_attention else None
+        return (
+            self.edge_mlp[0].weight, self.edge_mlp[0].bias, self.edge_mlp[2].weight,
+            self.edge_mlp[2].bias, self.coord_mlp[0].weight, self.coord_mlp[0].bias,
+            self.coord_mlp[2].weight,
+            None if att is None else att.weight, None if att is None else att.bias,
+            self.node_mlp[0].weight, self.node_mlp[0].bias, self.node_mlp[3].weight,
+            self.node_mlp[3].bias,
+            None if gn is None else gn.weight, None if gn is None else gn.bias,
+            None if gn is None else gn.mean_scale,
+            None if natt is None else natt.weight, None if natt is None else natt.bias,
+            getattr(self, 'edge_gate_parameter', None), getattr(self, 'node_gate_parameter', None))
+
+    def forward_prepared(self, pg, h, coord, m_prev_sorted=None, need_m=False):
+        """Layer on a PreparedGraph; edge tensors stay in CSR-sorted order (internal fast path)."""
+        if not self.edge_residual:
+            m_prev_sorted = None
+        h_out, x_out, m_sorted, att, natt = PF.egnn_layer(
+            h, coord, m_prev_sorted, pg, self._desc(), need_m, self._params())
+        self._att_src = None if att is None else (
+            lambda: PF.rows_to_input_order(att.detach()[:pg.n_edges].reshape(-1, 1), pg))
+        self._natt_src = None if natt is None else (lambda: natt.detach().reshape(-1, 1))
+        self._coords_src = (lambda: x_out.detach()) if self.use_coords else self._coords_src
+        return h_out, x_out, m_sorted
+
+    def forward(self, h, edge_index, coord, edge_attr=None, edge_messages=None):
+        """Same contract as the reference: returns (h, coord, edge_attr, edge_feat), edge_feat in
+        the caller's edge order. `coord` is NOT modified in place (the reference's `coord += agg`
+        aliasing quirk, SURVEY.md §8a Q2, is not reproduced; returned values are identical)."""
+        if (edge_attr is None) != (self.edges_in_d == 0):
+            raise ValueError(f'layer built with edges_in_d={self.edges_in_d}, edge_attr '
+                             f'{"missing" if edge_attr is None else "given"}')
+        pg = prepared_for(edge_index, edge_attr, h.size(0))
+        m_prev = None
+        if self.edge_residual and edge_messages is not None:
+            m_prev = PF.rows_to_sorted_order(edge_messages, pg)
+        h_out, x_out, m_sorted = self.forward_prepared(pg, h, coord, m_prev, need_m=True)
+        return h_out, x_out, edge_attr, PF.rows_to_input_order(m_sorted, pg)
+
+    def _fused(self, name):
+        raise NotImplementedError(
+            f'EGNNLayer.{name} is fused into pvs_egnn_layer_fwd (include/pvs_egnn.h); call the '
+            f'layer itself')
+
+    def edge_model(self, source, target, radial, edge_attr):
+        self._fused('edge_model')
+
+    def node_model(self, x, edge_index, m_ij):
+        self._fused('node_model')
+
+    def coord_model(self, coord, edge_index, coord_diff, edge_feat):
+        self._fused('coord_model')
+
+    def coord2radial(self, edge_index, coord):
+        self._fused('coord2radial')
+
+
+class SartorrasEGNN(PNNGeometricBase):
+    """Equivariant network based on EGNNLayer (egnn_satorras.py:209-329)."""
+
+    def _layer_flags(self, idx, num_layers, kw):
+        return kw['edge_attention'], kw['node_attention']
+
+    def _build_layers(self, dim_input, k, num_layers, act_fn, kw):
+        layers = [PygLinearPass(nn.Linear(dim_input, k), return_coords_and_edges=True)]
+        for idx in range(num_layers):
+            edge_att, node_att = self._layer_flags(idx, num_layers, kw)
+            layers.append(EGNNLayer(
+                k, k, k, edges_in_d=3, act_fn=act_fn, residual=kw['residual'],
+                edge_attention=edge_att, normalize=kw['normalize'], graphnorm=kw['graphnorm'],
+                tanh=kw['tanh'], update_coords=kw['update_coords'],
+                permutation_invariance=kw['permutation_invariance'],
+                attention_activation_fn=kw['attention_activation_fn'], node_attention=node_att,
+                edge_residual=kw['edge_residual'], gated_residual=kw['gated_residual'],
+                rezero=kw['rezero'], softmax_attention=kw['softmax_attention']))
+        return layers
+
+    def build_net(self, dim_input, k, dim_output, act_fn=nn.SiLU(), num_layers=4, residual=True,
+                  edge_residual=False, edge_attention=False, normalize=True, tanh=True, dropout=0.0,
+                  graphnorm=True, multi_fc=False, update_coords=True, permutation_invariance=False,
+                  attention_activation_fn='sigmoid', node_attention=False, gated_residual=False,
+                  rezero=False, model_task='classification', include_strain_info=False,
+                  final_softplus=False, softmax_attention=False, **kwargs):
+        assert not (gated_residual and rezero), 'gated_residual and rezero are incompatible'
+        if dropout and dropout > 0:
+            raise NotImplementedError('dropout_adj (dropout > 0) is outside the HIP path '
+                                      '(SURVEY.md §8a Q7)')
+        self.n_layers = num_layers
+        self.dropout_p = dropout
+        self.residual, self.edge_residual = residual, edge_residual
+        self.gated_residual, self.rezero = gated_residual, rezero
+        self.model_task = model_task
+        self.include_strain_info = include_strain_info
+        self.softmax_attention = softmax_attention
+        kw = dict(residual=residual, edge_residual=edge_residual, edge_attention=edge_attention,
+                  normalize=normalize, tanh=tanh, graphnorm=graphnorm, update_coords=update_coords,
+                  permutation_invariance=permutation_invariance,
+                  attention_activation_fn=attention_activation_fn, node_attention=node_attention,
+                  gated_residual=gated_residual, rezero=rezero, softmax_attention=softmax_attention)
+        kw.update({key: kwargs.get(key, False) for key in (
+            'node_attention_final_only', 'edge_attention_final_only', 'node_attention_first_only',
+            'edge_attention_first_only')})
+        layers = self._build_layers(dim_input, k, num_layers, act_fn, kw)
+        if include_strain_info:
+            k += 1
+        fc_dims = ((k, 32), (32, 16), (16, dim_output)) if multi_fc else ((k, dim_output),)
+        head = []
+        for idx, (n_in, n_out) in enumerate(fc_dims):
+            head.append(nn.Linear(n_in, n_out))
+            if idx < len(fc_dims) - 1:
+                head.append(nn.SiLU())
+        if final_softplus:
+            head.append(nn.Softplus())
+        self.feats_linear_layers = nn.Sequential(*head)
+        return nn.Sequential(*layers)
+
+    def embed_prepared(self, pg, feats, coords, need_messages=False, trace=None):
+        """Layer stack on a PreparedGraph. Edge messages stay in sorted order between layers and
+        are only materialised where a consumer exists (edge_residual, or need_messages)."""
+        embed = self.layers[0]
+        feats = embed.embed(feats, coords)
+        if trace is not None:
+            trace['h0'], trace['x0'] = feats, coords
+        m_sorted = None
+        egnn_layers = list(self.layers)[1:]
+        for idx, layer in enumerate(egnn_layers):
+            last = idx == len(egnn_layers) - 1
+            need_m = (need_messages and last) or (self.edge_residual and not last)
+            feats, coords, m_sorted = layer.forward_prepared(
+                pg, feats, coords, m_sorted, need_m=need_m)
+            if trace is not None:
+                trace[f'h{idx + 1}'], trace[f'x{idx + 1}'] = feats, coords
+        return feats, coords, m_sorted
+
+    def get_embeddings(self, feats, edges, coords, edge_attributes, batch):
+        """Reference signature (egnn_satorras.py:319-329): returns (feats, edge_messages) with
+        edge_messages in the caller's edge order."""
+        pg = prepared_for(edges, edge_attributes, feats.size(0))
+        feats, _, m_sorted = self.embed_prepared(pg, feats, coords, need_messages=True)
+        edge_messages = None if m_sorted is None else PF.rows_to_input_order(m_sorted, pg)
+        return feats, edge_messages
+
+
+def unsorted_segment_sum(data, segment_ids, num_segments):
+    """egnn_satorras.py:332-337. Kept for the module surface; inside the layers the segment sums
+    are fused into the edge kernels."""
+    raise NotImplementedError('unsorted_segment_sum is fused into pvs_egnn_layer_fwd')
+
+
+def unsorted_segment_mean(data, segment_ids, num_segments):
+    """egnn_satorras.py:340-347 (see unsorted_segment_sum)."""
+    raise NotImplementedError('unsorted_segment_mean is fused into pvs_egnn_layer_fwd')

@@ -1,0 +1,222 @@
+"""torch.autograd.Function wrappers over the C ABI (include/pvs_egnn.h).
+
+PyTorch supplies device memory, the current stream and the autograd tape; every arithmetic step
+of the path runs in libpvs_egnn.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _ws(nbytes, dev):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise TypeError(f'pointvs_amd kernels are fp32 (got {t.dtype}); --double is not supported')
+    return t.contiguous()
+
+
+class _PermuteRows(torch.autograd.Function):
+    """Rows between input edge order and CSR-sorted order (and back in the backward)."""
+
+    @staticmethod
+    def forward(ctx, src, perm, to_input):
+        src = _f32c(src)
+        _lib.require_hip(src)
+        ctx.perm, ctx.to_input = perm, to_input
+        width = src.shape[1] if src.dim() > 1 else 1
+        dst = torch.empty_like(src)
+        fn = _lib.lib().pvs_rows_to_input_order if to_input else _lib.lib().pvs_rows_to_sorted_order
+        _lib.check(fn(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(perm), src.shape[0], width,
+                      _stream(src.device)), 'pvs_rows_permute')
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        return _PermuteRows.apply(g, ctx.perm, not ctx.to_input), None, None
+
+
+def rows_to_input_order(src_sorted, pg):
+    return _PermuteRows.apply(src_sorted, pg.perm, True)
+
+
+def rows_to_sorted_order(src_input, pg):
+    return _PermuteRows.apply(src_input, pg.perm, False)
+
+
+class _EGNNLayerFn(torch.autograd.Function):
+    """One EGNNLayer.forward (egnn_satorras.py:189-206) and its backward, sorted edge order."""
+
+    @staticmethod
+    def forward(ctx, h, x, m_prev, pg, desc_tuple, need_m, *params):
+        lib = _lib.lib()
+        hidden, n_attr, flags, act = desc_tuple
+        h, x, m_prev = _f32c(h), _f32c(x), _f32c(m_prev)
+        params = tuple(_f32c(p) for p in params)
+        _lib.require_hip(h, x, m_prev, *params)
+        dev = h.device
+        n, e = pg.n_nodes, pg.n_edges
+        if h.shape != (n, hidden) or x.shape != (n, 3):
+            raise ValueError(f'h {tuple(h.shape)} / coord {tuple(x.shape)} do not match N={n}, '
+                             f'H={hidden}')
+        if n_attr != pg.n_edge_attr:
+            raise ValueError(f'layer built with edges_in_d={n_attr} but edge_attr has '
+                             f'{pg.n_edge_attr} columns')
+        desc = _lib.PvsLayerDesc(hidden, n_attr, flags, act)
+        pstruct = _lib.PvsLayerParams(*[_lib.ptr(p) for p in params])
+        eatt = bool(flags & _lib.EDGE_ATTENTION)
+        natt = bool(flags & _lib.NODE_ATTENTION)
+        eres = bool(flags & _lib.EDGE_RESIDUAL) and m_prev is not None
+        h_out = torch.empty_like(h)
+        x_out = torch.empty_like(x)
+        m_out = torch.empty((max(e, 0), hidden), dtype=torch.float32, device=dev) if need_m else None
+        att = torch.empty((max(e, 1),), dtype=torch.float32, device=dev) if eatt else None
+        node_att = torch.empty((n,), dtype=torch.float32, device=dev) if natt else None
+        saved = torch.empty(lib.pvs_egnn_layer_saved_floats(C.byref(desc), n, e),
+                            dtype=torch.float32, device=dev)
+        ws_bytes = lib.pvs_egnn_layer_workspace_bytes(C.byref(desc), n, e, 0)
+        ws = _ws(ws_bytes, dev)
+        rc = lib.pvs_egnn_layer_fwd(
+            C.byref(desc), C.byref(pg.c), C.byref(pstruct), _lib.ptr(h), _lib.ptr(x),
+            _lib.ptr(m_prev if eres else None), _lib.ptr(h_out), _lib.ptr(x_out), _lib.ptr(m_out),
+            _lib.ptr(att), _lib.ptr(node_att), _lib.ptr(saved), _lib.ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, 'pvs_egnn_layer_fwd')
+        ctx.pg, ctx.desc_tuple, ctx.eres = pg, desc_tuple, eres
+        ctx.n_params = len(params)
+        ctx.save_for_backward(h, x, m_prev if eres else None, att, saved, *params)
+        ctx.set_materialize_grads(False)
+        outs = (h_out, x_out,
+                m_out if m_out is not None else h.new_empty(0),
+                att if att is not None else h.new_empty(0),
+                node_att if node_att is not None else h.new_empty(0))
+        ctx.mark_non_differentiable(outs[3], outs[4])
+        if m_out is None:
+            ctx.mark_non_differentiable(outs[2])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_h_out, g_x_out, g_m_out, _g_att, _g_natt):
+        lib = _lib.lib()
+        h, x, m_prev, att, saved, *params = ctx.saved_tensors
+        pg = ctx.pg
+        hidden, n_attr, flags, act = ctx.desc_tuple
+        dev = h.device
+        n, e = pg.n_nodes, pg.n_edges
+        desc = _lib.PvsLayerDesc(hidden, n_attr, flags, act)
+        pstruct = _lib.PvsLayerParams(*[_lib.ptr(p) for p in params])
+        g_h_out = torch.zeros_like(h) if g_h_out is None else _f32c(g_h_out)
+        g_x_out = _f32c(g_x_out)       # None => the caller never used x_out (last layer)
+        g_m_out = _f32c(g_m_out) if (g_m_out is not None and g_m_out.numel()) else None
+        need = ctx.needs_input_grad
+        g_h = torch.empty_like(h)
+        g_x = torch.empty_like(x) if need[1] else None
+        g_m_prev = torch.empty_like(m_prev) if ctx.eres else None
+        coord_live = bool(flags & _lib.UPDATE_COORDS) and g_x_out is not None
+        live = {
+            'coord_w1': coord_live, 'coord_b1': coord_live, 'coord_w2': coord_live,
+            'edge_gate': ctx.eres and bool(flags & (_lib.REZERO | _lib.GATED_RESIDUAL)),
+        }
+        grads = []
+        for name, p in zip(_lib.PARAM_FIELDS, params):
+            if p is None or not live.get(name, True):
+                grads.append(None)
+            else:
+                grads.append(torch.empty_like(p))
+        gstruct = _lib.PvsLayerGrads(*[_lib.ptr(g) for g in grads])
+        ws_bytes = lib.pvs_egnn_layer_workspace_bytes(C.byref(desc), n, e, 1)
+        ws = _ws(ws_bytes, dev)
+        rc = lib.pvs_egnn_layer_bwd(
+            C.byref(desc), C.byref(pg.c), C.byref(pstruct), _lib.ptr(h), _lib.ptr(x),
+            _lib.ptr(m_prev), _lib.ptr(att), _lib.ptr(saved), _lib.ptr(g_h_out), _lib.ptr(g_x_out),
+            _lib.ptr(g_m_out), _lib.ptr(g_h), _lib.ptr(g_x), _lib.ptr(g_m_prev), C.byref(gstruct),
+            _lib.ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, 'pvs_egnn_layer_bwd')
+        return (g_h, g_x, g_m_prev, None, None, None, *grads)
+
+
+def egnn_layer(h, x, m_prev_sorted, pg, desc_tuple, need_m, params):
+    """Returns (h_out, x_out, m_sorted|None, att_sorted|None, node_att|None)."""
+    h_out, x_out, m, att, natt = _EGNNLayerFn.apply(h, x, m_prev_sorted, pg, desc_tuple, need_m,
+                                                    *params)
+    return (h_out, x_out, m if need_m else None, att if att.numel() else None,
+            natt if natt.numel() else None)
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b  (PygLinearPass / head Linear; pnn_geometric_base.py:83-94)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w, b = _f32c(x), _f32c(w), _f32c(b)
+        _lib.require_hip(x, w, b)
+        n, k = x.shape
+        c = w.shape[0]
+        y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().pvs_linear_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y),
+                                             n, k, c, _stream(x.device)), 'pvs_linear_fwd')
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        x, w = ctx.saved_tensors
+        g_y = _f32c(g_y)
+        n, k = x.shape
+        c = w.shape[0]
+        lib = _lib.lib()
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        g_w = torch.empty_like(w)
+        g_b = torch.empty((c,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        ws_bytes = lib.pvs_linear_bwd_workspace_bytes(n, k, c)
+        ws = _ws(ws_bytes, x.device)
+        _lib.check(lib.pvs_linear_bwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(g_y), _lib.ptr(g_x),
+                                      _lib.ptr(g_w), _lib.ptr(g_b), n, k, c, _lib.ptr(ws), ws_bytes,
+                                      _stream(x.device)), 'pvs_linear_bwd')
+        return g_x, g_w, g_b
+
+
+def linear(x, weight, bias=None):
+    squeeze = x.dim() == 1
+    y = _LinearFn.apply(x.reshape(1, -1) if squeeze else x, weight, bias)
+    return y.reshape(-1) if squeeze else y
+
+
+class _MeanPoolFn(torch.autograd.Function):
+    """global_mean_pool over contiguous per-graph node ranges (pnn_geometric_base.py:29-33)."""
+
+    @staticmethod
+    def forward(ctx, h, graph_ptr):
+        h = _f32c(h)
+        _lib.require_hip(h, graph_ptr)
+        b = graph_ptr.numel() - 1
+        pooled = torch.empty((b, h.shape[1]), dtype=torch.float32, device=h.device)
+        _lib.check(_lib.lib().pvs_mean_pool_fwd(_lib.ptr(h), _lib.ptr(graph_ptr), _lib.ptr(pooled),
+                                                b, h.shape[1], _stream(h.device)),
+                   'pvs_mean_pool_fwd')
+        ctx.graph_ptr, ctx.n = graph_ptr, h.shape[0]
+        return pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32c(g)
+        b, width = g.shape
+        g_h = torch.empty((ctx.n, width), dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().pvs_mean_pool_bwd(_lib.ptr(g), _lib.ptr(ctx.graph_ptr), _lib.ptr(g_h),
+                                                b, ctx.n, width, _stream(g.device)),
+                   'pvs_mean_pool_bwd')
+        return g_h, None
+
+
+def mean_pool(h, graph_ptr):
+    return _MeanPoolFn.apply(h, graph_ptr)

@@ -1,0 +1,170 @@
+"""Graph containers and the once-per-batch CSR/CSC preparation.
+
+`Data` / `Batch` are minimal duck types of the PyG objects the reference hands to the path
+(`.x .edge_index .edge_attr .pos .batch .y .lig_fname .rec_fname`,
+/root/reference/point_vs/preprocessing/data_loaders.py:381-391): PyG is not assumed present.
+`PreparedGraph` is what `pvs_graph_prepare` (include/pvs_egnn.h) produces from the int64 COO +
+int64 one-hot; every layer's forward and backward of a step share one instance.
+"""
+import collections
+
+import torch
+
+from . import _lib
+
+
+class Data:
+    """One graph: attribute bag, `.to(device)` moves tensors (PyG `Data` duck type)."""
+
+    def __init__(self, **kwargs):
+        self.__dict__.update(kwargs)
+
+    def to(self, device, non_blocking=False):
+        for key, val in list(self.__dict__.items()):
+            if torch.is_tensor(val):
+                self.__dict__[key] = val.to(device, non_blocking=non_blocking)
+        return self
+
+    def keys(self):
+        return list(self.__dict__.keys())
+
+
+class Batch(Data):
+    """Disjoint union of graphs with node-offset edge indices and a `batch` vector."""
+
+    @staticmethod
+    def from_data_list(items):
+        merged = {}
+        offset, shifted, batch_vec, ptr = 0, [], [], [0]
+        for gid, item in enumerate(items):
+            n = item.x.size(0)
+            batch_vec.append(torch.full((n,), gid, dtype=torch.long))
+            shifted.append(item.edge_index + offset)
+            offset += n
+            ptr.append(offset)
+        for key in items[0].__dict__:
+            vals = [getattr(item, key) for item in items]
+            if key == 'edge_index':
+                merged[key] = torch.cat(shifted, dim=1)
+            elif torch.is_tensor(vals[0]):
+                merged[key] = torch.cat([v.reshape(1) if v.dim() == 0 else v for v in vals], dim=0)
+            elif vals[0] is None:
+                merged[key] = None
+            else:
+                merged[key] = vals
+        merged['batch'] = torch.cat(batch_vec)
+        merged['ptr'] = torch.tensor(ptr, dtype=torch.long)
+        merged['num_graphs'] = len(items)
+        return Batch(**merged)
+
+
+class PreparedGraph:
+    """Device-resident CSR (by row = edge_index[0]) + CSC (by col) of one batch."""
+
+    def __init__(self, n_nodes, n_edges, n_edge_attr, tensors):
+        self.n_nodes, self.n_edges, self.n_edge_attr = n_nodes, n_edges, n_edge_attr
+        self.t = tensors  # keeps the storage alive for the struct's raw pointers
+        g = _lib.PvsGraph()
+        g.n_nodes, g.n_edges = n_nodes, n_edges
+        for name in ('rowptr', 'row', 'col', 'etype', 'perm', 'colptr', 'cedge', 'inv_deg'):
+            setattr(g, name, _lib.ptr(tensors.get(name)))
+        self.c = g
+        self._status_checked = False
+        self._status_host = None
+        self._status_event = None
+
+    @property
+    def perm(self):
+        return self.t['perm']
+
+    def poll_status(self):
+        """Asynchronous validation: the first call queues a D2H copy of the status word, later
+        calls (or check_status) raise once it has landed. Never blocks the stream."""
+        if self._status_checked:
+            return
+        if self._status_event is None:
+            self._status_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            self._status_host.copy_(self.t['status'], non_blocking=True)
+            self._status_event = torch.cuda.Event()
+            self._status_event.record(torch.cuda.current_stream(self.t['status'].device))
+            _PENDING.append(self)
+        for pg in list(_PENDING):
+            if pg._status_event.query():
+                _PENDING.remove(pg)
+                pg._raise_for(int(pg._status_host.item()))
+
+    def _raise_for(self, code):
+        if code & 1:
+            raise IndexError('edge_index contains node ids outside [0, n_nodes)')
+        if code & 2:
+            raise ValueError('edge_attr rows must be one-hot (the reference data loader emits '
+                             'one_hot(edge_type, 3)); dense edge attributes are not supported')
+        self._status_checked = True
+
+    def check_status(self):
+        """Host-side validation of the inputs (one tiny D2H copy; call where a sync is fine)."""
+        if not self._status_checked:
+            self._raise_for(int(self.t['status'].item()))
+
+
+_PENDING = []
+
+
+def prepare_graph(edge_index, edge_attr, n_nodes):
+    """int64 COO `[2,E]` (+ int64 one-hot `[E,A]` or None) -> PreparedGraph on the same device."""
+    _lib.require_hip(edge_index, edge_attr)
+    lib = _lib.lib()
+    if edge_index.dtype != torch.int64:
+        edge_index = edge_index.long()
+    edge_index = edge_index.contiguous()
+    n_edges = int(edge_index.shape[1])
+    n_attr = 0
+    if edge_attr is not None:
+        if edge_attr.dim() != 2 or edge_attr.shape[0] != n_edges:
+            raise ValueError(f'edge_attr shape {tuple(edge_attr.shape)} does not match E={n_edges}')
+        if edge_attr.dtype.is_floating_point:
+            if not bool(((edge_attr == 0) | (edge_attr == 1)).all()):
+                raise ValueError('edge_attr must be one-hot; dense edge attributes are not supported')
+        edge_attr = edge_attr.long().contiguous()
+        n_attr = int(edge_attr.shape[1])
+    dev = edge_index.device
+    e_alloc = max(n_edges, 1)
+    i32 = dict(dtype=torch.int32, device=dev)
+    t = {
+        'rowptr': torch.empty(n_nodes + 1, **i32), 'row': torch.empty(e_alloc, **i32),
+        'col': torch.empty(e_alloc, **i32), 'perm': torch.empty(e_alloc, **i32),
+        'colptr': torch.empty(n_nodes + 1, **i32), 'cedge': torch.empty(e_alloc, **i32),
+        'inv_deg': torch.empty(n_nodes, dtype=torch.float32, device=dev),
+        'status': torch.empty(1, **i32),
+    }
+    if n_attr:
+        t['etype'] = torch.empty(e_alloc, dtype=torch.uint8, device=dev)
+    ws_bytes = lib.pvs_graph_prepare_workspace_bytes(n_nodes, n_edges)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rc = lib.pvs_graph_prepare(
+        _lib.ptr(edge_index), _lib.ptr(edge_attr), n_attr, n_nodes, n_edges,
+        _lib.ptr(t['rowptr']), _lib.ptr(t['row']), _lib.ptr(t['col']), _lib.ptr(t.get('etype')),
+        _lib.ptr(t['perm']), _lib.ptr(t['colptr']), _lib.ptr(t['cedge']), _lib.ptr(t['inv_deg']),
+        _lib.ptr(t['status']), _lib.ptr(ws), ws_bytes, stream)
+    _lib.check(rc, 'pvs_graph_prepare')
+    return PreparedGraph(n_nodes, n_edges, n_attr, t)
+
+
+_CACHE = collections.OrderedDict()
+_CACHE_SIZE = 4
+
+
+def prepared_for(edge_index, edge_attr, n_nodes):
+    """Cached `prepare_graph`: the L layers of a forward are called with the same edge tensors."""
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
+           None if edge_attr is None else (edge_attr.data_ptr(), edge_attr._version), n_nodes)
+    hit = _CACHE.get(key)
+    if hit is not None:
+        _CACHE.move_to_end(key)
+        return hit[0]
+    pg = prepare_graph(edge_index, edge_attr, n_nodes)
+    _CACHE[key] = (pg, edge_index, edge_attr)  # hold the inputs so data_ptr keys stay unique
+    while len(_CACHE) > _CACHE_SIZE:
+        _CACHE.popitem(last=False)
+    return pg

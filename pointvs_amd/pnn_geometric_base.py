@@ -1,0 +1,107 @@
+"""Graph unpacking, input embedding wrapper, pooling + head.
+
+Mirrors /root/reference/point_vs/models/geometric/pnn_geometric_base.py:
+  PNNGeometricBase.forward                   :24-41
+  PNNGeometricBase.unpack_input_data_and_predict :43-53
+  PNNGeometricBase.unpack_graph              :55-58
+  PygLinearPass                              :61-94
+"""
+from abc import abstractmethod
+
+import torch
+from torch import nn
+
+from . import functional as PF
+from .global_objects import DEVICE
+from .graph import prepared_for
+from .point_neural_network_base import PointNeuralNetworkBase
+
+
+class PNNGeometricBase(PointNeuralNetworkBase):
+    """Base class of the geometric point networks."""
+
+    @abstractmethod
+    def get_embeddings(self, feats, edges, coords, edge_attributes, batch):
+        """Input features -> final node embeddings."""
+
+    def unpack_graph(self, graph):
+        return (graph.x.float().to(DEVICE), graph.edge_index.to(DEVICE),
+                graph.pos.float().to(DEVICE), graph.edge_attr.to(DEVICE), graph.batch.to(DEVICE))
+
+    def _embed_graph(self, graph):
+        feats, edges, coords, edge_attributes, batch = self.unpack_graph(graph)
+        n_nodes = feats.size(0)
+        n_graphs = getattr(graph, 'num_graphs', None)
+        if n_graphs is None:  # the reference syncs here too (torch.max(batch), :27)
+            n_graphs = int(batch.max()) + 1
+        ptr = getattr(graph, 'ptr', None)
+        if ptr is None:
+            counts = torch.bincount(batch, minlength=n_graphs)
+            ptr = torch.cat([counts.new_zeros(1), counts.cumsum(0)])
+        graph_ptr = ptr.to(device=feats.device, dtype=torch.int32).contiguous()
+        pg = prepared_for(edges, edge_attributes, n_nodes)
+        pg.poll_status()
+        feats, _, _ = self.embed_prepared(pg, feats, coords)
+        return feats, pg, graph_ptr, n_graphs
+
+    @staticmethod
+    def _pool(feats, graph_ptr, n_graphs):
+        """global_mean_pool, or plain mean over nodes for a single graph (:29-33)."""
+        if n_graphs == 1:
+            whole = torch.tensor([0, feats.size(0)], dtype=torch.int32, device=feats.device)
+            return PF.mean_pool(feats, whole).reshape(-1)
+        return PF.mean_pool(feats, graph_ptr)
+
+    @staticmethod
+    def _run_head(head, pooled):
+        out = pooled
+        for mod in head:
+            out = PF.linear(out, mod.weight, mod.bias) if isinstance(mod, nn.Linear) else mod(out)
+        return out
+
+    def forward(self, x):
+        feats, _, graph_ptr, n_graphs = self._embed_graph(x)
+        if self.feats_linear_layers is not None:
+            feats = self._run_head(self.feats_linear_layers, self._pool(feats, graph_ptr, n_graphs))
+        return feats
+
+    def unpack_input_data_and_predict(self, input_data):
+        y_true = input_data.y
+        try:
+            y_true = y_true.float()
+        except (AttributeError, TypeError):
+            pass
+        y_pred = self(input_data).reshape(-1, )
+        return y_pred, y_true, input_data.lig_fname, input_data.rec_fname
+
+
+class PygLinearPass(nn.Module):
+    """Linear input embedding with the layer-like call signature (:61-94)."""
+
+    def __init__(self, module, feats_appended_to_coords=False, return_coords_and_edges=False):
+        super().__init__()
+        if feats_appended_to_coords:
+            raise NotImplementedError('feats_appended_to_coords is only used by the lucid EGNN')
+        self.m = module
+        self.feats_appended_to_coords = feats_appended_to_coords
+        self.return_coords_and_edges = return_coords_and_edges
+        self._coords_src = None
+
+    @property
+    def intermediate_coords(self):
+        return None if self._coords_src is None else self._coords_src().detach().cpu().numpy()
+
+    @intermediate_coords.setter
+    def intermediate_coords(self, value):
+        self._coords_src = None if value is None else (lambda: torch.as_tensor(value))
+
+    def embed(self, h, coord=None):
+        if coord is not None:
+            self._coords_src = lambda: coord
+        return PF.linear(h, self.m.weight, self.m.bias)
+
+    def forward(self, h, **kwargs):
+        res = self.embed(h, kwargs.get('coord'))
+        if self.return_coords_and_edges:
+            return res, kwargs['coord'], kwargs['edge_attr'], kwargs.get('edge_messages', None)
+        return res

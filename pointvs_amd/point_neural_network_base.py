@@ -1,0 +1,202 @@
+"""Training / validation harness that calls the path (caller, kept by surface).
+
+Mirrors the constructor, loss, optimiser step and checkpoint format of
+/root/reference/point_vs/models/point_neural_network_base.py:
+  __init__        :49-123     get_loss   :362-370     backprop      :417-429
+  train_model     :136-205    save       :501-517     load_weights  :528-565
+  param_count / set_task :567-582
+Progress bars, wandb and the predictions-file writer are outside the hot-path scope and reduced to
+plain logging.
+"""
+import math
+import time
+from abc import abstractmethod
+from collections import OrderedDict
+from pathlib import Path
+
+import torch
+import yaml
+from torch import nn
+
+from .global_objects import DEVICE
+
+
+class PointNeuralNetworkBase(nn.Module):
+    """Base (abstract) class of the point-cloud networks."""
+
+    def __init__(self, save_path, learning_rate, weight_decay=None, wandb_project=None,
+                 wandb_run=None, silent=False, use_1cycle=False, warm_restarts=False,
+                 only_save_best_models=False, optimiser='adam', regression_loss='mse',
+                 **model_kwargs):
+        super().__init__()
+        self.set_task(model_kwargs.get('model_task', 'classification'))
+        self.include_strain_info = False
+        self.batch = 0
+        self.p_epoch = 0
+        self.a_epoch = 0
+        self.save_path = Path(save_path).expanduser()
+        self.only_save_best_models = only_save_best_models
+        if not silent:
+            self.save_path.mkdir(parents=True, exist_ok=True)
+        self.predictions_file = Path(self.save_path, 'predictions.txt')
+        self.lr = learning_rate
+        self.weight_decay = weight_decay
+        self.bce = nn.BCEWithLogitsLoss()
+        self.regression_loss = nn.MSELoss() if regression_loss == 'mse' else nn.HuberLoss()
+        self.wandb_project, self.wandb_run = wandb_project, wandb_run
+        self.n_layers = model_kwargs.get('num_layers', 12)
+        self.layers = self.build_net(**model_kwargs)
+        if optimiser == 'adam':
+            self.optimiser = torch.optim.Adam(self.parameters(), lr=self.lr,
+                                              weight_decay=weight_decay or 0)
+        elif optimiser == 'sgd':
+            self.optimiser = torch.optim.SGD(self.parameters(), lr=self.lr, momentum=0.9,
+                                             weight_decay=weight_decay or 0, nesterov=True)
+        else:
+            raise NotImplementedError(f'{optimiser} not recognised optimiser.')
+        assert not (use_1cycle and warm_restarts), '1cycle and warm restarts are mutually exclusive'
+        self.use_1cycle, self.warm_restarts = use_1cycle, warm_restarts
+        self.global_iter = 0
+        self.val_iter = 0
+        self.log_interval = 10
+        self.scheduler = None
+        self.test_metric = 0
+        self.grad_sync = None   # optional callable run between backward and clip (data parallel)
+        if not silent:
+            with open(self.save_path / 'model_kwargs.yaml', 'w', encoding='utf-8') as f:
+                yaml.dump(model_kwargs, f)
+        self.to(DEVICE)
+
+    @abstractmethod
+    def build_net(self, **model_kwargs):
+        """Construct self.layers (and the head)."""
+
+    @abstractmethod
+    def unpack_input_data_and_predict(self, input_data):
+        """Unpack the graph into tensors and run the network."""
+
+    def get_loss(self, y_true, y_pred):
+        if self.model_task == 'classification':
+            return self.bce(y_pred, y_true.to(y_pred.device))
+        if self.model_task == 'regression':
+            return self.regression_loss(y_pred, y_true.to(y_pred.device))
+        y_pred[torch.where(y_true == -1)] = -1
+        return 3 * self.regression_loss(y_pred, y_true.to(y_pred.device))
+
+    def backprop(self, y_true, y_pred):
+        loss = self.get_loss(y_true, y_pred)
+        self.optimiser.zero_grad()
+        loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync()
+        torch.nn.utils.clip_grad_value_(self.parameters(), 1.0)
+        self.optimiser.step()
+        loss_ = float(loss.detach().cpu())
+        if math.isnan(loss_):
+            raise FloatingPointError('We have hit a NaN loss value.')
+        return loss_
+
+    def training_setup(self, data_loader, epochs, model_task=None):
+        if self.use_1cycle:
+            self.scheduler = torch.optim.lr_scheduler.OneCycleLR(
+                self.optimiser, max_lr=self.lr, steps_per_epoch=epochs * len(data_loader), epochs=1)
+        elif self.warm_restarts:
+            self.scheduler = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(
+                self.optimiser, T_0=len(data_loader), T_mult=1, eta_min=0)
+        if model_task is not None:
+            self.set_task(model_task)
+        init_epoch = self.a_epoch if 'regression' in self.model_task else self.p_epoch
+        return init_epoch, time.time()
+
+    def train_model(self, data_loader, epochs=1, epoch_end_validation_set=None, top1_on_end=False):
+        init_epoch, _ = self.training_setup(data_loader=data_loader, epochs=epochs)
+        losses = []
+        for _ in range(init_epoch, epochs):
+            self.train()
+            for self.batch, graph in enumerate(data_loader):
+                y_pred, y_true, _, _ = self.unpack_input_data_and_predict(graph)
+                losses.append(self.backprop(y_true, y_pred))
+                if self.scheduler is not None:
+                    self.scheduler.step()
+                self.global_iter += 1
+            self.eval()
+            if 'regression' in self.model_task:
+                self.a_epoch += 1
+            else:
+                self.p_epoch += 1
+            if not self.only_save_best_models:
+                self.save()
+        return losses
+
+    @torch.no_grad()
+    def val(self, data_loader, predictions_file=None, top1_on_end=False, rich_ctx=None):
+        """Inference loop; writes `<label> | <prediction> <receptor> <ligand>` lines like the
+        reference's predictions file (:287-325, simplified)."""
+        predictions_file = Path(predictions_file or self.predictions_file)
+        lines = []
+        self.eval()
+        for self.batch, graph in enumerate(data_loader):
+            y_pred, y_true, ligands, receptors = self.unpack_input_data_and_predict(graph)
+            if self.model_task == 'classification':
+                y_pred = torch.sigmoid(y_pred)
+            for yt, yp, lig, rec in zip(y_true.reshape(-1).tolist(), y_pred.reshape(-1).tolist(),
+                                        ligands, receptors):
+                lines.append(f'{yt:.3f} | {yp:.3f} {rec} {lig}')
+        predictions_file.parent.mkdir(parents=True, exist_ok=True)
+        predictions_file.write_text('\n'.join(lines) + '\n')
+        return lines
+
+    def save(self, save_path=None):
+        epoch = self.a_epoch if 'regression' in self.model_task else self.p_epoch
+        if save_path is None:
+            save_path = (self.save_path / 'checkpoints' /
+                         f'{self.model_task_for_fnames}_ckpt_epoch_{epoch}.pt')
+        Path(save_path).parent.mkdir(parents=True, exist_ok=True)
+        torch.save({
+            'learning_rate': self.lr, 'weight_decay': self.weight_decay,
+            'p_epoch': self.p_epoch, 'a_epoch': self.a_epoch,
+            'model_state_dict': self.state_dict(),
+            'optimiser_state_dict': self.optimiser.state_dict()}, save_path)
+
+    @staticmethod
+    def _transform_names(d):
+        """Legacy key names of older reference checkpoints (:520-526)."""
+        out = OrderedDict()
+        for key, value in d.items():
+            out[key.replace('edge_attention_mlp', 'att_mlp').replace(
+                'node_attention_mlp', 'node_att_mlp')] = value
+        return out
+
+    def load_weights(self, checkpoint_file, silent=False):
+        checkpoint_file = Path(checkpoint_file).expanduser()
+        if checkpoint_file.is_dir():
+            found = sorted(checkpoint_file.glob('**/*.pt'), key=lambda p: p.stat().st_mtime)
+            checkpoint_file = found[-1]
+        checkpoint = torch.load(str(checkpoint_file), map_location=DEVICE)
+        state = self._transform_names(checkpoint['model_state_dict'])
+        # older checkpoints hold att_mlp as a 4-element Sequential (Linear at index 2, :540-546)
+        state = OrderedDict((k.replace('att_mlp.2.', 'att_mlp.0.'), v) for k, v in state.items())
+        self.load_state_dict(state)
+        if 'optimiser_state_dict' in checkpoint:
+            try:
+                self.optimiser.load_state_dict(checkpoint['optimiser_state_dict'])
+            except ValueError:
+                pass
+        self.p_epoch = checkpoint.get('p_epoch', checkpoint.get('epoch', 0))
+        self.a_epoch = checkpoint.get('a_epoch', 0)
+
+    @property
+    def param_count(self):
+        return sum(torch.numel(t) for t in self.parameters() if t.requires_grad)
+
+    def set_task(self, task):
+        if task not in ('classification', 'regression', 'multi_regression'):
+            raise ValueError('Argument for set_task must be one of classification, regression or '
+                             'multi_regression')
+        self.model_task = task
+        if 'regression' in task:
+            self.model_task_for_fnames = 'affinity'
+            self.model_task_string = 'Mean squared error'
+        else:
+            self.model_task_for_fnames = 'pose'
+            self.model_task_string = 'Binary crossentropy'
