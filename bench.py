@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Benchmark of the EGNN hot path: protein-ligand graphs/s, forward + backward + optimiser step.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY.md §8d "cfg2"): 3-layer EGNN, 32 channels, CLI-default
+layer flags, batch of 32 synthetic point clouds of 2000 atoms, edge radius 10 A
+(~3.2e5 directed edges per graph), fp32. A step = graph preparation (COO -> CSR/CSC, every step,
+as a fresh batch would need) + forward + BCE loss + backward + gradient all-reduce (N>1) +
+clip_grad_value_(1.0) + Adam, the reference's `unpack_input_data_and_predict` + `backprop`
+(point_neural_network_base.py:176-199, 417-429) without the per-step host read of the loss.
+Inputs are resident in HBM before the timed region. One rank per GPU; every rank holds its own
+32 graphs (weak scaling), graphs never cross ranks, the only collective is the gradient all-reduce.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP32_PEAK_TFLOPS = 157.3   # fp32 vector = fp32 MFMA peak
+
+
+def algorithmic_bytes_per_layer(n, e, h):
+    """SURVEY.md §8d "store-m" formula: fwd + bwd HBM bytes of one layer on one batch."""
+    return 8 * e * h + 14 * e + 6 * (4 * h + 12) * n
+
+
+def algorithmic_bytes_edge_bwd(n, e, h):
+    """Backward share of that formula = what one edge-backward launch must move: read m (4EH),
+    read col + type + reverse index (9E), node-level reads/writes (3(4H+12)N)."""
+    return 4 * e * h + 9 * e + 3 * (4 * h + 12) * n
+
+
+def algorithmic_flops_per_step(n, e, h, a, layers, edge_att=False, node_att=False):
+    """SURVEY.md §8d reference-formulation FLOPs: 3 x forward (fwd + dgrad + wgrad)."""
+    f_e = 2 * h * (2 * h + 1 + a) + 2 * h * h + (2 * h * h + 2 * h) + (2 * h if edge_att else 0)
+    f_n = 6 * h * h + (2 * h if node_att else 0)
+    return 3 * layers * (f_e * e + f_n * n)
+
+
+def cpu_baseline(cfg, seconds_budget=25.0):
+    """The CPU oracle (oracle/egnn_oracle.py, a port of the reference's eager-PyTorch path) on
+    the host cores: fwd + bwd + clip + Adam on single graphs of the same workload."""
+    from oracle import egnn_oracle as orc
+    from pointvs_amd.synthetic import synthetic_graph
+    from pointvs_amd.graph import Batch
+    from pointvs_amd.egnn_satorras import SartorrasEGNN
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    model = SartorrasEGNN(Path('/tmp/pvs_bench_cpu'), 2e-3, 1e-4, silent=True, **cfg['model'])
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    ocfg = dict(cfg['model'], _class='SartorrasEGNN')
+    g = Batch.from_data_list([synthetic_graph(1000 * cfg['cfg_id'], **cfg['graph'])])
+    y_true = g.y.float()
+    times = []
+    t_start = time.perf_counter()
+    for it in range(8):
+        t0 = time.perf_counter()
+        _, _, grads = orc.forward_backward(sd, ocfg, g.x, g.pos, g.edge_index, g.edge_attr, g.batch,
+                                           y_true)
+        new = orc.adam_step(sd, grads, 2e-3, 1e-4)
+        sd = {k: (new[k].numpy() if k in new else v) for k, v in sd.items()}
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > seconds_budget and it >= 2:
+            break
+    timed = times[1:] if len(times) > 1 else times
+    med = float(np.median(timed))
+    return {'value': round(1.0 / med, 4), 'unit': 'graphs/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{len(timed)} timed fwd+bwd+Adam steps (1 warm-up) of the CPU oracle on 1 '
+                      f'graph of the same workload (N={g.x.shape[0]}, E={g.edge_index.shape[1]}), '
+                      f'median {med * 1e3:.0f} ms/step, torch {torch.__version__} CPU'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3'])
+    ap.add_argument('--batch', type=int, default=32, help='graphs per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (there is no CPU path in the product)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    from pointvs_amd import _lib, graph as pgraph
+    from pointvs_amd.distributed import GradAllReducer
+    from pointvs_amd.egnn_satorras import SartorrasEGNN
+    from pointvs_amd.synthetic import CONFIGS, synthetic_batch
+
+    cfg = CONFIGS[args.config]
+    lib = _lib.lib()
+    pgraph.CACHE_ENABLED = False        # every step prepares its batch, as a fresh batch would
+
+    # ---- inputs: this rank's graphs, built on the host, then resident in HBM ----
+    batch = synthetic_batch(cfg['cfg_id'], args.batch, first_graph=rank * args.batch, **cfg['graph'])
+    n_nodes, n_edges = int(batch.x.shape[0]), int(batch.edge_index.shape[1])
+    batch = batch.to(dev)
+    y_true = batch.y.float()
+
+    torch.manual_seed(0)
+    model = SartorrasEGNN(Path('/tmp/pvs_bench'), 2e-3, 1e-4, silent=True, **cfg['model']).train()
+    params = list(model.parameters())
+    reducer = GradAllReducer(params) if world > 1 else None
+
+    def step():
+        y_pred = model(batch).reshape(-1)
+        loss = model.get_loss(y_true, y_pred)
+        model.optimiser.zero_grad()
+        loss.backward()
+        if reducer is not None:
+            reducer()
+        torch.nn.utils.clip_grad_value_(params, 1.0)
+        model.optimiser.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    lib.pvs_profile_reset()
+    lib.pvs_profile_enable(1)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    lib.pvs_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    def kernel_ms(name):
+        tot, cnt = C.c_double(0.0), C.c_int64(0)
+        rc = lib.pvs_profile_read(name.encode(), C.byref(tot), C.byref(cnt))
+        return (tot.value, cnt.value) if rc == 0 else (0.0, 0)
+
+    if rank == 0:
+        h = cfg['model']['k']
+        layers = cfg['model']['num_layers']
+        ms_step = elapsed / args.steps * 1e3
+        graphs_per_s = world * args.batch * args.steps / elapsed
+        bwd_ms, bwd_n = kernel_ms('edge_bwd')
+        fwd_ms, fwd_n = kernel_ms('edge_fwd')
+        col_ms, col_n = kernel_ms('col_gather')
+        prep_ms, prep_n = kernel_ms('graph_prepare')
+        dom_avg_ms = bwd_ms / max(bwd_n, 1)
+        dom_bytes = algorithmic_bytes_edge_bwd(n_nodes, n_edges, h)
+        achieved = dom_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
+        step_bytes = layers * algorithmic_bytes_per_layer(n_nodes, n_edges, h)
+        step_flops = algorithmic_flops_per_step(
+            n_nodes, n_edges, h, 3, layers, cfg['model']['edge_attention'],
+            cfg['model']['node_attention'])
+        out = {
+            'metric': 'protein-ligand graphs/sec fwd+bwd (+Adam step), 3-layer EGNN ch=32, '
+                      '~2k nodes r=10A' if args.config == 'cfg2' else
+                      'protein-ligand graphs/sec fwd+bwd (+Adam step), 12-layer EGNN ch=64 '
+                      'edge+node attention, ~2k nodes r=6A',
+            'value': round(graphs_per_s, 2), 'unit': 'graphs/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': f'{args.config}: {layers}-layer EGNN, channels={h}, '
+                                   f'edge_radius={cfg["graph"]["edge_radius"]}A, '
+                                   f'{args.batch} graphs/GPU x {cfg["graph"]["n_nodes"]} atoms, '
+                                   f'N={n_nodes} nodes E={n_edges} edges per rank, CLI-default '
+                                   f'layer flags, Adam lr 2e-3 wd 1e-4 clip 1.0, random init',
+                       'graphs_per_gpu': args.batch, 'global_batch': world * args.batch,
+                       'parallelism': f'dp{world}', 'final_loss': round(final_loss, 6)},
+            'roofline': {
+                'bound': 'hbm', 'kernel': 'k_edge_bwd_v0 (edge backward, one launch per layer)',
+                'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+                'algorithmic_bytes_per_launch': dom_bytes,
+                'avg_launch_ms': round(dom_avg_ms, 4), 'launches': bwd_n,
+                'step_hbm_frac': round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                'step_fp32_frac': round(step_flops / (ms_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5),
+                'kernel_ms_per_step': {
+                    'edge_fwd': round(fwd_ms / args.steps, 3),
+                    'edge_bwd': round(bwd_ms / args.steps, 3),
+                    'col_gather': round(col_ms / args.steps, 3),
+                    'graph_prepare': round(prep_ms / args.steps, 3)}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -186,6 +186,16 @@ int pvs_mean_pool_fwd(const float* h, const int32_t* graph_ptr, float* pooled,
 int pvs_mean_pool_bwd(const float* g_pooled, const int32_t* graph_ptr, float* g_h,
                       int32_t n_graphs, int32_t n_nodes, int32_t width, pvs_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Measurement hook (no reference counterpart): when enabled, the library brackets its dominant
+ * kernels ("edge_fwd", "edge_bwd", "col_gather", "graph_prepare") with HIP events on the launch
+ * stream; pvs_profile_read waits for those events and returns the summed kernel time. Used by
+ * bench.py for the roofline figure; off by default (no events are created).
+ */
+int pvs_profile_enable(int on);
+int pvs_profile_reset(void);
+int pvs_profile_read(const char* kernel, double* total_ms, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@
 // Reference semantics: EGNNLayer.coord2radial / edge_model / coord_model / node_model's
 // aggregation, /root/reference/point_vs/models/geometric/egnn_satorras.py:123-187.
 #include "edge_kernels.h"
+#include "profile.h"
 
 namespace {
 
@@ -492,6 +493,7 @@ int pvs_launch_edge_fwd_v0(hipStream_t s, int H, const PvsGraph& g, const PvsEdg
     PVS_REQUIRE(w.n_attr <= PVS_MAX_EDGE_ATTR, "edge_attr classes %d > %d", w.n_attr,
                 PVS_MAX_EDGE_ATTR);
     const int blocks = pvs_edge_v0_blocks(g.n_nodes);
+    PvsProfScope prof(s, PVS_PROF_EDGE_FWD);
     PVS_DISPATCH_H(H, {
         size_t lds = (size_t)(2 * HH * HH + PVS_MAX_EDGE_ATTR * HH + kWaves * 128) * sizeof(float);
         if (set_lds(k_edge_fwd_v0<HH>, lds)) return -2;
@@ -512,6 +514,7 @@ int pvs_launch_edge_bwd_v0(hipStream_t s, int H, const PvsGraph& g, const PvsEdg
     int blocks = pvs_edge_v0_blocks(g.n_nodes);
     if (blocks > 512) blocks = 512;
     *n_slabs = blocks;
+    PvsProfScope prof(s, PVS_PROF_EDGE_BWD);
     PVS_DISPATCH_H(H, {
         const PvsSlabLayout L = pvs_slab_layout(HH);
         size_t words = (size_t)(4 * HH * HH + PVS_MAX_EDGE_ATTR * HH + kWaves * 192);
@@ -527,6 +530,7 @@ int pvs_launch_edge_bwd_v0(hipStream_t s, int H, const PvsGraph& g, const PvsEdg
 int pvs_launch_col_gather(hipStream_t s, int H, const PvsGraph& g, const float* gz1, const float* gd,
                           const float* gx_row, const float* g_x_out, float* gPQ, float* g_x) {
     const int blocks = pvs_edge_v0_blocks(g.n_nodes);
+    PvsProfScope prof(s, PVS_PROF_COL_GATHER);
     PVS_DISPATCH_H(H, {
         k_col_gather<HH><<<blocks, kThreads, 0, s>>>(g, gz1, gd, gx_row, g_x_out, gPQ, g_x);
     });

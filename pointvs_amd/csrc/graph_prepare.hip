@@ -1,6 +1,7 @@
 // pvs_graph_prepare: int64 COO + int64 one-hot edge_attr  ->  CSR (by row) + CSC (by col).
 // Once per batch; every layer's forward and backward reuse the result.
 #include "common.h"
+#include "profile.h"
 #include <hipcub/hipcub.hpp>
 
 namespace {
@@ -118,6 +119,7 @@ extern "C" int pvs_graph_prepare(const int64_t* edge_index, const int64_t* edge_
     carve(arena, N, E, &w);
     PVS_REQUIRE(arena.ok(), "pvs_graph_prepare: workspace too small (%zu < %zu)", workspace_bytes,
                 arena.off);
+    PvsProfScope prof(stream, PVS_PROF_PREPARE);
     PVS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), stream));
     const int bits = key_bits(N > 1 ? N : 2);
     const int T = 256;

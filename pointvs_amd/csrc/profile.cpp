@@ -1,0 +1,63 @@
+#include <mutex>
+#include <string.h>
+#include <vector>
+#include "profile.h"
+#include "../../include/pvs_egnn.h"
+
+namespace {
+struct Rec { int id; hipEvent_t a, b; };
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Rec*> g_recs;
+const char* kNames[PVS_PROF_COUNT] = {"edge_fwd", "edge_bwd", "col_gather", "graph_prepare"};
+}  // namespace
+
+PvsProfScope::PvsProfScope(hipStream_t stream, int id) : s(stream), rec(nullptr) {
+    if (!g_on) return;
+    Rec* r = new Rec{id, nullptr, nullptr};
+    if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) { delete r; return; }
+    hipEventRecord(r->a, s);
+    rec = r;
+}
+
+PvsProfScope::~PvsProfScope() {
+    if (!rec) return;
+    Rec* r = (Rec*)rec;
+    hipEventRecord(r->b, s);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_recs.push_back(r);
+}
+
+extern "C" int pvs_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+    return 0;
+}
+
+extern "C" int pvs_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (Rec* r : g_recs) { hipEventDestroy(r->a); hipEventDestroy(r->b); delete r; }
+    g_recs.clear();
+    return 0;
+}
+
+extern "C" int pvs_profile_read(const char* kernel, double* total_ms, int64_t* launches) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int id = -1;
+    for (int i = 0; i < PVS_PROF_COUNT; ++i)
+        if (strcmp(kernel, kNames[i]) == 0) id = i;
+    if (id < 0) return -1;
+    double tot = 0.0;
+    int64_t n = 0;
+    for (Rec* r : g_recs) {
+        if (r->id != id) continue;
+        if (hipEventSynchronize(r->b) != hipSuccess) return -2;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r->a, r->b) != hipSuccess) return -2;
+        tot += ms;
+        ++n;
+    }
+    *total_ms = tot;
+    *launches = n;
+    return 0;
+}

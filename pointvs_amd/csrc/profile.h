@@ -1,0 +1,13 @@
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
+#pragma once
+#include <hip/hip_runtime.h>
+
+enum { PVS_PROF_EDGE_FWD = 0, PVS_PROF_EDGE_BWD = 1, PVS_PROF_COL_GATHER = 2, PVS_PROF_PREPARE = 3,
+       PVS_PROF_COUNT = 4 };
+
+struct PvsProfScope {
+    hipStream_t s;
+    void* rec;
+    PvsProfScope(hipStream_t stream, int id);
+    ~PvsProfScope();
+};

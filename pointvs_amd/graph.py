@@ -153,10 +153,13 @@ def prepare_graph(edge_index, edge_attr, n_nodes):
 
 _CACHE = collections.OrderedDict()
 _CACHE_SIZE = 4
+CACHE_ENABLED = True   # bench.py turns this off: a training step prepares every batch afresh
 
 
 def prepared_for(edge_index, edge_attr, n_nodes):
     """Cached `prepare_graph`: the L layers of a forward are called with the same edge tensors."""
+    if not CACHE_ENABLED:
+        return prepare_graph(edge_index, edge_attr, n_nodes)
     key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
            None if edge_attr is None else (edge_attr.data_ptr(), edge_attr._version), n_nodes)
     hit = _CACHE.get(key)

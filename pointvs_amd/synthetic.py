@@ -1,0 +1,69 @@
+"""Deterministic synthetic protein-ligand radius graphs (SURVEY.md §8d input generator).
+
+Edge rule = the reference's generate_edges with estimate_bonds=False
+(/root/reference/point_vs/preprocessing/preprocessing.py:108-142): block 1 = every ordered
+ligand<->receptor pair with 1e-7 < d < r (class 1); block 2 = every ordered pair with
+1e-7 < d < r (class 2 if both receptor, else 0), each block row-major - so inter-molecular pairs
+appear twice. edge_attr is the int64 one-hot(3) the data loader emits
+(data_loaders.py:370), edge_index int64.
+"""
+import numpy as np
+import torch
+
+from .graph import Batch, Data
+
+
+def synthetic_graph(seed, n_nodes=2000, n_lig=30, edge_radius=10.0, density=0.05, n_feats=12):
+    rng = np.random.default_rng(seed)
+    big_r = (3.0 * n_nodes / (4.0 * np.pi * density)) ** (1.0 / 3.0)
+    direction = rng.normal(size=(n_nodes, 3))
+    direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+    pts = (direction * (big_r * rng.random(n_nodes) ** (1.0 / 3.0))[:, None]).astype(np.float32)
+    order = np.argsort(np.linalg.norm(pts, axis=1), kind='stable')
+    pts = pts[order]                       # ligand = the n_lig points nearest the centre
+    bp = np.ones(n_nodes, dtype=np.int64)
+    bp[:n_lig] = 0
+    feats = np.zeros((n_nodes, n_feats), dtype=np.float32)
+    feats[np.arange(n_nodes), rng.integers(0, n_feats - 1, n_nodes)] = 1.0
+    feats[:, n_feats - 1] = bp
+    p64 = pts.astype(np.float64)
+    sq = (p64 ** 2).sum(1)
+    d2 = np.maximum(sq[:, None] + sq[None, :] - 2.0 * p64 @ p64.T, 0.0)
+    adj = (d2 < edge_radius ** 2) & (d2 > 1e-14)
+    rows, cols = np.nonzero(adj)           # row-major, like np.where in the reference
+    inter = bp[rows] != bp[cols]
+    e_rows = np.concatenate([rows[inter], rows])
+    e_cols = np.concatenate([cols[inter], cols])
+    intra_type = np.where((bp[rows] == 1) & (bp[cols] == 1), 2, 0)
+    e_type = np.concatenate([np.ones(int(inter.sum()), dtype=np.int64), intra_type])
+    return Data(
+        x=torch.from_numpy(feats), pos=torch.from_numpy(pts),
+        edge_index=torch.from_numpy(np.vstack([e_rows, e_cols]).astype(np.int64)),
+        edge_attr=torch.nn.functional.one_hot(torch.from_numpy(e_type), 3),
+        y=torch.tensor(seed % 2), lig_fname=f'lig_{seed}', rec_fname=f'rec_{seed}')
+
+
+def synthetic_batch(cfg_id, batch_size, first_graph=0, **graph_kwargs):
+    """Batch of graphs g = first_graph .. first_graph+batch_size-1 with seed 1000*cfg_id + g."""
+    graphs = [synthetic_graph(1000 * cfg_id + g, **graph_kwargs)
+              for g in range(first_graph, first_graph + batch_size)]
+    return Batch.from_data_list(graphs)
+
+
+# BASELINE.json configs
+CONFIGS = {
+    'cfg2': dict(cfg_id=2, graph=dict(n_nodes=2000, n_lig=30, edge_radius=10.0),
+                 model=dict(dim_input=12, k=32, dim_output=1, num_layers=3, residual=False,
+                            edge_residual=False, edge_attention=False, normalize=False, tanh=False,
+                            dropout=0.0, graphnorm=False, update_coords=True,
+                            permutation_invariance=False, node_attention=False,
+                            gated_residual=False, rezero=False, softmax_attention=False,
+                            model_task='classification')),
+    'cfg3': dict(cfg_id=3, graph=dict(n_nodes=2000, n_lig=30, edge_radius=6.0),
+                 model=dict(dim_input=12, k=64, dim_output=1, num_layers=12, residual=False,
+                            edge_residual=False, edge_attention=True, normalize=False, tanh=False,
+                            dropout=0.0, graphnorm=False, update_coords=True,
+                            permutation_invariance=False, node_attention=True,
+                            gated_residual=False, rezero=False, softmax_attention=False,
+                            model_task='classification')),
+}

@@ -1,0 +1,156 @@
+"""CPU-side checks: C-ABI export surface, class surface / state_dict contract, synthetic inputs,
+loud failure without a GPU, and the data-parallel gradient exchange on gloo (world_size 2)."""
+import ctypes
+import os
+import re
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    from pointvs_amd import _lib
+    header = (ROOT / 'include' / 'pvs_egnn.h').read_text()
+    declared = set(re.findall(r'\b(pvs_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'no declarations parsed'
+    assert _lib.LIB_PATH.exists(), 'run __graft_entry__.build() first'
+    handle = ctypes.CDLL(str(_lib.LIB_PATH))
+    for name in sorted(declared):
+        assert hasattr(handle, name), f'{name} declared in pvs_egnn.h but not exported'
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert _lib.lib().pvs_version() >= 100
+
+
+def test_state_dict_contract_and_seeded_init_match_reference():
+    from pointvs_amd.egnn_multitask import MultitaskSatorrasEGNN
+    from pointvs_amd.egnn_satorras import SartorrasEGNN
+    from tests._golden import CASES, GoldenCase
+    for name in CASES:
+        c = GoldenCase(name)
+        torch.manual_seed(c.meta['seed'])
+        cls = SartorrasEGNN if c.meta['class'] == 'SartorrasEGNN' else MultitaskSatorrasEGNN
+        model = cls(Path('/tmp/pvs_t'), c.meta['lr'], c.meta['wd'], None, None, silent=True,
+                    **c.meta['kwargs'])
+        sd = model.state_dict()
+        assert list(sd.keys()) == list(c.sd.keys()), name
+        for k, v in sd.items():
+            assert np.array_equal(v.cpu().numpy(), c.sd[k]), (name, k)
+        assert [n for n, _ in model.named_parameters()] == c.meta['param_order']
+
+
+def test_param_counts_match_survey():
+    from pointvs_amd.egnn_satorras import SartorrasEGNN
+    from pointvs_amd.synthetic import CONFIGS
+    m2 = SartorrasEGNN(Path('/tmp/pvs_t'), 2e-3, 1e-4, silent=True, **CONFIGS['cfg2']['model'])
+    m3 = SartorrasEGNN(Path('/tmp/pvs_t'), 2e-3, 1e-4, silent=True, **CONFIGS['cfg3']['model'])
+    assert m2.param_count == 22913      # SURVEY.md §8a row a1 [probe]
+    assert m3.param_count == 354201
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU behaviour')
+def test_no_cpu_fallback():
+    """The product path must fail loudly on CPU tensors instead of computing somewhere else."""
+    from pointvs_amd.egnn_satorras import EGNNLayer
+    layer = EGNNLayer(16, 16, 16, edges_in_d=3)
+    h = torch.randn(5, 16)
+    ei = torch.tensor([[0, 1, 2], [1, 2, 3]])
+    ea = torch.nn.functional.one_hot(torch.tensor([0, 1, 2]), 3)
+    with pytest.raises(RuntimeError, match='HIP device only'):
+        layer(h, ei, torch.randn(5, 3), ea)
+
+
+def test_product_never_imports_the_oracle():
+    for path in (ROOT / 'pointvs_amd').rglob('*.py'):
+        text = path.read_text()
+        assert 'import oracle' not in text and 'from oracle' not in text, path
+
+
+def test_synthetic_graph_follows_reference_edge_rule():
+    from pointvs_amd.synthetic import synthetic_graph
+    g = synthetic_graph(2000, n_nodes=300, n_lig=20, edge_radius=6.0)
+    ei, et = g.edge_index.numpy(), g.edge_attr.argmax(1).numpy()
+    assert g.edge_attr.dtype == torch.int64 and bool((g.edge_attr.sum(1) == 1).all())
+    bp = g.x[:, 11].numpy().astype(int)
+    d = np.linalg.norm(g.pos.numpy()[ei[0]] - g.pos.numpy()[ei[1]], axis=1)
+    assert (d < 6.0 + 1e-4).all() and (d > 0).all()
+    n_inter = int((et == 1).sum())
+    # block 1 = inter-molecular pairs, row-major; block 2 = all pairs, row-major
+    assert (bp[ei[0, :n_inter]] != bp[ei[1, :n_inter]]).all()
+    for lo, hi in ((0, n_inter), (n_inter, ei.shape[1])):
+        keys = ei[0, lo:hi].astype(np.int64) * 300 + ei[1, lo:hi]
+        assert (np.diff(keys) > 0).all()
+    blk2 = et[n_inter:]
+    both_rec = (bp[ei[0, n_inter:]] == 1) & (bp[ei[1, n_inter:]] == 1)
+    assert (blk2[both_rec] == 2).all() and (blk2[~both_rec] == 0).all()
+    # every inter pair appears twice, graph is symmetric
+    pairs = set(zip(ei[0].tolist(), ei[1].tolist()))
+    assert all((b, a) in pairs for a, b in pairs)
+    assert ei.shape[1] - len(pairs) == n_inter
+    g2 = synthetic_graph(2000, n_nodes=300, n_lig=20, edge_radius=6.0)
+    assert torch.equal(g.edge_index, g2.edge_index) and torch.equal(g.pos, g2.pos)
+
+
+def test_batch_collation():
+    from pointvs_amd.graph import Batch
+    from pointvs_amd.synthetic import synthetic_graph
+    gs = [synthetic_graph(s, n_nodes=50, n_lig=5, edge_radius=5.0) for s in (1, 2, 3)]
+    b = Batch.from_data_list(gs)
+    assert b.num_graphs == 3 and b.ptr.tolist() == [0, 50, 100, 150]
+    assert b.batch.tolist() == [0] * 50 + [1] * 50 + [2] * 50
+    off = gs[0].edge_index.shape[1]
+    assert torch.equal(b.edge_index[:, off:off + gs[1].edge_index.shape[1]], gs[1].edge_index + 50)
+    assert b.y.tolist() == [1, 0, 1]
+
+
+def test_shard_range_partitions_all_graphs():
+    from pointvs_amd.distributed import shard_range
+    for n, w in ((256, 8), (33, 4), (5, 8)):
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _ddp_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, str(ROOT))
+        from pointvs_amd.distributed import GradAllReducer
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5)),
+                  torch.nn.Parameter(torch.randn(2, 2))]
+        gen = torch.Generator().manual_seed(100 + rank)
+        params[0].grad = torch.randn(4, 3, generator=gen)
+        params[1].grad = None                         # "last layer coord_mlp": stays None
+        params[2].grad = torch.randn(2, 2, generator=gen)
+        red = GradAllReducer(params)
+        red()
+        red()   # second call reuses the bucket; averaging already-equal values changes nothing
+        out[rank] = (params[0].grad.clone(), params[1].grad, params[2].grad.clone())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_allreduce_gloo_world2():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
+    expect0 = sum(torch.randn(4, 3, generator=torch.Generator().manual_seed(100 + r))
+                  for r in range(2)) / 2
+    for rank in range(2):
+        g0, g1, g2 = out[rank]
+        assert g1 is None
+        assert torch.allclose(g0, expect0, atol=1e-6)
+    assert torch.equal(out[0][2], out[1][2])
