@@ -5,6 +5,15 @@
 #include "edge_kernels.h"
 #include "node_ops.h"
 
+#include <stdlib.h>
+
+// PVS_EGNN_KERNELS=generic forces the generic (VALU/LDS) edge kernels everywhere: used by the
+// tests to cross-check the MFMA path against the generic one on the same inputs.
+static bool pvs_use_mfma() {
+    const char* v = getenv("PVS_EGNN_KERNELS");
+    return !(v && v[0] == 'g');
+}
+
 namespace {
 
 struct Dims {
@@ -225,7 +234,10 @@ extern "C" int pvs_egnn_layer_fwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     PvsEdgeFwdIO io;
     io.PQ = w.PQ; io.x = x; io.m_prev = m_prev; io.Magg = Magg; io.x_out = x_out; io.m_out = m_out;
     io.att_out = att_out; io.smax = w.smax; io.ssum = w.ssum;
-    PVS_TRY(pvs_launch_edge_fwd_v0(s, H, *g, ew, d->flags, d->att_act, io));
+    if (pvs_use_mfma() && pvs_edge_mfma_supported(H, d->flags))
+        PVS_TRY(pvs_launch_edge_fwd_mfma(s, H, *g, ew, d->flags, d->att_act, io));
+    else
+        PVS_TRY(pvs_launch_edge_fwd_v0(s, H, *g, ew, d->flags, d->att_act, io));
     if (!(d->flags & PVS_UPDATE_COORDS))
         PVS_CHECK_HIP(hipMemcpyAsync(x_out, x, sizeof(float) * 3 * (size_t)m.N,
                                      hipMemcpyDeviceToDevice, s));
