@@ -72,6 +72,9 @@ __host__ __device__ static inline PvsSlabLayout pvs_slab_layout(int H) {
 int pvs_edge_mfma_supported(int H, uint32_t flags);
 int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,
                              int att_act, const PvsEdgeFwdIO& io);
+int pvs_edge_bwd_mfma_supported(int H, uint32_t flags, int n_attr);
+int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,
+                             int att_act, const PvsEdgeBwdIO& io, int* n_slabs);
 int pvs_edge_v0_supported(int H);
 int pvs_edge_v0_blocks(int N);
 int pvs_launch_edge_fwd_v0(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,

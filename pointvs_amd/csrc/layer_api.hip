@@ -340,7 +340,10 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     io.g_m_out = g_m_out; io.gPQ = w.gPQ; io.gz1 = w.gz1; io.gd = w.gd; io.gx_row = w.gx_row;
     io.g_m_prev = eres ? g_m_prev : nullptr; io.slabs = w.eslabs;
     int n_slabs = 0;
-    PVS_TRY(pvs_launch_edge_bwd_v0(s, H, *g, ew, F, d->att_act, io, &n_slabs));
+    if (pvs_use_mfma() && pvs_edge_bwd_mfma_supported(H, F, m.A))
+        PVS_TRY(pvs_launch_edge_bwd_mfma(s, H, *g, ew, F, d->att_act, io, &n_slabs));
+    else
+        PVS_TRY(pvs_launch_edge_bwd_v0(s, H, *g, ew, F, d->att_act, io, &n_slabs));
     PVS_TRY(pvs_launch_col_gather(s, H, *g, w.gz1, w.gd, w.gx_row, g_x_out, w.gPQ, g_x));
     const PvsSlabLayout L = pvs_slab_layout(H);
     PVS_TRY(pvs_launch_reduce_slabs(s, w.gsum, L.total, L.total, w.eslabs, n_slabs, L.total, false));
