@@ -214,7 +214,7 @@ def main():
                        'graphs_per_gpu': args.batch, 'global_batch': world * args.batch,
                        'parallelism': f'dp{world}', 'final_loss': round(final_loss, 6)},
             'roofline': {
-                'bound': 'hbm', 'kernel': 'k_edge_bwd_v0 (edge backward, one launch per layer)',
+                'bound': 'hbm', 'kernel': 'k_edge_bwd_mfma<1> (edge backward, one launch per layer)',
                 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
                 'algorithmic_bytes_per_launch': dom_bytes,

@@ -48,22 +48,24 @@ struct PvsArena {
 };
 
 // ---- device math: SiLU / sigmoid and their derivatives ----
-__device__ __forceinline__ float pvs_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
+// One v_exp_f32 + one v_rcp_f32 (1 ulp each) per sigmoid: an IEEE division costs ~10 VALU
+// instructions and the edge kernels evaluate ~100 sigmoids per edge.
+__device__ __forceinline__ float pvs_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+__device__ __forceinline__ float pvs_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.4426950408889634f); }
+__device__ __forceinline__ float pvs_sigmoid(float v) { return pvs_rcp(1.0f + pvs_exp(-v)); }
 __device__ __forceinline__ float pvs_silu(float v) { return v * pvs_sigmoid(v); }
 // d/dv [v*sigmoid(v)] given s = sigmoid(v)
 __device__ __forceinline__ float pvs_silu_grad(float v, float s) { return s * (1.0f + v * (1.0f - s)); }
 __device__ __forceinline__ float pvs_tanh(float v) {
-    // tanh(v) = 1 - 2/(exp(2v)+1); exact limits at +-inf, no cancellation blow-up near 0 beyond 1 ulp of 1
-    float a = fabsf(v);
-    float t;
-    if (a < 0.35f) {  // odd series region: keep relative accuracy for small |v|
-        float v2 = v * v;
-        t = v * (1.0f + v2 * (-0.33333334f + v2 * (0.13333334f + v2 * (-0.053968254f + v2 * 0.021869488f))));
-    } else {
-        float e = __expf(2.0f * a);
-        t = copysignf(1.0f - 2.0f / (e + 1.0f), v);
+    // |v| < 0.35: odd series (relative accuracy for tiny arguments: coord_mlp's last layer is
+    // initialised with gain 1e-3); else 1 - 2/(exp(2|v|)+1) with the sign restored.
+    const float a = fabsf(v);
+    if (a < 0.35f) {
+        const float v2 = v * v;
+        return v * (1.0f + v2 * (-0.33333334f + v2 * (0.13333334f + v2 * (-0.053968254f + v2 * 0.021869488f))));
     }
-    return t;
+    const float e = pvs_exp(2.0f * a);
+    return copysignf(1.0f - 2.0f * pvs_rcp(e + 1.0f), v);
 }
 
 // attention activation (PVS_ACT_*) and derivative wrt its logit, given logit l and value a

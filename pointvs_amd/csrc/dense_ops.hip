@@ -123,16 +123,28 @@ k_colreduce(int mode, float* __restrict__ slabs, const float* __restrict__ A, in
     }
 }
 
-__global__ void k_reduce_slabs(float* __restrict__ out, int ldo, int inner,
-                               const float* __restrict__ slabs, int n_slabs, int width, float scale,
-                               int accumulate) {
-    int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= width) return;
+// out[map(o)] (=|+=) scale * sum_g slabs[g][o].  One block per 32 outputs: 8 slab lanes x 32
+// outputs; each slab lane sums its slabs g = lane, lane+8, ... in order, then the 8 partials are
+// added in lane order: a fixed summation tree, so the result is reproducible.
+__global__ void __launch_bounds__(kThreads)
+k_reduce_slabs(float* __restrict__ out, int ldo, int inner, const float* __restrict__ slabs,
+               int n_slabs, int width, float scale, int accumulate) {
+    __shared__ float part[8][33];
+    const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int o = blockIdx.x * 32 + ol;
     float s = 0.f;
-    for (int g = 0; g < n_slabs; ++g) s += slabs[(size_t)g * width + o];
-    s *= scale;
-    float* dst = out + (size_t)(o / inner) * ldo + (o % inner);
-    *dst = accumulate ? *dst + s : s;
+    if (o < width)
+        for (int gidx = sl; gidx < n_slabs; gidx += 8) s += slabs[(size_t)gidx * width + o];
+    part[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && o < width) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += part[k][ol];
+        t *= scale;
+        float* dst = out + (size_t)(o / inner) * ldo + (o % inner);
+        *dst = accumulate ? *dst + t : t;
+    }
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -211,8 +223,8 @@ int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx,
 
 int pvs_launch_reduce_slabs(hipStream_t s, float* out, int ldo, int inner, const float* slabs,
                             int n_slabs, int width, bool accumulate) {
-    k_reduce_slabs<<<(width + 255) / 256, 256, 0, s>>>(out, ldo, inner, slabs, n_slabs, width, 1.0f,
-                                                       accumulate ? 1 : 0);
+    k_reduce_slabs<<<(width + 31) / 32, kThreads, 0, s>>>(out, ldo, inner, slabs, n_slabs, width, 1.0f,
+                                                          accumulate ? 1 : 0);
     PVS_CHECK_LAUNCH();
     return 0;
 }
@@ -240,8 +252,8 @@ int pvs_launch_colreduce(hipStream_t s, int mode, float* out, const float* A, in
     const int rpb = rows_per_block_for(N, blocks);
     k_colreduce<<<blocks, kThreads, 0, s>>>(mode, slabs, A, lda, B, ldb, shift, N, C, rpb);
     PVS_CHECK_LAUNCH();
-    k_reduce_slabs<<<(C + 255) / 256, 256, 0, s>>>(out, C, C, slabs, blocks, C, scale,
-                                                   accumulate ? 1 : 0);
+    k_reduce_slabs<<<(C + 31) / 32, kThreads, 0, s>>>(out, C, C, slabs, blocks, C, scale,
+                                                      accumulate ? 1 : 0);
     PVS_CHECK_LAUNCH();
     return 0;
 }

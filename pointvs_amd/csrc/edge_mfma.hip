@@ -332,8 +332,8 @@ __device__ __forceinline__ void store_x(float* __restrict__ base, int hh, const 
 // gradients as products over the EDGE index (operands re-read edge-major from per-wave LDS tiles),
 // 96 MFMAs per 32x32 block in total. Vector gradients ride on the same LDS tiles with the channel
 // on the lane (one accumulator register each).
-template <int HB>
-__global__ void __launch_bounds__(kThreads)
+template <int HB, bool ERES, bool EATT>
+__global__ void __launch_bounds__(kThreads, 2)
 k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks) {
     constexpr int H = 32 * HB;
     constexpr int TS = H + 4;
@@ -353,8 +353,8 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     constexpr int kWaveFloats = 3 * kTile * TS + kTile * 4 + kTile * 8 + kTile;
 
     const bool upd = (flags & PVS_UPDATE_COORDS) && io.gxagg != nullptr;
-    const bool eatt = flags & PVS_EDGE_ATTENTION;
-    const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
+    constexpr bool eatt = EATT;
+    constexpr bool eres = ERES;
 
     stage_weights<HB>(W2s, w.w2, false);
     stage_weights<HB>(W2ts, w.w2, true);
@@ -402,12 +402,12 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
 #pragma unroll
         for (int r = 0; r < 16; ++r) g_wc2x[b][r] = 0.f;
     // channel-on-lane accumulators (lane = channel 32b + j, parity hh)
-    float g_b2[HB], g_bc1[HB], g_wa[HB], g_wrho[HB], g_wattr[HB][PVS_MAX_EDGE_ATTR];
+    float g_b2[HB], g_bc1[HB], g_wa[HB], g_wrho[HB], g_wattr[HB][6];
 #pragma unroll
     for (int b = 0; b < HB; ++b) {
         g_b2[b] = g_bc1[b] = g_wa[b] = g_wrho[b] = 0.f;
 #pragma unroll
-        for (int t = 0; t < PVS_MAX_EDGE_ATTR; ++t) g_wattr[b][t] = 0.f;
+        for (int t = 0; t < 6; ++t) g_wattr[b][t] = 0.f;
     }
     float g_ba = 0.f, g_gate = 0.f;
 
@@ -447,7 +447,6 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
             const float rho = d0 * d0 + d1 * d1 + d2 * d2;
 
             // ---- recompute: z1, a1 ----
-            float z1[HB][16], s1[HB][16];
             {
                 const float* Pp = io.PQ + (size_t)i * 2 * H + 4 * hh;
                 const float* Qp = io.PQ + (size_t)jn * 2 * H + H + 4 * hh;
@@ -467,10 +466,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                                              p.z + q.z + fmaf(r.z, rho, a.z), p.w + q.w + fmaf(r.w, rho, a.w)};
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4) {
-                            const float sg = pvs_sigmoid(zz[q4]);
-                            z1[b][4 * gq + q4] = zz[q4];
-                            s1[b][4 * gq + q4] = sg;
-                            a1[b][4 * gq + q4] = zz[q4] * sg;
+                            a1[b][4 * gq + q4] = pvs_silu(zz[q4]);
                         }
                     }
                 // a1 edge-major in T0 for the W2 weight gradient (zero rows for padded slots)
@@ -489,23 +485,19 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[b][r] = bias[b][r];
                 mfma_chain<HB>(W2s, lane, a1, acc2);
-#pragma unroll
-                for (int b = 0; b < HB; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) z1[b][r] = z1[b][r], a1[b][r] = acc2[b][r];
-                // keep z2 in a1's registers from here on
-                float (&z2)[HB][16] = a1;
-                float s2[HB][16], m[HB][16], m_new[HB][16];
+                float dz2[HB][16], m[HB][16];     // SiLU'(z2) and the message
+                float m_new[ERES ? HB : 1][16], mp[ERES ? HB : 1][16];
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        s2[b][r] = pvs_sigmoid(z2[b][r]);
-                        m_new[b][r] = z2[b][r] * s2[b][r];
-                        m[b][r] = m_new[b][r];
+                        const float z2 = acc2[b][r];
+                        const float sg = pvs_sigmoid(z2);
+                        dz2[b][r] = pvs_silu_grad(z2, sg);
+                        m[b][r] = z2 * sg;
+                        if constexpr (ERES) m_new[b][r] = m[b][r];
                     }
-                float mp[HB][16];
-                if (eres) {
+                if constexpr (ERES) {
                     load_x<HB>(io.m_prev + (size_t)ee * H, hh, mp);
 #pragma unroll
                     for (int b = 0; b < HB; ++b)
@@ -537,7 +529,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 float gMi[HB][16];
                 load_x<HB>(io.gM + (size_t)i * H, hh, gMi);
                 float g_l = 0.f, aval = 1.f;
-                if (eatt) {
+                if constexpr (EATT) {
                     const float logit = dot_tab<HB>(wat, hh, m) + bac;
                     aval = io.att[ee];
                     float dot = 0.f;
@@ -653,7 +645,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                     for (int r = 0; r < 16; ++r) {
                         const float gmv = gm[b][r];
                         float gnew = gmv;
-                        if (eres) {
+                        if constexpr (ERES) {
                             if (flags & PVS_REZERO) {
                                 gnew = gate * gmv;
                                 g_gate = fmaf(gmv, m_new[b][r], g_gate);
@@ -666,9 +658,11 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                                 mp[b][r] = gmv;
                             }
                         }
-                        g_z2[b][r] = gnew * pvs_silu_grad(z2[b][r], s2[b][r]);
+                        g_z2[b][r] = gnew * dz2[b][r];
                     }
-                if (eres && valid) store_x<HB>(io.g_m_prev + (size_t)e * H, hh, mp);
+                if constexpr (ERES) {
+                    if (valid) store_x<HB>(io.g_m_prev + (size_t)e * H, hh, mp);
+                }
                 pvs_wave_lds_sync();      // all reads of T2 (g_zc) done before it is reused
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
@@ -684,11 +678,25 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ga1[b][r] = 0.f;
                 mfma_chain<HB>(W2ts, lane, g_z2, ga1);
+                // SiLU'(z1): z1 is re-gathered here (L2-hot) instead of living in 16 registers
+                // across the whole tile
                 float g_z1[HB][16];
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) g_z1[b][r] = ga1[b][r] * pvs_silu_grad(z1[b][r], s1[b][r]);
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int off = 32 * b + 8 * gq;
+                        const float4 p = *reinterpret_cast<const float4*>(Pp + off);
+                        const float4 q = *reinterpret_cast<const float4*>(Qp + off);
+                        const float4 a = *reinterpret_cast<const float4*>(At + off);
+                        const float4 r = *reinterpret_cast<const float4*>(Rt + off);
+                        const float zz[4] = {p.x + q.x + fmaf(r.x, rho, a.x), p.y + q.y + fmaf(r.y, rho, a.y),
+                                             p.z + q.z + fmaf(r.z, rho, a.z), p.w + q.w + fmaf(r.w, rho, a.w)};
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4)
+                            g_z1[b][4 * gq + q4] =
+                                ga1[b][4 * gq + q4] * pvs_silu_grad(zz[q4], pvs_sigmoid(zz[q4]));
+                    }
                 if (valid) store_x<HB>(io.gz1 + (size_t)e * H, hh, g_z1);
                 const float g_rho = dot_tab<HB>(wrhot, hh, g_z1);
                 const float k1 = s_coord * nrm * vm;
@@ -729,7 +737,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                                         g_z1[b][4 * gq + 3]);
                 pvs_wave_lds_sync();
                 for (int el = 0; el < kTile; ++el) {
-                    if ((bmask >> el) & 1u) {
+                    if (bmask && ((bmask >> el) & 1u)) {
                         flush(cur_row);
                         cur_row = __builtin_amdgcn_readfirstlane(rowbuf[el]);
                     }
@@ -782,7 +790,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
         g_wa[b] += __shfl_xor(g_wa[b], 32, 64);
         g_wrho[b] += __shfl_xor(g_wrho[b], 32, 64);
 #pragma unroll
-        for (int t = 0; t < PVS_MAX_EDGE_ATTR; ++t) g_wattr[b][t] += __shfl_xor(g_wattr[b][t], 32, 64);
+        for (int t = 0; t < 6; ++t) g_wattr[b][t] += __shfl_xor(g_wattr[b][t], 32, 64);
     }
     for (int turn = 0; turn < kWaves; ++turn) {
         if (wv == turn) {
@@ -805,7 +813,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                     slab[L.wa + c] += g_wa[b];
                     slab[L.wrho + c] += g_wrho[b];
 #pragma unroll
-                    for (int t = 0; t < PVS_MAX_EDGE_ATTR; ++t) slab[L.wattr + t * H + c] += g_wattr[b][t];
+                    for (int t = 0; t < 6; ++t) slab[L.wattr + t * H + c] += g_wattr[b][t];
                 }
             }
             if (j == 0) {
@@ -900,8 +908,18 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
                    (size_t)kWaves * (3 * kTile * (H + 4) + kTile * 4 + kTile * 8 + kTile);
     if (words < (size_t)L.total) words = L.total;
     const size_t lds = words * sizeof(float);
-    if (set_lds(k_edge_bwd_mfma<1>, lds)) return -2;
-    k_edge_bwd_mfma<1><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks);
+    const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
+    const bool eatt = flags & PVS_EDGE_ATTENTION;
+#define PVS_BWD_LAUNCH(ER, EA)                                                                    \
+    do {                                                                                          \
+        if (set_lds(k_edge_bwd_mfma<1, ER, EA>, lds)) return -2;                                  \
+        k_edge_bwd_mfma<1, ER, EA><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks); \
+    } while (0)
+    if (eres && eatt) PVS_BWD_LAUNCH(true, true);
+    else if (eres) PVS_BWD_LAUNCH(true, false);
+    else if (eatt) PVS_BWD_LAUNCH(false, true);
+    else PVS_BWD_LAUNCH(false, false);
+#undef PVS_BWD_LAUNCH
     PVS_CHECK_LAUNCH();
     return 0;
 }

@@ -1,4 +1,4 @@
-// Generic (any flag set, H in {8,16,32,64}) edge kernels: one wavefront walks one destination-row
+// Generic (any flag set, H in {16,32,64}) edge kernels: one wavefront walks one destination-row
 // segment of the CSR; lane = (edge slot, channel); the per-edge MLPs are GEMVs with the weights in
 // LDS and the edge's activation vector broadcast through a per-wave LDS scratch; the per-row sums
 // (scatter-sum / scatter-mean of the reference) are lane-local accumulators, so there are no
@@ -421,41 +421,57 @@ k_edge_bwd_v0(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO 
 }
 
 // gPQ[j, H + c] = sum_{edges with col j} gz1[e, c];  g_x[n] = g_x_out[n] + gx_row[n] - sum gd[e]
+// Lane = (edge slot, 16-byte quad of the row): one wave-instruction fetches 64/(H/4) whole rows,
+// two batches of independent index + row loads are in flight per iteration (latency-bound gather).
 template <int H>
 __global__ void __launch_bounds__(kThreads)
 k_col_gather(PvsGraph g, const float* __restrict__ gz1, const float* __restrict__ gd,
              const float* __restrict__ gx_row, const float* __restrict__ g_x_out,
              float* __restrict__ gPQ, float* __restrict__ g_x) {
-    constexpr int EPW = 64 / H;
+    constexpr int QPR = H / 4;          // float4 quads per row
+    constexpr int EPW = 64 / QPR;       // rows per wave-instruction
+    constexpr int UN = 4;               // independent batches in flight
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c = lane % H, sub = lane / H;
+    const int quad = lane % QPR, sub = lane / QPR;
     const int total_waves = gridDim.x * kWaves;
     for (int j = blockIdx.x * kWaves + wv; j < g.n_nodes; j += total_waves) {
         const int p0 = g.colptr[j], p1 = g.colptr[j + 1];
-        float acc = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int pb = p0; pb < p1; pb += EPW) {
-            const int p = pb + sub;
-            if (p < p1) {
-                const int e = g.cedge[p];
-                acc += gz1[(size_t)e * H + c];
-                if (g_x && c < 3) {
-                    const float v = gd[(size_t)e * 3 + c];
-                    if (c == 0) a0 += v; else if (c == 1) a1 += v; else a2 += v;
-                }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float ax = 0.f;                 // lanes with quad == 0 own coordinate component sub % 3 ... see below
+        for (int pb = p0; pb < p1; pb += EPW * UN) {
+            int idx[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int p = pb + u * EPW + sub;
+                idx[u] = p < p1 ? g.cedge[p] : -1;
+            }
+            float4 v[UN];
+            float dv[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                v[u] = idx[u] >= 0 ? *reinterpret_cast<const float4*>(gz1 + (size_t)idx[u] * H + 4 * quad)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                dv[u] = (g_x && quad < 3 && idx[u] >= 0) ? gd[(size_t)idx[u] * 3 + quad] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+                ax += dv[u];
             }
         }
+        // combine the EPW edge slots (lanes with equal quad)
 #pragma unroll
-        for (int o = H; o < 64; o <<= 1) {
-            acc += __shfl_xor(acc, o, 64);
-            a0 += __shfl_xor(a0, o, 64);
-            a1 += __shfl_xor(a1, o, 64);
-            a2 += __shfl_xor(a2, o, 64);
+        for (int o = QPR; o < 64; o <<= 1) {
+            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+            acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+            ax += __shfl_xor(ax, o, 64);
         }
-        if (sub == 0) gPQ[(size_t)j * 2 * H + H + c] = acc;
-        if (g_x && sub == 0 && c < 3) {
-            const float col_side = c == 0 ? a0 : (c == 1 ? a1 : a2);
-            const float base = g_x_out ? g_x_out[3 * j + c] : 0.f;
-            g_x[3 * j + c] = base + gx_row[3 * j + c] - col_side;
+        if (sub == 0) {
+            *reinterpret_cast<float4*>(gPQ + (size_t)j * 2 * H + H + 4 * quad) = acc;
+            if (g_x && quad < 3) {
+                const float base = g_x_out ? g_x_out[3 * j + quad] : 0.f;
+                g_x[3 * j + quad] = base + gx_row[3 * j + quad] - ax;
+            }
         }
     }
 }
@@ -470,7 +486,7 @@ int set_lds(K kernel, size_t lds) {
 
 }  // namespace
 
-int pvs_edge_v0_supported(int H) { return H == 8 || H == 16 || H == 32 || H == 64; }
+int pvs_edge_v0_supported(int H) { return H == 16 || H == 32 || H == 64; }
 
 int pvs_edge_v0_blocks(int N) {
     int b = (N + kWaves - 1) / kWaves;
@@ -481,11 +497,10 @@ int pvs_edge_v0_blocks(int N) {
 
 #define PVS_DISPATCH_H(H, ...)                                         \
     switch (H) {                                                       \
-        case 8: { constexpr int HH = 8; __VA_ARGS__; break; }                 \
         case 16: { constexpr int HH = 16; __VA_ARGS__; break; }               \
         case 32: { constexpr int HH = 32; __VA_ARGS__; break; }               \
         case 64: { constexpr int HH = 64; __VA_ARGS__; break; }               \
-        default: pvs_set_error("edge kernels: hidden size %d unsupported (8,16,32,64)", H); return -1; \
+        default: pvs_set_error("edge kernels: hidden size %d unsupported (16,32,64)", H); return -1; \
     }
 
 int pvs_launch_edge_fwd_v0(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,

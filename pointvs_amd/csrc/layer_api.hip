@@ -55,7 +55,7 @@ PvsNodeW make_node_w(const PvsLayerDesc* d, const PvsLayerParams* p) {
 int check_desc(const PvsLayerDesc* d, const PvsGraph* g, const PvsLayerParams* p) {
     PVS_REQUIRE(d && g && p, "NULL descriptor/graph/params");
     PVS_REQUIRE(pvs_edge_v0_supported(d->hidden),
-                "hidden size %d unsupported by this build (8, 16, 32, 64)", d->hidden);
+                "hidden size %d unsupported by this build (16, 32, 64)", d->hidden);
     PVS_REQUIRE(d->n_edge_attr >= 0 && d->n_edge_attr <= PVS_MAX_EDGE_ATTR,
                 "n_edge_attr %d unsupported (0..%d)", d->n_edge_attr, PVS_MAX_EDGE_ATTR);
     PVS_REQUIRE(!((d->flags & PVS_GATED_RESIDUAL) && (d->flags & PVS_REZERO)),

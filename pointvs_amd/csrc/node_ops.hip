@@ -230,11 +230,10 @@ int pvs_node_tail_fwd(hipStream_t s, const float* y1, const float* stats, const 
 
 #define PVS_NODE_DISPATCH_H(H, ...)                                    \
     switch (H) {                                                       \
-        case 8: { constexpr int HH = 8; __VA_ARGS__; break; }          \
         case 16: { constexpr int HH = 16; __VA_ARGS__; break; }        \
         case 32: { constexpr int HH = 32; __VA_ARGS__; break; }        \
         case 64: { constexpr int HH = 64; __VA_ARGS__; break; }        \
-        default: pvs_set_error("node kernels: hidden size %d unsupported (8,16,32,64)", H); return -1; \
+        default: pvs_set_error("node kernels: hidden size %d unsupported (16,32,64)", H); return -1; \
     }
 
 int pvs_node_out_fwd(hipStream_t s, int H, const float* o, const float* h, const PvsNodeW& w,
