@@ -184,6 +184,76 @@ __global__ void k_mean_pool_bwd(const float* __restrict__ gp, const int32_t* __r
     }
 }
 
+// MFMA weight-gradient product for 32-aligned shapes: out[c][k] = sum_n A[n][c] * B[n][k].
+// The sum runs over rows, so both operands are read straight from the row-major arrays in
+// A/B-operand order (lane l: row n + (l>>5), column 32*blk + (l&31): two coalesced 128-B runs per
+// instruction) - no LDS staging. Each wave walks its rows two at a time; the 4 waves of a block
+// are added in wave order through LDS; block partials go to slabs.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+template <int CB, int KB>
+__global__ void __launch_bounds__(kThreads)
+k_tsgemm_mfma(float* __restrict__ slabs, const float* __restrict__ A, int lda,
+              const float* __restrict__ B, int ldb, int N, int rows_per_block) {
+    __shared__ float red[CB * KB * 1024];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(N, r0 + rows_per_block);
+    f32x16_t acc[CB][KB];
+#pragma unroll
+    for (int a = 0; a < CB; ++a)
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    constexpr int UN = 4;
+    for (int n0 = r0 + wv * 2 * UN; n0 < r1; n0 += kThreads / 64 * 2 * UN) {
+        float av[UN][CB], bv[UN][KB];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int n = n0 + 2 * u + hh;
+            const bool ok = n < r1;
+#pragma unroll
+            for (int a = 0; a < CB; ++a) av[u][a] = ok ? A[(size_t)n * lda + 32 * a + j] : 0.f;
+#pragma unroll
+            for (int b = 0; b < KB; ++b) bv[u][b] = ok ? B[(size_t)n * ldb + 32 * b + j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int a = 0; a < CB; ++a)
+#pragma unroll
+                for (int b = 0; b < KB; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+    }
+    // D layout: register r of lane l = out[c = 32a + (r&3) + 8(r>>2) + 4hh][k = 32b + j]
+    for (int i = threadIdx.x; i < CB * KB * 1024; i += kThreads) red[i] = 0.f;
+    __syncthreads();
+    for (int turn = 0; turn < kThreads / 64; ++turn) {
+        if (wv == turn) {
+#pragma unroll
+            for (int a = 0; a < CB; ++a)
+#pragma unroll
+                for (int b = 0; b < KB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        red[((a * KB + b) * 32 + c) * 32 + j] += acc[a][b][r];
+                    }
+        }
+        __syncthreads();
+    }
+    // slab layout = row-major [C][K] like the generic kernel
+    constexpr int K = 32 * KB;
+    float* dst = slabs + (size_t)blockIdx.x * (CB * KB * 1024);
+    for (int i = threadIdx.x; i < CB * KB * 1024; i += kThreads) {
+        const int jj = i & 31, c = (i >> 5) & 31, blk = i >> 10;
+        const int a = blk / KB, b = blk % KB;
+        dst[(32 * a + c) * K + 32 * b + jj] = red[i];
+    }
+}
+
 int grid_for(long long work_items, int per_block) {
     long long b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -235,6 +305,15 @@ int pvs_launch_tsgemm_tn(hipStream_t s, float* out, int ldo, const float* A, int
     PVS_REQUIRE(CK <= 32 * kThreads, "tsgemm: %d x %d outputs unsupported", C, K);
     const int blocks = pvs_reduce_blocks(N);
     const int rpb = rows_per_block_for(N, blocks);
+    if (C % 32 == 0 && K % 32 == 0 && C <= 64 && K <= 64) {
+        const int cb = C / 32, kb = K / 32;
+        if (cb == 1 && kb == 1) k_tsgemm_mfma<1, 1><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb);
+        else if (cb == 1 && kb == 2) k_tsgemm_mfma<1, 2><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb);
+        else if (cb == 2 && kb == 1) k_tsgemm_mfma<2, 1><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb);
+        else k_tsgemm_mfma<2, 2><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb);
+        PVS_CHECK_LAUNCH();
+        return pvs_launch_reduce_slabs(s, out, ldo, K, slabs, blocks, CK, accumulate);
+    }
     size_t lds = (size_t)16 * (C + K) * sizeof(float);
     if (CK <= 8 * kThreads)
         k_tsgemm_tn<8><<<blocks, kThreads, lds, s>>>(slabs, A, lda, B, ldb, N, C, K, rpb);
