@@ -52,7 +52,11 @@ struct PvsArena {
 // instructions and the edge kernels evaluate ~100 sigmoids per edge.
 __device__ __forceinline__ float pvs_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 __device__ __forceinline__ float pvs_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.4426950408889634f); }
+#ifdef PVS_ABL_NO_SILU   // timing-only build: no transcendental in the activations
+__device__ __forceinline__ float pvs_sigmoid(float v) { return fmaf(0.1f, v, 0.5f); }
+#else
 __device__ __forceinline__ float pvs_sigmoid(float v) { return pvs_rcp(1.0f + pvs_exp(-v)); }
+#endif
 __device__ __forceinline__ float pvs_silu(float v) { return v * pvs_sigmoid(v); }
 // d/dv [v*sigmoid(v)] given s = sigmoid(v)
 __device__ __forceinline__ float pvs_silu_grad(float v, float s) { return s * (1.0f + v * (1.0f - s)); }
@@ -88,11 +92,27 @@ __device__ __forceinline__ float pvs_att_act_grad(int act, float l, float a) {
     }
 }
 
-// Same-wave LDS hand-off: order this wave's LDS writes before its later LDS reads.
+// rho (>= 0) and the edge class (< 4) share one float of the per-edge backward record: rho is
+// rounded to 22 mantissa bits (relative 1.2e-7, it only weights the w_rho gradient), the class
+// sits in the two low bits, so the column gather needs no separate 1-byte type gather.
+__device__ __forceinline__ float pvs_pack_rho_type(float rho, int ty) {
+    return __uint_as_float(((__float_as_uint(rho) + 2u) & ~3u) | (unsigned)(ty & 3));
+}
+__device__ __forceinline__ float pvs_unpack_rho(float packed, int* ty) {
+    const unsigned u = __float_as_uint(packed);
+    *ty = (int)(u & 3u);
+    return __uint_as_float(u & ~3u);
+}
+
+// Same-wave LDS hand-off: order this wave's LDS writes before its later LDS reads. LDS
+// instructions of one wave execute in issue order, so only the COMPILER must be kept from
+// reordering them: wavefront-scope fences emit no instruction. (A workgroup-scope release would
+// also drain every outstanding global load/store of the wave - s_waitcnt vmcnt(0) - at each
+// hand-off, serialising the gathers behind the reductions.)
 __device__ __forceinline__ void pvs_wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Sum over aligned groups of W consecutive lanes (W power of two <= 64); every lane gets the total.

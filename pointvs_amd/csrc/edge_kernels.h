@@ -41,7 +41,7 @@ struct PvsEdgeBwdIO {
     const float* g_m_out;  // [E,H] sorted or NULL
     float* gPQ;            // [N,2H]: row part written here (col part by the col gather)
     float* gz1;            // [E,H] sorted: grad wrt the first edge-MLP pre-activation
-    float* gd;             // [E,3] sorted: grad wrt (x_row - x_col)
+    float* gd;             // [E,4] sorted: grad wrt (x_row - x_col), and rho in .w
     float* gx_row;         // [N,3] row-side coordinate gradient
     float* g_m_prev;       // [E,H] sorted or NULL
     float* slabs;          // [blocks][slab_floats] per-block weight-gradient partials
@@ -81,6 +81,9 @@ int pvs_launch_edge_fwd_v0(hipStream_t s, int H, const PvsGraph& g, const PvsEdg
                            int att_act, const PvsEdgeFwdIO& io);
 int pvs_launch_edge_bwd_v0(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,
                            int att_act, const PvsEdgeBwdIO& io, int* n_slabs);
-// gPQ[j, H + c] = sum over edges with col j of gz1[e, c];  g_x[n] = g_x_out[n] + gx_row[n] - sum gd
-int pvs_launch_col_gather(hipStream_t s, int H, const PvsGraph& g, const float* gz1, const float* gd,
-                          const float* gx_row, const float* g_x_out, float* gPQ, float* g_x);
+// Column-side gather (see k_node_gather); with wsums also the g_wrho/g_wattr partial slabs
+// ([n_slabs][4H]: wrho, wattr0..2) that the MFMA backward leaves to this kernel.
+int pvs_node_gather_blocks(int N);
+int pvs_launch_node_gather(hipStream_t s, int H, const PvsGraph& g, bool wsums, const float* gz1,
+                           const float* gd4, const float* gx_row, const float* g_x_out, float* gPQ,
+                           float* g_x, float* slabs, int* n_slabs);

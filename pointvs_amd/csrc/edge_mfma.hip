@@ -25,6 +25,14 @@ constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 constexpr int kTile = 32;
 
+#ifndef PVS_PREFETCH
+#define PVS_PREFETCH 0   // gather tile t+1's node rows while tile t is reduced (0: gather at tile start)
+#endif
+
+// Timing-only ablation switches (PVS_ABLATE env, tools/ablate.py): results are wrong when set.
+constexpr uint32_t kAblNoMfma = 1u << 24, kAblNoSilu = 1u << 25, kAblNoReduce = 1u << 26,
+                   kAblNoGather = 1u << 27;
+
 __device__ __forceinline__ int xch(int t, int hh) { return (t & 3) + 8 * (t >> 2) + 4 * hh; }
 
 // Stage W[H][H] (row-major, W[out][in]) for  Z = W V  (transpose=false)  or  Z = W^T V  (true)
@@ -43,7 +51,13 @@ __device__ __forceinline__ void stage_weights(float* dst, const float* __restric
 // acc[bo] += sum over (bi,t) of A-staged weights x v[bi][t]   (v in X layout)
 template <int HB>
 __device__ __forceinline__ void mfma_chain(const float* __restrict__ Ws, int lane,
-                                           const float (&v)[HB][16], f32x16 (&acc)[HB]) {
+                                           const float (&v)[HB][16], f32x16 (&acc)[HB],
+                                           bool skip = false) {
+    if (skip) {   // ablation: keep the operands live, issue no MFMA
+#pragma unroll
+        for (int b = 0; b < HB; ++b) acc[b][0] += v[b][0];
+        return;
+    }
 #pragma unroll
     for (int bo = 0; bo < HB; ++bo)
 #pragma unroll
@@ -86,6 +100,138 @@ __device__ __forceinline__ int chunk_begin(const PvsGraph& g, int k, int n_chunk
     if (k >= n_chunks) return g.n_edges;
     const long long t = (long long)k * g.n_edges / n_chunks;
     return g.rowptr[g.row[t]];   // start of the row that contains edge t: chunks are row-aligned
+}
+
+// Indices of one 32-edge tile (lane = edge slot j, both halves hold the same values).
+struct TileIdx {
+    int e, ee, i, jn, ty, prev_row;
+    bool valid;
+};
+
+__device__ __forceinline__ TileIdx load_tile_idx(const PvsGraph& g, int n_attr, int e0, int e_begin,
+                                                 int e_end, int j) {
+    TileIdx t;
+    t.e = e0 + j;
+    t.valid = t.e < e_end;
+    t.ee = t.valid ? t.e : e_end - 1;
+    t.i = g.row[t.ee];
+    t.jn = g.col[t.ee];
+    if (n_attr & 0x100) { t.i &= 7; t.jn &= 7; }   // ablation: every gather hits 8 hot rows
+    t.ty = (n_attr & 0xff) ? (int)g.etype[t.ee] : 0;
+    t.prev_row = (t.ee == e_begin) ? -1 : g.row[t.ee - 1];
+    return t;
+}
+
+// Gathered node data of one tile in X layout: P_i and Q_j rows, coordinate difference.
+template <int HB>
+struct TileGather {
+    float P[HB][16], Q[HB][16];
+    float d0, d1, d2;
+};
+
+template <int HB>
+__device__ __forceinline__ void gather_tile(const float* __restrict__ PQ, const float* __restrict__ x,
+                                            const TileIdx& t, int hh, TileGather<HB>& G) {
+    constexpr int H = 32 * HB;
+    const float* Pp = PQ + (size_t)t.i * 2 * H + 4 * hh;
+    const float* Qp = PQ + (size_t)t.jn * 2 * H + H + 4 * hh;
+#pragma unroll
+    for (int b = 0; b < HB; ++b)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 p = *reinterpret_cast<const float4*>(Pp + 32 * b + 8 * gq);
+            const float4 q = *reinterpret_cast<const float4*>(Qp + 32 * b + 8 * gq);
+            G.P[b][4 * gq] = p.x; G.P[b][4 * gq + 1] = p.y; G.P[b][4 * gq + 2] = p.z; G.P[b][4 * gq + 3] = p.w;
+            G.Q[b][4 * gq] = q.x; G.Q[b][4 * gq + 1] = q.y; G.Q[b][4 * gq + 2] = q.z; G.Q[b][4 * gq + 3] = q.w;
+        }
+    G.d0 = x[3 * t.i] - x[3 * t.jn];
+    G.d1 = x[3 * t.i + 1] - x[3 * t.jn + 1];
+    G.d2 = x[3 * t.i + 2] - x[3 * t.jn + 2];
+}
+
+// z1 = P_i + Q_j + w_rho * rho + W_a[type]  (X layout)
+template <int HB>
+__device__ __forceinline__ void assemble_z1(const TileGather<HB>& G, const float* __restrict__ attrt,
+                                            const float* __restrict__ wrhot, int ty, int hh, float rho,
+                                            float (&z1)[HB][16]) {
+    constexpr int H = 32 * HB;
+    const float* At = attrt + ty * H + 4 * hh;
+    const float* Rt = wrhot + 4 * hh;
+#pragma unroll
+    for (int b = 0; b < HB; ++b)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 a = *reinterpret_cast<const float4*>(At + 32 * b + 8 * gq);
+            const float4 r = *reinterpret_cast<const float4*>(Rt + 32 * b + 8 * gq);
+            z1[b][4 * gq] = G.P[b][4 * gq] + G.Q[b][4 * gq] + fmaf(r.x, rho, a.x);
+            z1[b][4 * gq + 1] = G.P[b][4 * gq + 1] + G.Q[b][4 * gq + 1] + fmaf(r.y, rho, a.y);
+            z1[b][4 * gq + 2] = G.P[b][4 * gq + 2] + G.Q[b][4 * gq + 2] + fmaf(r.z, rho, a.z);
+            z1[b][4 * gq + 3] = G.P[b][4 * gq + 3] + G.Q[b][4 * gq + 3] + fmaf(r.w, rho, a.w);
+        }
+}
+
+
+// ---- row (segment) reduction of one edge-major LDS tile -------------------------------------------
+// T[32][TS] holds one H-vector per edge of the tile, tx[32][4] one float4 per edge, rowbuf[32] the
+// row id of each edge. Lane = (row slot rsub, 16-byte quad): each lane reads whole float4s, so the
+// same LDS reads feed both the per-row sums and (optionally) fully coalesced 128-byte row stores to
+// HBM. bmask bit e = "edge e starts a new row" (wave-uniform), so segments are handled by scalar
+// control flow: the first segment continues the carried row, every later one starts at a set bit.
+// acc/accx carry the open row's partial sums (per lane: its quad, summed over its row slots);
+// flush(row) reduces them over the row slots, stores and clears.
+template <int HB, class Flush, class RowStore>
+__device__ __forceinline__ void reduce_rows_tile(const float* __restrict__ T, const float* __restrict__ tx,
+                                                 const int* __restrict__ rowbuf, unsigned bmask, int lane,
+                                                 float4& acc, float4& accx, int& cur_row, Flush&& flush,
+                                                 RowStore&& store_row) {
+    constexpr int H = 32 * HB, TS = H + 4;
+    constexpr int QPR = H / 4, RPI = 64 / QPR, NK = kTile / RPI;
+    const int quad = lane % QPR, rsub = lane / QPR;
+    float4 v[NK], dx[NK];
+    int seg[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int rl = k * RPI + rsub;
+        v[k] = *reinterpret_cast<const float4*>(T + rl * TS + 4 * quad);
+        dx[k] = *reinterpret_cast<const float4*>(tx + rl * 4);
+        store_row(rl, quad, v[k]);
+        const unsigned upto = rl == 31 ? 0xffffffffu : ((2u << rl) - 1u);
+        seg[k] = __popc(bmask & upto);
+    }
+    auto add4 = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    if (bmask == 0u) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { add4(acc, v[k]); add4(accx, dx[k]); }
+        return;
+    }
+    unsigned bm = bmask;
+    for (int s = 0;; ++s) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const float m = seg[k] == s ? 1.f : 0.f;
+            acc.x = fmaf(m, v[k].x, acc.x); acc.y = fmaf(m, v[k].y, acc.y);
+            acc.z = fmaf(m, v[k].z, acc.z); acc.w = fmaf(m, v[k].w, acc.w);
+            accx.x = fmaf(m, dx[k].x, accx.x); accx.y = fmaf(m, dx[k].y, accx.y);
+            accx.z = fmaf(m, dx[k].z, accx.z);
+        }
+        if (bm == 0u) break;            // the last segment stays open (carried to the next tile)
+        flush(cur_row);
+        const int pos = __builtin_ctz(bm);
+        bm &= bm - 1u;
+        cur_row = __builtin_amdgcn_readfirstlane(rowbuf[pos]);
+    }
+}
+
+// sum a float4 over the row slots (lanes that share a quad)
+template <int HB>
+__device__ __forceinline__ float4 sum_row_slots(float4 a) {
+    constexpr int QPR = 8 * HB;
+#pragma unroll
+    for (int o = QPR; o < 64; o <<= 1) {
+        a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64);
+        a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+    }
+    return a;
 }
 
 template <int HB>
@@ -139,61 +285,52 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
         const int e_begin = chunk_begin(g, chunk, n_chunks);
         const int e_end = chunk_begin(g, chunk + 1, n_chunks);
         int cur_row = -1;
-        float acc[HB], accx = 0.f;   // Y-phase: lane = channel 32b + j (and coordinate j < 3), parity hh
-#pragma unroll
-        for (int b = 0; b < HB; ++b) acc[b] = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accx = acc;   // open row: lane = (row slot, quad)
+        constexpr int QPR = H / 4;
+        const int quad = lane % QPR, rsub = lane / QPR;
 
         auto flush = [&](int row_id) {
-            if (row_id < 0) return;
-#pragma unroll
-            for (int b = 0; b < HB; ++b) {
-                const float tot = acc[b] + __shfl_xor(acc[b], 32, 64);
-                if (hh == 0) io.Magg[(size_t)row_id * H + 32 * b + j] = tot;
-                acc[b] = 0.f;
+            if (row_id >= 0) {
+                const float4 tot = sum_row_slots<HB>(acc);
+                if (rsub == 0) *reinterpret_cast<float4*>(io.Magg + (size_t)row_id * H + 4 * quad) = tot;
+                if (upd) {
+                    const float4 tx4 = sum_row_slots<HB>(accx);
+                    if (lane == 0) {
+                        const float inv = g.inv_deg[row_id];
+                        io.x_out[3 * row_id] = io.x[3 * row_id] + tx4.x * inv;
+                        io.x_out[3 * row_id + 1] = io.x[3 * row_id + 1] + tx4.y * inv;
+                        io.x_out[3 * row_id + 2] = io.x[3 * row_id + 2] + tx4.z * inv;
+                    }
+                }
             }
-            if (upd) {
-                const float totx = accx + __shfl_xor(accx, 32, 64);
-                if (hh == 0 && j < 3)
-                    io.x_out[3 * row_id + j] = io.x[3 * row_id + j] + totx * g.inv_deg[row_id];
-                accx = 0.f;
-            }
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            accx = acc;
         };
 
+        // software pipeline: the gathers of tile t+1 are issued while tile t is being reduced
+        TileIdx I = load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_begin, e_begin, e_end, j);
+        TileGather<HB> G;
+        if (e_begin < e_end) gather_tile<HB>(io.PQ, io.x, I, hh, G);
         for (int e0 = e_begin; e0 < e_end; e0 += kTile) {
-            const int e = e0 + j;
-            const bool valid = e < e_end;
-            const int ee = valid ? e : e_end - 1;
-            const int i = g.row[ee], jn = g.col[ee];
-            const int ty = w.n_attr ? (int)g.etype[ee] : 0;
-            const int prev_row = (ee == e_begin) ? -1 : g.row[ee - 1];
-            const unsigned long long ball = __ballot(valid && hh == 0 && i != prev_row);
+            const int e_next = (e0 + kTile < e_end) ? e0 + kTile : e0;
+            const TileIdx In = load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_next, e_begin, e_end, j);
+            const int e = I.e, ee = I.ee, i = I.i;
+            const bool valid = I.valid;
+            const unsigned long long ball = __ballot(valid && hh == 0 && i != I.prev_row);
             const unsigned bmask = (unsigned)ball;
-            const float d0 = io.x[3 * i] - io.x[3 * jn], d1 = io.x[3 * i + 1] - io.x[3 * jn + 1];
-            const float d2 = io.x[3 * i + 2] - io.x[3 * jn + 2];
+#if !PVS_PREFETCH
+            gather_tile<HB>(io.PQ, io.x, I, hh, G);
+#endif
+            const float d0 = G.d0, d1 = G.d1, d2 = G.d2;
             const float rho = d0 * d0 + d1 * d1 + d2 * d2;
 
             // ---- first layer: z1 = P_i + Q_j + w_rho*rho + W_a[type]; a1 = SiLU(z1) ----
             float a1[HB][16];
-            {
-                const float* Pp = io.PQ + (size_t)i * 2 * H + 4 * hh;
-                const float* Qp = io.PQ + (size_t)jn * 2 * H + H + 4 * hh;
-                const float* At = attrt + ty * H + 4 * hh;
-                const float* Rt = wrhot + 4 * hh;
+            assemble_z1<HB>(G, attrt, wrhot, I.ty, hh, rho, a1);
 #pragma unroll
-                for (int b = 0; b < HB; ++b)
+            for (int b = 0; b < HB; ++b)
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const int off = 32 * b + 8 * gq;
-                        const float4 p = *reinterpret_cast<const float4*>(Pp + off);
-                        const float4 q = *reinterpret_cast<const float4*>(Qp + off);
-                        const float4 a = *reinterpret_cast<const float4*>(At + off);
-                        const float4 r = *reinterpret_cast<const float4*>(Rt + off);
-                        a1[b][4 * gq] = pvs_silu(p.x + q.x + fmaf(r.x, rho, a.x));
-                        a1[b][4 * gq + 1] = pvs_silu(p.y + q.y + fmaf(r.y, rho, a.y));
-                        a1[b][4 * gq + 2] = pvs_silu(p.z + q.z + fmaf(r.z, rho, a.z));
-                        a1[b][4 * gq + 3] = pvs_silu(p.w + q.w + fmaf(r.w, rho, a.w));
-                    }
-            }
+                for (int r = 0; r < 16; ++r) a1[b][r] = pvs_silu(a1[b][r]);
             // ---- second layer on the matrix cores: m = SiLU(W2 a1 + b2) ----
             float m[HB][16];
             {
@@ -204,7 +341,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[b][r] = bias[b][r];
-                mfma_chain<HB>(W2s, lane, a1, acc2);
+                mfma_chain<HB>(W2s, lane, a1, acc2, flags & kAblNoMfma);
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
@@ -245,7 +382,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) accc[b][r] = bias[b][r];
-                mfma_chain<HB>(Wc1s, lane, m, accc);
+                mfma_chain<HB>(Wc1s, lane, m, accc, flags & kAblNoMfma);
                 float q[HB][16];
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
@@ -275,28 +412,14 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                 *reinterpret_cast<float4*>(tx + j * 4) = make_float4(d0 * sv, d1 * sv, d2 * sv, 0.f);
                 rowbuf[j] = i;
             }
+#if PVS_PREFETCH
+            gather_tile<HB>(io.PQ, io.x, In, hh, G);   // next tile's rows fly during the reduction
+#endif
+            I = In;
             pvs_wave_lds_sync();
-            if (bmask == 0u) {   // the whole tile continues the current row
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int el = 2 * k + hh;
-#pragma unroll
-                    for (int b = 0; b < HB; ++b) acc[b] += tile[el * TS + 32 * b + j];
-                    if (upd) accx += tx[el * 4 + (j & 3)];
-                }
-            } else {
-                for (int el = 0; el < kTile; ++el) {
-                    if ((bmask >> el) & 1u) {
-                        flush(cur_row);
-                        cur_row = __builtin_amdgcn_readfirstlane(rowbuf[el]);
-                    }
-                    if ((el & 1) == hh) {
-#pragma unroll
-                        for (int b = 0; b < HB; ++b) acc[b] += tile[el * TS + 32 * b + j];
-                        if (upd) accx += tx[el * 4 + (j & 3)];
-                    }
-                }
-            }
+            if (!(flags & kAblNoReduce))
+                reduce_rows_tile<HB>(tile, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
+                                     [](int, int, const float4&) {});
             pvs_wave_lds_sync();
         }
         flush(cur_row);
@@ -349,8 +472,8 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     float* wrhot = wat + H;
     float* attrt = wrhot + H;                            // [PVS_MAX_EDGE_ATTR][H]
     float* wave_base = attrt + PVS_MAX_EDGE_ATTR * H;
-    // per wave: T0 (a1), T1 (m, then g_z1), T2 (g_zc, then g_z2), tx[32][4], sc[32][8], rowbuf[32]
-    constexpr int kWaveFloats = 3 * kTile * TS + kTile * 4 + kTile * 8 + kTile;
+    // per wave: T0 (a1), T1 (m, then g_z1), T2 (g_zc, then g_z2), tx[32][4] (gd), gl[32], rowbuf[32]
+    constexpr int kWaveFloats = 3 * kTile * TS + kTile * 4 + 2 * kTile;
 
     const bool upd = (flags & PVS_UPDATE_COORDS) && io.gxagg != nullptr;
     constexpr bool eatt = EATT;
@@ -379,8 +502,8 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     float* T1 = T0 + kTile * TS;
     float* T2 = T1 + kTile * TS;
     float* tx = T2 + kTile * TS;
-    float* sc = tx + kTile * 4;      // per edge: [0]=rho, [1]=g_logit, [2..2+A)=one-hot(type)
-    int* rowbuf = reinterpret_cast<int*>(sc + kTile * 8);
+    float* glb = tx + kTile * 4;
+    int* rowbuf = reinterpret_cast<int*>(glb + kTile);
     const float bac = eatt ? w.ba[0] : 0.f;
     float gate_raw = 0.f, gate = 1.f;
     if (eres && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
@@ -402,13 +525,9 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
 #pragma unroll
         for (int r = 0; r < 16; ++r) g_wc2x[b][r] = 0.f;
     // channel-on-lane accumulators (lane = channel 32b + j, parity hh)
-    float g_b2[HB], g_bc1[HB], g_wa[HB], g_wrho[HB], g_wattr[HB][6];
+    float g_b2[HB], g_bc1[HB], g_wa[HB];
 #pragma unroll
-    for (int b = 0; b < HB; ++b) {
-        g_b2[b] = g_bc1[b] = g_wa[b] = g_wrho[b] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) g_wattr[b][t] = 0.f;
-    }
+    for (int b = 0; b < HB; ++b) g_b2[b] = g_bc1[b] = g_wa[b] = 0.f;
     float g_ba = 0.f, g_gate = 0.f;
 
     const int total_waves = gridDim.x * kWaves;
@@ -416,59 +535,49 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
         const int e_begin = chunk_begin(g, chunk, n_chunks);
         const int e_end = chunk_begin(g, chunk + 1, n_chunks);
         int cur_row = -1;
-        float gP[HB], gxr = 0.f;
-#pragma unroll
-        for (int b = 0; b < HB; ++b) gP[b] = 0.f;
-
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accx = acc;   // open row: lane = (row slot, quad)
+        constexpr int QPR = H / 4;
+        const int quad = lane % QPR, rsub = lane / QPR;
         auto flush = [&](int row_id) {
-            if (row_id < 0) return;
-#pragma unroll
-            for (int b = 0; b < HB; ++b) {
-                const float tot = gP[b] + __shfl_xor(gP[b], 32, 64);
-                if (hh == 0) io.gPQ[(size_t)row_id * 2 * H + 32 * b + j] = tot;
-                gP[b] = 0.f;
+            if (row_id >= 0) {
+                const float4 tot = sum_row_slots<HB>(acc);
+                if (rsub == 0) *reinterpret_cast<float4*>(io.gPQ + (size_t)row_id * 2 * H + 4 * quad) = tot;
+                const float4 tx4 = sum_row_slots<HB>(accx);
+                if (lane == 0) {
+                    io.gx_row[3 * row_id] = tx4.x;
+                    io.gx_row[3 * row_id + 1] = tx4.y;
+                    io.gx_row[3 * row_id + 2] = tx4.z;
+                }
             }
-            const float totx = gxr + __shfl_xor(gxr, 32, 64);
-            if (hh == 0 && j < 3) io.gx_row[3 * row_id + j] = totx;
-            gxr = 0.f;
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            accx = acc;
         };
-
+        // software pipeline: tile t+1's indices are loaded at the top of tile t, its node rows
+        // are gathered before tile t's weight-gradient / reduction phase
+        TileIdx I = load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_begin, e_begin, e_end, j);
+        TileGather<HB> G;
+        if (e_begin < e_end) gather_tile<HB>(io.PQ, io.x, I, hh, G);
         for (int e0 = e_begin; e0 < e_end; e0 += kTile) {
-            const int e = e0 + j;
-            const bool valid = e < e_end;
+            const int e_next = (e0 + kTile < e_end) ? e0 + kTile : e0;
+            const TileIdx In = load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_next, e_begin, e_end, j);
+            const int e = I.e, ee = I.ee, i = I.i, ty = I.ty;
+            const bool valid = I.valid;
             const float vm = valid ? 1.f : 0.f;
-            const int ee = valid ? e : e_end - 1;
-            const int i = g.row[ee], jn = g.col[ee];
-            const int ty = w.n_attr ? (int)g.etype[ee] : 0;
-            const int prev_row = (ee == e_begin) ? -1 : g.row[ee - 1];
-            const unsigned bmask = (unsigned)__ballot(valid && hh == 0 && i != prev_row);
-            const float d0 = io.x[3 * i] - io.x[3 * jn], d1 = io.x[3 * i + 1] - io.x[3 * jn + 1];
-            const float d2 = io.x[3 * i + 2] - io.x[3 * jn + 2];
+#if !PVS_PREFETCH
+            gather_tile<HB>(io.PQ, io.x, I, hh, G);
+#endif
+            const unsigned bmask = (unsigned)__ballot(valid && hh == 0 && i != I.prev_row);
+            const float d0 = G.d0, d1 = G.d1, d2 = G.d2;
             const float rho = d0 * d0 + d1 * d1 + d2 * d2;
 
             // ---- recompute: z1, a1 ----
             {
-                const float* Pp = io.PQ + (size_t)i * 2 * H + 4 * hh;
-                const float* Qp = io.PQ + (size_t)jn * 2 * H + H + 4 * hh;
-                const float* At = attrt + ty * H + 4 * hh;
-                const float* Rt = wrhot + 4 * hh;
                 float a1[HB][16];
+                assemble_z1<HB>(G, attrt, wrhot, ty, hh, rho, a1);
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const int off = 32 * b + 8 * gq;
-                        const float4 p = *reinterpret_cast<const float4*>(Pp + off);
-                        const float4 q = *reinterpret_cast<const float4*>(Qp + off);
-                        const float4 a = *reinterpret_cast<const float4*>(At + off);
-                        const float4 r = *reinterpret_cast<const float4*>(Rt + off);
-                        const float zz[4] = {p.x + q.x + fmaf(r.x, rho, a.x), p.y + q.y + fmaf(r.y, rho, a.y),
-                                             p.z + q.z + fmaf(r.z, rho, a.z), p.w + q.w + fmaf(r.w, rho, a.w)};
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            a1[b][4 * gq + q4] = pvs_silu(zz[q4]);
-                        }
-                    }
+                    for (int r = 0; r < 16; ++r) a1[b][r] = pvs_silu(a1[b][r]);
                 // a1 edge-major in T0 for the W2 weight gradient (zero rows for padded slots)
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
@@ -484,7 +593,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[b][r] = bias[b][r];
-                mfma_chain<HB>(W2s, lane, a1, acc2);
+                mfma_chain<HB>(W2s, lane, a1, acc2, flags & kAblNoMfma);
                 float dz2[HB][16], m[HB][16];     // SiLU'(z2) and the message
                 float m_new[ERES ? HB : 1][16], mp[ERES ? HB : 1][16];
 #pragma unroll
@@ -563,7 +672,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                     for (int b = 0; b < HB; ++b)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) accc[b][r] = bias2[b][r];
-                    mfma_chain<HB>(Wc1s, lane, m, accc);
+                    mfma_chain<HB>(Wc1s, lane, m, accc, flags & kAblNoMfma);
                     float q[HB][16], dq[HB][16];
 #pragma unroll
                     for (int b = 0; b < HB; ++b)
@@ -596,19 +705,9 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                             *reinterpret_cast<float4*>(T2 + j * TS + 32 * b + 8 * gq + 4 * hh) =
                                 make_float4(g_zc[b][4 * gq], g_zc[b][4 * gq + 1], g_zc[b][4 * gq + 2],
                                             g_zc[b][4 * gq + 3]);
-                    mfma_chain<HB>(Wc1ts, lane, g_zc, gm);     // g_m += Wc1^T g_zc
+                    mfma_chain<HB>(Wc1ts, lane, g_zc, gm, flags & kAblNoMfma);     // g_m += Wc1^T g_zc
                 }
-                if (hh == 0) {
-                    float4 s0 = make_float4(rho, g_l, 0.f, 0.f), s1v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    float oh[6];
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) oh[t] = (valid && w.n_attr && ty == t) ? 1.f : 0.f;
-                    s0.z = oh[0]; s0.w = oh[1];
-                    s1v = make_float4(oh[2], oh[3], oh[4], oh[5]);
-                    *reinterpret_cast<float4*>(sc + j * 8) = s0;
-                    *reinterpret_cast<float4*>(sc + j * 8 + 4) = s1v;
-                    rowbuf[j] = i;
-                }
+                if (hh == 0) { glb[j] = g_l; rowbuf[j] = i; }
                 pvs_wave_lds_sync();
                 // ---- Wc1 weight gradient + g_bc1 + g_wa from the edge-major tiles ----
                 if (upd || eatt) {
@@ -621,7 +720,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                             av[b] = upd ? T2[el * TS + 32 * b + j] : 0.f;
                             bv[b] = T1[el * TS + 32 * b + j];
                         }
-                        const float gl_e = sc[el * 8 + 1];
+                        const float gl_e = glb[el];
 #pragma unroll
                         for (int b = 0; b < HB; ++b) {
                             g_bc1[b] += av[b];
@@ -672,42 +771,36 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                             make_float4(g_z2[b][4 * gq], g_z2[b][4 * gq + 1], g_z2[b][4 * gq + 2],
                                         g_z2[b][4 * gq + 3]);
                 // ---- g_a1 = W2^T g_z2 ; g_z1 = g_a1 * SiLU'(z1) ----
+                // SiLU'(z1): this tile's rows are re-gathered (L2-hot) under the W2^T product
+                // instead of holding z1 in 16 registers across the whole tile
+                gather_tile<HB>(io.PQ, io.x, I, hh, G);
                 f32x16 ga1[HB];
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ga1[b][r] = 0.f;
-                mfma_chain<HB>(W2ts, lane, g_z2, ga1);
-                // SiLU'(z1): z1 is re-gathered here (L2-hot) instead of living in 16 registers
-                // across the whole tile
+                mfma_chain<HB>(W2ts, lane, g_z2, ga1, flags & kAblNoMfma);
                 float g_z1[HB][16];
+                assemble_z1<HB>(G, attrt, wrhot, ty, hh, rho, g_z1);
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const int off = 32 * b + 8 * gq;
-                        const float4 p = *reinterpret_cast<const float4*>(Pp + off);
-                        const float4 q = *reinterpret_cast<const float4*>(Qp + off);
-                        const float4 a = *reinterpret_cast<const float4*>(At + off);
-                        const float4 r = *reinterpret_cast<const float4*>(Rt + off);
-                        const float zz[4] = {p.x + q.x + fmaf(r.x, rho, a.x), p.y + q.y + fmaf(r.y, rho, a.y),
-                                             p.z + q.z + fmaf(r.z, rho, a.z), p.w + q.w + fmaf(r.w, rho, a.w)};
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4)
-                            g_z1[b][4 * gq + q4] =
-                                ga1[b][4 * gq + q4] * pvs_silu_grad(zz[q4], pvs_sigmoid(zz[q4]));
-                    }
-                if (valid) store_x<HB>(io.gz1 + (size_t)e * H, hh, g_z1);
+                    for (int r = 0; r < 16; ++r)
+                        g_z1[b][r] = ga1[b][r] * pvs_silu_grad(g_z1[b][r], pvs_sigmoid(g_z1[b][r]));
+#if PVS_PREFETCH
+                gather_tile<HB>(io.PQ, io.x, In, hh, G);   // next tile, lands during the reductions
+#endif
                 const float g_rho = dot_tab<HB>(wrhot, hh, g_z1);
                 const float k1 = s_coord * nrm * vm;
                 const float gd0 = fmaf(k1, gT0, 2.f * d0 * g_rho);
                 const float gd1 = fmaf(k1, gT1, 2.f * d1 * g_rho);
                 const float gd2 = fmaf(k1, gT2, 2.f * d2 * g_rho);
+                // per edge: grad wrt (x_row - x_col) and rho, 16 B, for the node gather kernel
                 if (hh == 0) {
                     *reinterpret_cast<float4*>(tx + j * 4) = make_float4(gd0, gd1, gd2, 0.f);
-                    if (valid) {
-                        io.gd[(size_t)e * 3] = gd0; io.gd[(size_t)e * 3 + 1] = gd1; io.gd[(size_t)e * 3 + 2] = gd2;
-                    }
+                    if (valid)
+                        *reinterpret_cast<float4*>(io.gd + (size_t)e * 4) =
+                            make_float4(gd0, gd1, gd2, pvs_pack_rho_type(rho, ty));
                 }
                 pvs_wave_lds_sync();      // T2 = g_z2 visible; T1 (m) no longer needed
                 // ---- W2 weight gradient + g_b2 ----
@@ -727,7 +820,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                         for (int bi = 0; bi < HB; ++bi)
                             gW2[bo][bi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bo], bv[bi], gW2[bo][bi], 0, 0, 0);
                 }
-                // ---- g_z1 edge-major in T1: row sums (g_P), g_wrho, g_wattr, row-side g_x ----
+                // ---- g_z1 edge-major in T1, then whole 128-B rows to HBM (8 lanes per row) ----
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
@@ -736,26 +829,14 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                             make_float4(g_z1[b][4 * gq], g_z1[b][4 * gq + 1], g_z1[b][4 * gq + 2],
                                         g_z1[b][4 * gq + 3]);
                 pvs_wave_lds_sync();
-                for (int el = 0; el < kTile; ++el) {
-                    if (bmask && ((bmask >> el) & 1u)) {
-                        flush(cur_row);
-                        cur_row = __builtin_amdgcn_readfirstlane(rowbuf[el]);
-                    }
-                    if ((el & 1) == hh) {
-                        const float4 s0 = *reinterpret_cast<const float4*>(sc + el * 8);
-                        const float4 s1v = *reinterpret_cast<const float4*>(sc + el * 8 + 4);
-                        const float ohv[6] = {s0.z, s0.w, s1v.x, s1v.y, s1v.z, s1v.w};
-#pragma unroll
-                        for (int b = 0; b < HB; ++b) {
-                            const float v = T1[el * TS + 32 * b + j];
-                            gP[b] += v;
-                            g_wrho[b] = fmaf(v, s0.x, g_wrho[b]);
-#pragma unroll
-                            for (int t = 0; t < 6; ++t) g_wattr[b][t] = fmaf(v, ohv[t], g_wattr[b][t]);
-                        }
-                        gxr += tx[el * 4 + (j & 3)];
-                    }
-                }
+                // whole 128-B rows of g_z1 to HBM + the row-side sums g_P / g_x from the same reads
+                if (!(flags & kAblNoReduce))
+                    reduce_rows_tile<HB>(T1, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
+                                         [&](int rl, int q, const float4& v) {
+                                             if (e0 + rl < e_end)
+                                                 *reinterpret_cast<float4*>(io.gz1 + (size_t)(e0 + rl) * H + 4 * q) = v;
+                                         });
+                I = In;
                 pvs_wave_lds_sync();
             }
         }
@@ -788,9 +869,6 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
         g_b2[b] += __shfl_xor(g_b2[b], 32, 64);
         g_bc1[b] += __shfl_xor(g_bc1[b], 32, 64);
         g_wa[b] += __shfl_xor(g_wa[b], 32, 64);
-        g_wrho[b] += __shfl_xor(g_wrho[b], 32, 64);
-#pragma unroll
-        for (int t = 0; t < 6; ++t) g_wattr[b][t] += __shfl_xor(g_wattr[b][t], 32, 64);
     }
     for (int turn = 0; turn < kWaves; ++turn) {
         if (wv == turn) {
@@ -811,9 +889,6 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                     slab[L.b2 + c] += g_b2[b];
                     slab[L.bc1 + c] += g_bc1[b];
                     slab[L.wa + c] += g_wa[b];
-                    slab[L.wrho + c] += g_wrho[b];
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) slab[L.wattr + t * H + c] += g_wattr[b][t];
                 }
             }
             if (j == 0) {
@@ -888,7 +963,7 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
 
 int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,
                              int att_act, const PvsEdgeBwdIO& io, int* n_slabs) {
-    PVS_REQUIRE(w.n_attr <= 6, "MFMA edge backward supports up to 6 edge classes (got %d)", w.n_attr);
+    PVS_REQUIRE(w.n_attr <= 3, "MFMA edge backward supports up to 3 edge classes (got %d)", w.n_attr);
     PVS_REQUIRE(H == 32, "MFMA edge backward is built for H = 32 (got %d)", H);
     // rows without edges are never flushed
     PVS_CHECK_HIP(hipMemsetAsync(io.gPQ, 0, sizeof(float) * 2 * (size_t)g.n_nodes * H, s));
@@ -905,7 +980,7 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     PvsProfScope prof(s, PVS_PROF_EDGE_BWD);
     const PvsSlabLayout L = pvs_slab_layout(H);
     size_t words = (size_t)4 * H * H + (5 + PVS_MAX_EDGE_ATTR) * H +
-                   (size_t)kWaves * (3 * kTile * (H + 4) + kTile * 4 + kTile * 8 + kTile);
+                   (size_t)kWaves * (3 * kTile * (H + 4) + kTile * 4 + 2 * kTile);
     if (words < (size_t)L.total) words = L.total;
     const size_t lds = words * sizeof(float);
     const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
@@ -925,7 +1000,7 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
 }
 
 int pvs_edge_bwd_mfma_supported(int H, uint32_t flags, int n_attr) {
-    if (H != 32 || n_attr > 6) return 0;
+    if (H != 32 || n_attr > 3) return 0;
     if ((flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT)) return 0;
     return 1;
 }

@@ -362,11 +362,9 @@ k_edge_bwd_v0(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO 
             const float gd0 = fmaf(k1, gT0, 2.f * d0 * g_rho);
             const float gd1 = fmaf(k1, gT1, 2.f * d1 * g_rho);
             const float gd2 = fmaf(k1, gT2, 2.f * d2 * g_rho);
-            if (valid && c == 0) {
-                io.gd[(size_t)e * 3] = gd0;
-                io.gd[(size_t)e * 3 + 1] = gd1;
-                io.gd[(size_t)e * 3 + 2] = gd2;
-            }
+            if (valid && c == 0)
+                *reinterpret_cast<float4*>(io.gd + (size_t)e * 4) =
+                    make_float4(gd0, gd1, gd2, pvs_pack_rho_type(rho, t));
             gx0 += gd0; gx1 += gd1; gx2 += gd2;
         }
 #pragma unroll
@@ -420,24 +418,34 @@ k_edge_bwd_v0(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO 
     for (int i = threadIdx.x; i < L.total; i += kThreads) dst[i] = slab[i];
 }
 
-// gPQ[j, H + c] = sum_{edges with col j} gz1[e, c];  g_x[n] = g_x_out[n] + gx_row[n] - sum gd[e]
-// Lane = (edge slot, 16-byte quad of the row): one wave-instruction fetches 64/(H/4) whole rows,
-// two batches of independent index + row loads are in flight per iteration (latency-bound gather).
-template <int H>
+// Column-side gather: per node n,  g_Q[n] = sum_{e: col=n} gz1[e],  gx_col = sum gd[e]  over the CSC
+// list;  g_x[n] = g_x_out[n] + gx_row[n] - gx_col.  With WSUMS it also accumulates, over the same
+// rows (every edge is in exactly one CSC list), the per-edge-scalar weight gradients
+// g_wrho = sum gz1[e]*rho_e (rho in gd4[e].w) and g_wattr[t] = sum_{type_e=t} gz1[e] into per-block
+// slabs [4H] - the MFMA edge backward leaves those to this memory-bound kernel, whose VALU is idle.
+// Lane = (edge slot, 16-byte quad): one wave-instruction fetches 64/(H/4) whole rows; UN independent
+// batches in flight. Fixed order everywhere: bitwise reproducible.
+template <int H, bool WSUMS>
 __global__ void __launch_bounds__(kThreads)
-k_col_gather(PvsGraph g, const float* __restrict__ gz1, const float* __restrict__ gd,
-             const float* __restrict__ gx_row, const float* __restrict__ g_x_out,
-             float* __restrict__ gPQ, float* __restrict__ g_x) {
-    constexpr int QPR = H / 4;          // float4 quads per row
-    constexpr int EPW = 64 / QPR;       // rows per wave-instruction
-    constexpr int UN = 4;               // independent batches in flight
+k_node_gather(PvsGraph g, const float* __restrict__ gz1, const float* __restrict__ gd4,
+              const float* __restrict__ gx_row, const float* __restrict__ g_x_out,
+              float* __restrict__ gPQ, float* __restrict__ g_x, float* __restrict__ slabs) {
+    constexpr int QPR = H / 4;
+    constexpr int EPW = 64 / QPR;
+    constexpr int UN = 4;
+    __shared__ float red[kWaves][4 * H];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int quad = lane % QPR, sub = lane / QPR;
     const int total_waves = gridDim.x * kWaves;
-    for (int j = blockIdx.x * kWaves + wv; j < g.n_nodes; j += total_waves) {
-        const int p0 = g.colptr[j], p1 = g.colptr[j + 1];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        float ax = 0.f;                 // lanes with quad == 0 own coordinate component sub % 3 ... see below
+    float4 wrho = make_float4(0.f, 0.f, 0.f, 0.f), wat0 = wrho, wat1 = wrho, wat2 = wrho;
+    auto add4 = [](float4& a, const float4& v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+    auto fma4 = [](float4& a, const float4& v, float s) {
+        a.x = fmaf(v.x, s, a.x); a.y = fmaf(v.y, s, a.y); a.z = fmaf(v.z, s, a.z); a.w = fmaf(v.w, s, a.w);
+    };
+    for (int n = blockIdx.x * kWaves + wv; n < g.n_nodes; n += total_waves) {
+        float4 accc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float axc = 0.f;     // lanes with quad < 3 own coordinate component `quad`
+        const int p0 = g.colptr[n], p1 = g.colptr[n + 1];
         for (int pb = p0; pb < p1; pb += EPW * UN) {
             int idx[UN];
 #pragma unroll
@@ -445,33 +453,69 @@ k_col_gather(PvsGraph g, const float* __restrict__ gz1, const float* __restrict_
                 const int p = pb + u * EPW + sub;
                 idx[u] = p < p1 ? g.cedge[p] : -1;
             }
-            float4 v[UN];
-            float dv[UN];
+            float4 v[UN], d[UN];
+            int ty[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                v[u] = idx[u] >= 0 ? *reinterpret_cast<const float4*>(gz1 + (size_t)idx[u] * H + 4 * quad)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-                dv[u] = (g_x && quad < 3 && idx[u] >= 0) ? gd[(size_t)idx[u] * 3 + quad] : 0.f;
+                const bool ok = idx[u] >= 0;
+                v[u] = ok ? *reinterpret_cast<const float4*>(gz1 + (size_t)idx[u] * H + 4 * quad)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                d[u] = ok ? *reinterpret_cast<const float4*>(gd4 + (size_t)idx[u] * 4)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                ty[u] = -1;
+                if (WSUMS) {
+                    int tt;
+                    d[u].w = pvs_unpack_rho(d[u].w, &tt);
+                    ty[u] = (ok && g.etype) ? tt : -1;
+                }
             }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
-                ax += dv[u];
+                add4(accc, v[u]);
+                axc += quad == 0 ? d[u].x : (quad == 1 ? d[u].y : (quad == 2 ? d[u].z : 0.f));
+                if (WSUMS) {
+                    fma4(wrho, v[u], d[u].w);
+                    fma4(wat0, v[u], ty[u] == 0 ? 1.f : 0.f);
+                    fma4(wat1, v[u], ty[u] == 1 ? 1.f : 0.f);
+                    fma4(wat2, v[u], ty[u] == 2 ? 1.f : 0.f);
+                }
             }
         }
-        // combine the EPW edge slots (lanes with equal quad)
 #pragma unroll
         for (int o = QPR; o < 64; o <<= 1) {
-            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
-            acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
-            ax += __shfl_xor(ax, o, 64);
+            accc.x += __shfl_xor(accc.x, o, 64); accc.y += __shfl_xor(accc.y, o, 64);
+            accc.z += __shfl_xor(accc.z, o, 64); accc.w += __shfl_xor(accc.w, o, 64);
+            axc += __shfl_xor(axc, o, 64);
         }
         if (sub == 0) {
-            *reinterpret_cast<float4*>(gPQ + (size_t)j * 2 * H + H + 4 * quad) = acc;
+            *reinterpret_cast<float4*>(gPQ + (size_t)n * 2 * H + H + 4 * quad) = accc;
             if (g_x && quad < 3) {
-                const float base = g_x_out ? g_x_out[3 * j + quad] : 0.f;
-                g_x[3 * j + quad] = base + gx_row[3 * j + quad] - ax;
+                const float base = g_x_out ? g_x_out[3 * n + quad] : 0.f;
+                g_x[3 * n + quad] = base + gx_row[3 * n + quad] - axc;
             }
+        }
+    }
+    if (WSUMS) {   // per-block partial of [g_wrho | g_wattr0 | g_wattr1 | g_wattr2], fixed order
+        auto reduce_subs = [&](float4& a) {
+#pragma unroll
+            for (int o = QPR; o < 64; o <<= 1) {
+                a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64);
+                a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+            }
+        };
+        reduce_subs(wrho); reduce_subs(wat0); reduce_subs(wat1); reduce_subs(wat2);
+        if (sub == 0) {
+            *reinterpret_cast<float4*>(&red[wv][0 * H + 4 * quad]) = wrho;
+            *reinterpret_cast<float4*>(&red[wv][1 * H + 4 * quad]) = wat0;
+            *reinterpret_cast<float4*>(&red[wv][2 * H + 4 * quad]) = wat1;
+            *reinterpret_cast<float4*>(&red[wv][3 * H + 4 * quad]) = wat2;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4 * H; i += kThreads) {
+            float t = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < kWaves; ++ww) t += red[ww][i];
+            slabs[(size_t)blockIdx.x * 4 * H + i] = t;
         }
     }
 }
@@ -542,12 +586,22 @@ int pvs_launch_edge_bwd_v0(hipStream_t s, int H, const PvsGraph& g, const PvsEdg
     return 0;
 }
 
-int pvs_launch_col_gather(hipStream_t s, int H, const PvsGraph& g, const float* gz1, const float* gd,
-                          const float* gx_row, const float* g_x_out, float* gPQ, float* g_x) {
-    const int blocks = pvs_edge_v0_blocks(g.n_nodes);
+int pvs_node_gather_blocks(int N) {
+    int b = pvs_edge_v0_blocks(N);
+    return b > 512 ? 512 : b;
+}
+
+int pvs_launch_node_gather(hipStream_t s, int H, const PvsGraph& g, bool wsums, const float* gz1,
+                           const float* gd4, const float* gx_row, const float* g_x_out, float* gPQ,
+                           float* g_x, float* slabs, int* n_slabs) {
+    const int blocks = wsums ? pvs_node_gather_blocks(g.n_nodes) : pvs_edge_v0_blocks(g.n_nodes);
+    *n_slabs = wsums ? blocks : 0;
     PvsProfScope prof(s, PVS_PROF_COL_GATHER);
     PVS_DISPATCH_H(H, {
-        k_col_gather<HH><<<blocks, kThreads, 0, s>>>(g, gz1, gd, gx_row, g_x_out, gPQ, g_x);
+        if (wsums)
+            k_node_gather<HH, true><<<blocks, kThreads, 0, s>>>(g, gz1, gd4, gx_row, g_x_out, gPQ, g_x, slabs);
+        else
+            k_node_gather<HH, false><<<blocks, kThreads, 0, s>>>(g, gz1, gd4, gx_row, g_x_out, gPQ, g_x, slabs);
     });
     PVS_CHECK_LAUNCH();
     return 0;

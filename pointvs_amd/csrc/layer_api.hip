@@ -14,6 +14,12 @@ static bool pvs_use_mfma() {
     return !(v && v[0] == 'g');
 }
 
+// PVS_ABLATE=<hex bits>: timing-only switches of the MFMA edge kernels (tools/ablate.py)
+static uint32_t pvs_ablate_bits() {
+    const char* v = getenv("PVS_ABLATE");
+    return v ? (uint32_t)strtoul(v, nullptr, 16) << 24 : 0u;
+}
+
 namespace {
 
 struct Dims {
@@ -98,7 +104,7 @@ size_t carve_fwd(PvsArena& a, const Dims& m, FwdWs* w) {
 
 struct BwdWs {
     float *PQ, *y1, *u, *o, *g_o, *g_u, *gM, *t1, *tg, *gl, *gxagg, *softD, *gPQ, *gz1, *gd, *gx_row;
-    float *eslabs, *gsum, *dslabs, *S1, *S2, *coefs, *gvec;
+    float *eslabs, *gsum, *dslabs, *S1, *S2, *coefs, *gvec, *nslabs, *nsum;
 };
 
 size_t carve_bwd(PvsArena& a, const Dims& m, BwdWs* w) {
@@ -119,7 +125,7 @@ size_t carve_bwd(PvsArena& a, const Dims& m, BwdWs* w) {
     t.softD = a.take<float>(m.N);
     t.gPQ = a.take<float>(2 * NH);
     t.gz1 = a.take<float>((size_t)(m.E > 0 ? m.E : 1) * m.H);
-    t.gd = a.take<float>(3 * (size_t)(m.E > 0 ? m.E : 1));
+    t.gd = a.take<float>(4 * (size_t)(m.E > 0 ? m.E : 1));
     t.gx_row = a.take<float>(3 * (size_t)m.N);
     t.eslabs = a.take<float>((size_t)512 * L.total);
     t.gsum = a.take<float>(L.total);
@@ -128,6 +134,8 @@ size_t carve_bwd(PvsArena& a, const Dims& m, BwdWs* w) {
     t.S2 = a.take<float>(m.H);
     t.coefs = a.take<float>(3 * (size_t)m.H);
     t.gvec = a.take<float>(m.H);
+    t.nslabs = a.take<float>((size_t)512 * 4 * m.H);
+    t.nsum = a.take<float>(4 * (size_t)m.H);
     if (w) *w = t;
     return a.off;
 }
@@ -235,7 +243,7 @@ extern "C" int pvs_egnn_layer_fwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     io.PQ = w.PQ; io.x = x; io.m_prev = m_prev; io.Magg = Magg; io.x_out = x_out; io.m_out = m_out;
     io.att_out = att_out; io.smax = w.smax; io.ssum = w.ssum;
     if (pvs_use_mfma() && pvs_edge_mfma_supported(H, d->flags))
-        PVS_TRY(pvs_launch_edge_fwd_mfma(s, H, *g, ew, d->flags, d->att_act, io));
+        PVS_TRY(pvs_launch_edge_fwd_mfma(s, H, *g, ew, d->flags | pvs_ablate_bits(), d->att_act, io));
     else
         PVS_TRY(pvs_launch_edge_fwd_v0(s, H, *g, ew, d->flags, d->att_act, io));
     if (!(d->flags & PVS_UPDATE_COORDS))
@@ -340,13 +348,21 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     io.g_m_out = g_m_out; io.gPQ = w.gPQ; io.gz1 = w.gz1; io.gd = w.gd; io.gx_row = w.gx_row;
     io.g_m_prev = eres ? g_m_prev : nullptr; io.slabs = w.eslabs;
     int n_slabs = 0;
-    if (pvs_use_mfma() && pvs_edge_bwd_mfma_supported(H, F, m.A))
-        PVS_TRY(pvs_launch_edge_bwd_mfma(s, H, *g, ew, F, d->att_act, io, &n_slabs));
+    const bool mfma_bwd = pvs_use_mfma() && pvs_edge_bwd_mfma_supported(H, F, m.A);
+    if (mfma_bwd)
+        PVS_TRY(pvs_launch_edge_bwd_mfma(s, H, *g, ew, F | pvs_ablate_bits(), d->att_act, io, &n_slabs));
     else
         PVS_TRY(pvs_launch_edge_bwd_v0(s, H, *g, ew, F, d->att_act, io, &n_slabs));
-    PVS_TRY(pvs_launch_col_gather(s, H, *g, w.gz1, w.gd, w.gx_row, g_x_out, w.gPQ, g_x));
+    int n_nslabs = 0;
+    PVS_TRY(pvs_launch_node_gather(s, H, *g, mfma_bwd, w.gz1, w.gd, w.gx_row, g_x_out, w.gPQ, g_x,
+                                   w.nslabs, &n_nslabs));
     const PvsSlabLayout L = pvs_slab_layout(H);
     PVS_TRY(pvs_launch_reduce_slabs(s, w.gsum, L.total, L.total, w.eslabs, n_slabs, L.total, false));
+    if (mfma_bwd) {   // g_wrho / g_wattr come from the node gather: overwrite those slab regions
+        // slab layout [wrho | wattr0 | wattr1 | wattr2] == gsum[L.wrho .. L.wrho + 4H)
+        PVS_TRY(pvs_launch_reduce_slabs(s, w.gsum + L.wrho, 4 * H, 4 * H, w.nslabs, n_nslabs, 4 * H,
+                                        false));
+    }
 
     // ---- first edge-MLP layer at node level: P = W1a h + b1, Q = W1b h ----
     PVS_TRY(pvs_launch_linear(s, g_h, H, w.gPQ, 2 * H, p->edge_w1, 1, m.ld1, nullptr, nullptr, 0,

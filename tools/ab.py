@@ -1,0 +1,27 @@
+"""A/B of library builds in ONE process tree on ONE device (interleaved rounds).
+Usage: python tools/ab.py name1=path1.so name2=path2.so [--rounds 3]"""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+libs = [a.split('=', 1) for a in sys.argv[1:] if '=' in a]
+rounds = 3
+res = {n: [] for n, _ in libs}
+for r in range(rounds):
+    for name, path in libs:
+        e = dict(os.environ, PVS_EGNN_LIB=str(Path(path).resolve()))
+        out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--steps', '4', '--warmup', '2',
+                              '--no-cpu-baseline'], env=e, capture_output=True, text=True)
+        line = [l for l in out.stdout.splitlines() if l.startswith('{')]
+        if not line:
+            print(name, 'FAILED', out.stderr[-400:])
+            continue
+        d = json.loads(line[0])
+        k = d['roofline']['kernel_ms_per_step']
+        res[name].append((d['ms_per_step'], k['edge_fwd'], k['edge_bwd'], k['col_gather']))
+for name, rows in res.items():
+    for row in rows:
+        print(f'{name:16s} step {row[0]:7.3f}  fwd {row[1]:.3f}  bwd {row[2]:.3f}  col {row[3]:.3f}')
