@@ -69,6 +69,39 @@ __device__ __forceinline__ void mfma_chain(const float* __restrict__ Ws, int lan
             }
 }
 
+// Natural row-major staging W[c*(H+1) + k] (row stride padded by one word): ONE copy serves both
+// Z = W V (lanes vary the row: stride H+1 -> distinct banks) and Z = W^T V (lanes vary the column:
+// consecutive words), halving the LDS the backward needs for its four operand orientations.
+template <int HB>
+__device__ __forceinline__ void stage_weights_nat(float* dst, const float* __restrict__ W) {
+    constexpr int H = 32 * HB;
+    for (int i = threadIdx.x; i < H * H; i += kThreads) dst[(i / H) * (H + 1) + (i % H)] = W[i];
+}
+
+template <int HB, bool TRANSPOSE>
+__device__ __forceinline__ void mfma_chain_nat(const float* __restrict__ Wn, int lane,
+                                               const float (&v)[HB][16], f32x16 (&acc)[HB],
+                                               bool skip = false) {
+    constexpr int H = 32 * HB, LD = H + 1;
+    if (skip) {
+#pragma unroll
+        for (int b = 0; b < HB; ++b) acc[b][0] += v[b][0];
+        return;
+    }
+    const int j = lane & 31, hh = lane >> 5;
+    const float* base = TRANSPOSE ? Wn + (4 * hh) * LD + j : Wn + j * LD + 4 * hh;
+#pragma unroll
+    for (int bo = 0; bo < HB; ++bo)
+#pragma unroll
+        for (int bi = 0; bi < HB; ++bi)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kc = 32 * bi + (t & 3) + 8 * (t >> 2);   // + 4hh folded into base
+                const float a = TRANSPOSE ? base[kc * LD + 32 * bo] : base[(32 * bo) * LD + kc];
+                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v[bi][t], acc[bo], 0, 0, 0);
+            }
+}
+
 // value of a per-channel table at this lane's X-layout channels: out[b][4g+q] = tab[32b+8g+4hh+q]
 template <int HB>
 __device__ __forceinline__ void load_tab(const float* __restrict__ tab, int hh, float (&out)[HB][16]) {
@@ -456,16 +489,14 @@ __device__ __forceinline__ void store_x(float* __restrict__ base, int hh, const 
 // 96 MFMAs per 32x32 block in total. Vector gradients ride on the same LDS tiles with the channel
 // on the lane (one accumulator register each).
 template <int HB, bool ERES, bool EATT>
-__global__ void __launch_bounds__(kThreads, 2)
+__global__ void __launch_bounds__(kThreads, HB == 1 ? 2 : 1)
 k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks) {
     constexpr int H = 32 * HB;
     constexpr int TS = H + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* W2s = smem;               // z2 = W2 a1
-    float* W2ts = W2s + H * H;       // g_a1 = W2^T g_z2
-    float* Wc1s = W2ts + H * H;      // zc = Wc1 m
-    float* Wc1ts = Wc1s + H * H;     // g_m += Wc1^T g_zc
-    float* b2t = Wc1ts + H * H;
+    float* W2n = smem;                    // W2 natural, padded rows: z2 = W2 a1, g_a1 = W2^T g_z2
+    float* Wc1n = W2n + H * (H + 1);      // Wc1 natural: zc = Wc1 m, g_m += Wc1^T g_zc
+    float* b2t = Wc1n + H * (H + 1);
     float* bc1t = b2t + H;
     float* wc2t = bc1t + H;
     float* wat = wc2t + H;
@@ -479,12 +510,8 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     constexpr bool eatt = EATT;
     constexpr bool eres = ERES;
 
-    stage_weights<HB>(W2s, w.w2, false);
-    stage_weights<HB>(W2ts, w.w2, true);
-    if (upd) {
-        stage_weights<HB>(Wc1s, w.wc1, false);
-        stage_weights<HB>(Wc1ts, w.wc1, true);
-    }
+    stage_weights_nat<HB>(W2n, w.w2);
+    if (upd) stage_weights_nat<HB>(Wc1n, w.wc1);
     for (int c = threadIdx.x; c < H; c += kThreads) {
         b2t[c] = w.b2[c];
         bc1t[c] = upd ? w.bc1[c] : 0.f;
@@ -593,7 +620,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[b][r] = bias[b][r];
-                mfma_chain<HB>(W2s, lane, a1, acc2, flags & kAblNoMfma);
+                mfma_chain_nat<HB, false>(W2n, lane, a1, acc2, flags & kAblNoMfma);
                 float dz2[HB][16], m[HB][16];     // SiLU'(z2) and the message
                 float m_new[ERES ? HB : 1][16], mp[ERES ? HB : 1][16];
 #pragma unroll
@@ -672,7 +699,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                     for (int b = 0; b < HB; ++b)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) accc[b][r] = bias2[b][r];
-                    mfma_chain<HB>(Wc1s, lane, m, accc, flags & kAblNoMfma);
+                    mfma_chain_nat<HB, false>(Wc1n, lane, m, accc, flags & kAblNoMfma);
                     float q[HB][16], dq[HB][16];
 #pragma unroll
                     for (int b = 0; b < HB; ++b)
@@ -705,7 +732,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                             *reinterpret_cast<float4*>(T2 + j * TS + 32 * b + 8 * gq + 4 * hh) =
                                 make_float4(g_zc[b][4 * gq], g_zc[b][4 * gq + 1], g_zc[b][4 * gq + 2],
                                             g_zc[b][4 * gq + 3]);
-                    mfma_chain<HB>(Wc1ts, lane, g_zc, gm, flags & kAblNoMfma);     // g_m += Wc1^T g_zc
+                    mfma_chain_nat<HB, true>(Wc1n, lane, g_zc, gm, flags & kAblNoMfma);   // g_m += Wc1^T g_zc
                 }
                 if (hh == 0) { glb[j] = g_l; rowbuf[j] = i; }
                 pvs_wave_lds_sync();
@@ -779,7 +806,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ga1[b][r] = 0.f;
-                mfma_chain<HB>(W2ts, lane, g_z2, ga1, flags & kAblNoMfma);
+                mfma_chain_nat<HB, true>(W2n, lane, g_z2, ga1, flags & kAblNoMfma);
                 float g_z1[HB][16];
                 assemble_z1<HB>(G, attrt, wrhot, ty, hh, rho, g_z1);
 #pragma unroll
@@ -964,14 +991,15 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
 int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,
                              int att_act, const PvsEdgeBwdIO& io, int* n_slabs) {
     PVS_REQUIRE(w.n_attr <= 3, "MFMA edge backward supports up to 3 edge classes (got %d)", w.n_attr);
-    PVS_REQUIRE(H == 32, "MFMA edge backward is built for H = 32 (got %d)", H);
+    PVS_REQUIRE(H == 32 || H == 64, "MFMA edge backward is built for H = 32, 64 (got %d)", H);
     // rows without edges are never flushed
     PVS_CHECK_HIP(hipMemsetAsync(io.gPQ, 0, sizeof(float) * 2 * (size_t)g.n_nodes * H, s));
     PVS_CHECK_HIP(hipMemsetAsync(io.gx_row, 0, sizeof(float) * 3 * (size_t)g.n_nodes, s));
     int blocks, n_chunks;
     pick_grid(g.n_edges, &blocks, &n_chunks);
-    if (blocks > 512) {   // the slab buffer holds 512 partials
-        blocks = 512;
+    const int max_blocks = H == 32 ? 512 : 256;   // resident blocks: 2 per CU (H=32), 1 per CU (H=64)
+    if (blocks > max_blocks) {
+        blocks = max_blocks;
         const long long waves = (long long)blocks * kWaves;
         long long per_wave = ((long long)g.n_edges + waves * 4096 - 1) / (waves * 4096);
         n_chunks = (int)(waves * (per_wave < 1 ? 1 : per_wave));
@@ -979,28 +1007,34 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     *n_slabs = blocks;
     PvsProfScope prof(s, PVS_PROF_EDGE_BWD);
     const PvsSlabLayout L = pvs_slab_layout(H);
-    size_t words = (size_t)4 * H * H + (5 + PVS_MAX_EDGE_ATTR) * H +
+    size_t words = (size_t)2 * H * (H + 1) + (5 + PVS_MAX_EDGE_ATTR) * H +
                    (size_t)kWaves * (3 * kTile * (H + 4) + kTile * 4 + 2 * kTile);
     if (words < (size_t)L.total) words = L.total;
     const size_t lds = words * sizeof(float);
     const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
     const bool eatt = flags & PVS_EDGE_ATTENTION;
-#define PVS_BWD_LAUNCH(ER, EA)                                                                    \
+#define PVS_BWD_LAUNCH(HBV, ER, EA)                                                               \
     do {                                                                                          \
-        if (set_lds(k_edge_bwd_mfma<1, ER, EA>, lds)) return -2;                                  \
-        k_edge_bwd_mfma<1, ER, EA><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks); \
+        if (set_lds(k_edge_bwd_mfma<HBV, ER, EA>, lds)) return -2;                                \
+        k_edge_bwd_mfma<HBV, ER, EA><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks); \
     } while (0)
-    if (eres && eatt) PVS_BWD_LAUNCH(true, true);
-    else if (eres) PVS_BWD_LAUNCH(true, false);
-    else if (eatt) PVS_BWD_LAUNCH(false, true);
-    else PVS_BWD_LAUNCH(false, false);
+#define PVS_BWD_PICK(HBV)                               \
+    do {                                                \
+        if (eres && eatt) PVS_BWD_LAUNCH(HBV, true, true);   \
+        else if (eres) PVS_BWD_LAUNCH(HBV, true, false);     \
+        else if (eatt) PVS_BWD_LAUNCH(HBV, false, true);     \
+        else PVS_BWD_LAUNCH(HBV, false, false);              \
+    } while (0)
+    if (H == 32) PVS_BWD_PICK(1);
+    else PVS_BWD_PICK(2);
+#undef PVS_BWD_PICK
 #undef PVS_BWD_LAUNCH
     PVS_CHECK_LAUNCH();
     return 0;
 }
 
 int pvs_edge_bwd_mfma_supported(int H, uint32_t flags, int n_attr) {
-    if (H != 32 || n_attr > 3) return 0;
+    if ((H != 32 && H != 64) || n_attr > 3) return 0;
     if ((flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT)) return 0;
     return 1;
 }
