@@ -1,4 +1,5 @@
 #include "dense_ops.h"
+#include "mfma_common.h"
 
 namespace {
 
@@ -184,12 +185,79 @@ __global__ void k_mean_pool_bwd(const float* __restrict__ gp, const int32_t* __r
     }
 }
 
+// MFMA linear for 32-aligned shapes: y[n][c] (=|+=) b[c] + sum_k x[n][k] W(c,k) (+ second input).
+// Rows (nodes) sit on the lanes: the X-layout operand of the products is read straight from the
+// row-major input (16-byte pieces), the weights are staged once per block in LDS (natural, padded
+// rows), the accumulator is stored back as rows. 32 rows per wave-tile.
+template <int KB, int CB>
+__global__ void __launch_bounds__(kThreads)
+k_linear_mfma(float* __restrict__ y, int ldy, const float* __restrict__ x, int ldx, int kb1,
+              const float* __restrict__ x2, int ldx2, const float* __restrict__ W, int swc, int swk,
+              const float* __restrict__ W2, int swc2, int swk2, const float* __restrict__ b, int N,
+              int accumulate) {
+    constexpr int K = 32 * KB, C = 32 * CB, LD = K + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wn = smem;
+    float* bias = smem + C * LD;
+    const int k1 = 32 * kb1;
+    for (int i = threadIdx.x; i < C * K; i += kThreads) {
+        const int c = i / K, k = i % K;
+        Wn[c * LD + k] = k < k1 ? W[(size_t)c * swc + (size_t)k * swk]
+                                : W2[(size_t)c * swc2 + (size_t)(k - k1) * swk2];
+    }
+    for (int c = threadIdx.x; c < C; c += kThreads) bias[c] = b ? b[c] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int n_tiles = (N + 31) / 32;
+    for (int tile = blockIdx.x * (kThreads / 64) + wv; tile < n_tiles; tile += gridDim.x * (kThreads / 64)) {
+        const int n = tile * 32 + j;
+        const bool valid = n < N;
+        const int nn = valid ? n : N - 1;
+        float v[KB][16];
+#pragma unroll
+        for (int bb = 0; bb < KB; ++bb) {
+            const float* src = bb < kb1 ? x + (size_t)nn * ldx + 32 * bb
+                                        : x2 + (size_t)nn * ldx2 + 32 * (bb - kb1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 q = *reinterpret_cast<const float4*>(src + 8 * g + 4 * hh);
+                v[bb][4 * g] = q.x; v[bb][4 * g + 1] = q.y; v[bb][4 * g + 2] = q.z; v[bb][4 * g + 3] = q.w;
+            }
+        }
+        f32x16 acc[CB];
+        float* dst = y + (size_t)nn * ldy;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bq = *reinterpret_cast<const float4*>(bias + 32 * cb + 8 * g + 4 * hh);
+                float4 init = bq;
+                if (accumulate) {
+                    const float4 old = *reinterpret_cast<const float4*>(dst + 32 * cb + 8 * g + 4 * hh);
+                    init.x += old.x; init.y += old.y; init.z += old.z; init.w += old.w;
+                }
+                acc[cb][4 * g] = init.x; acc[cb][4 * g + 1] = init.y;
+                acc[cb][4 * g + 2] = init.z; acc[cb][4 * g + 3] = init.w;
+            }
+        mfma_chain_rect<CB, KB, false>(Wn, lane, v, acc);
+        if (valid) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(dst + 32 * cb + 8 * g + 4 * hh) =
+                        make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
+        }
+    }
+}
+
 // MFMA weight-gradient product for 32-aligned shapes: out[c][k] = sum_n A[n][c] * B[n][k].
 // The sum runs over rows, so both operands are read straight from the row-major arrays in
 // A/B-operand order (lane l: row n + (l>>5), column 32*blk + (l&31): two coalesced 128-B runs per
 // instruction) - no LDS staging. Each wave walks its rows two at a time; the 4 waves of a block
 // are added in wave order through LDS; block partials go to slabs.
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef f32x16 f32x16_t;
 
 template <int CB, int KB>
 __global__ void __launch_bounds__(kThreads)
@@ -278,6 +346,26 @@ int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx,
     PVS_REQUIRE(C >= 1 && C <= kThreads, "linear: n_out %d unsupported (1..256)", C);
     if (N <= 0) return 0;
     const int KK = K + K2;
+    const bool aligned16 = ((ldx | ldy | (x2 ? ldx2 : 0)) & 3) == 0 &&
+                           (((uintptr_t)x | (uintptr_t)y | (uintptr_t)x2) & 15) == 0;
+    if (aligned16 && K % 32 == 0 && K2 % 32 == 0 && C % 32 == 0 && C <= 64 && (KK == 32 || KK == 64 || KK == 128)) {
+        const int kb = KK / 32, cb = C / 32;
+        const size_t lds_m = (size_t)(C * (KK + 1) + C) * sizeof(float);
+        int blocks_m = (N + 127) / 128;
+        if (blocks_m > 1024) blocks_m = 1024;
+#define PVS_LIN(KBV, CBV)                                                                          \
+    k_linear_mfma<KBV, CBV><<<blocks_m, kThreads, lds_m, s>>>(y, ldy, x, ldx, K / 32, x2, ldx2, W, swc, \
+                                                              swk, W2, swc2, swk2, b, N, accumulate ? 1 : 0)
+        if (kb == 1 && cb == 1) PVS_LIN(1, 1);
+        else if (kb == 2 && cb == 1) PVS_LIN(2, 1);
+        else if (kb == 4 && cb == 1) PVS_LIN(4, 1);
+        else if (kb == 1 && cb == 2) PVS_LIN(1, 2);
+        else if (kb == 2 && cb == 2) PVS_LIN(2, 2);
+        else PVS_LIN(4, 2);
+#undef PVS_LIN
+        PVS_CHECK_LAUNCH();
+        return 0;
+    }
     const int NB = kThreads / C > 0 ? kThreads / C : 1;
     size_t lds = (size_t)(KK * C + NB * KK) * sizeof(float);
     PVS_REQUIRE(lds <= 160 * 1024, "linear: %d x %d weights do not fit LDS", KK, C);

@@ -15,11 +15,10 @@
 //
 // Layout maps validated lane-by-lane in tools/mfma_layout_check.py.
 #include "edge_kernels.h"
+#include "mfma_common.h"
 #include "profile.h"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
@@ -32,8 +31,6 @@ constexpr int kTile = 32;
 // Timing-only ablation switches (PVS_ABLATE env, tools/ablate.py): results are wrong when set.
 constexpr uint32_t kAblNoMfma = 1u << 24, kAblNoSilu = 1u << 25, kAblNoReduce = 1u << 26,
                    kAblNoGather = 1u << 27;
-
-__device__ __forceinline__ int xch(int t, int hh) { return (t & 3) + 8 * (t >> 2) + 4 * hh; }
 
 // Stage W[H][H] (row-major, W[out][in]) for  Z = W V  (transpose=false)  or  Z = W^T V  (true)
 // in A-operand order: dst[((bo*HB + bi)*16 + t)*64 + l] = Wx[32bo + (l&31)][32bi + ch(t, l>>5)].
@@ -459,29 +456,6 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
     }
 }
 
-
-// ---- X-layout helpers ----
-template <int HB>
-__device__ __forceinline__ void load_x(const float* __restrict__ base, int hh, float (&out)[HB][16]) {
-    // base points at channel 0 of one row of a row-major [rows][H] array
-#pragma unroll
-    for (int b = 0; b < HB; ++b)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 v = *reinterpret_cast<const float4*>(base + 32 * b + 8 * g + 4 * hh);
-            out[b][4 * g] = v.x; out[b][4 * g + 1] = v.y; out[b][4 * g + 2] = v.z; out[b][4 * g + 3] = v.w;
-        }
-}
-
-template <int HB>
-__device__ __forceinline__ void store_x(float* __restrict__ base, int hh, const float (&v)[HB][16]) {
-#pragma unroll
-    for (int b = 0; b < HB; ++b)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(base + 32 * b + 8 * g + 4 * hh) =
-                make_float4(v[b][4 * g], v[b][4 * g + 1], v[b][4 * g + 2], v[b][4 * g + 3]);
-}
 
 // Backward of the per-edge work on the matrix cores. Per 32-edge tile: recompute the forward
 // (2 products), back-propagate (2 transposed products) and accumulate the two HxH weight

@@ -203,7 +203,9 @@ int node_pre_forward(hipStream_t s, const Dims& m, const PvsLayerParams* p, cons
 
 extern "C" size_t pvs_egnn_layer_saved_floats(const PvsLayerDesc* d, int32_t N, int32_t E) {
     (void)E;
-    return (size_t)N * d->hidden + 2 * (size_t)d->hidden;
+    // Magg [N,H] | graphnorm stats [2H] | PQ [N,2H] | y1 [N,H] | o [N,H]: the node-level forward is
+    // kept for the backward (N rows: small) instead of being recomputed
+    return 5 * (size_t)N * d->hidden + 2 * (size_t)d->hidden;
 }
 
 extern "C" size_t pvs_egnn_layer_workspace_bytes(const PvsLayerDesc* d, int32_t N, int32_t E,
@@ -235,12 +237,15 @@ extern "C" int pvs_egnn_layer_fwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     const int H = m.H;
     float* Magg = saved;
     float* stats = saved + (size_t)m.N * H;
+    float* sPQ = stats + 2 * H;
+    float* sy1 = sPQ + 2 * (size_t)m.N * H;
+    float* so = sy1 + (size_t)m.N * H;
     const PvsEdgeW ew = make_edge_w(m, p);
     const PvsNodeW nw = make_node_w(d, p);
 
-    PVS_TRY(node_pre_forward(s, m, p, h, w.PQ));
+    PVS_TRY(node_pre_forward(s, m, p, h, sPQ));
     PvsEdgeFwdIO io;
-    io.PQ = w.PQ; io.x = x; io.m_prev = m_prev; io.Magg = Magg; io.x_out = x_out; io.m_out = m_out;
+    io.PQ = sPQ; io.x = x; io.m_prev = m_prev; io.Magg = Magg; io.x_out = x_out; io.m_out = m_out;
     io.att_out = att_out; io.smax = w.smax; io.ssum = w.ssum;
     if (pvs_use_mfma() && pvs_edge_mfma_supported(H, d->flags))
         PVS_TRY(pvs_launch_edge_fwd_mfma(s, H, *g, ew, d->flags | pvs_ablate_bits(), d->att_act, io));
@@ -249,8 +254,8 @@ extern "C" int pvs_egnn_layer_fwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     if (!(d->flags & PVS_UPDATE_COORDS))
         PVS_CHECK_HIP(hipMemcpyAsync(x_out, x, sizeof(float) * 3 * (size_t)m.N,
                                      hipMemcpyDeviceToDevice, s));
-    PVS_TRY(node_mlp_forward(s, m, d, p, nw, h, Magg, w.y1, w.u, w.o, stats, true, w.shift, w.slabs));
-    PVS_TRY(pvs_node_out_fwd(s, H, w.o, h, nw, d->flags, d->att_act, m.N, h_out, node_att_out));
+    PVS_TRY(node_mlp_forward(s, m, d, p, nw, h, Magg, sy1, w.u, so, stats, true, w.shift, w.slabs));
+    PVS_TRY(pvs_node_out_fwd(s, H, so, h, nw, d->flags, d->att_act, m.N, h_out, node_att_out));
     return 0;
 }
 
@@ -278,18 +283,20 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     const int H = m.H, N = m.N;
     const float* Magg = saved;
     float* stats = const_cast<float*>(saved) + (size_t)N * H;   // read-only here
+    const float* sPQ = stats + 2 * H;
+    const float* sy1 = sPQ + 2 * (size_t)N * H;
+    const float* so = sy1 + (size_t)N * H;
     const PvsEdgeW ew = make_edge_w(m, p);
     const PvsNodeW nw = make_node_w(d, p);
     const bool gn = F & PVS_GRAPHNORM, natt = F & PVS_NODE_ATTENTION;
     const bool gates = (F & PVS_RESIDUAL) && (F & (PVS_REZERO | PVS_GATED_RESIDUAL));
     const bool coord_bwd = (F & PVS_UPDATE_COORDS) && g_x_out;
 
-    // ---- recompute the node-level forward (cheap: N rows) ----
-    PVS_TRY(node_pre_forward(s, m, p, h, w.PQ));
-    PVS_TRY(node_mlp_forward(s, m, d, p, nw, h, Magg, w.y1, w.u, w.o, stats, false, nullptr, nullptr));
+    // ---- node-level forward: PQ, y1, o were kept by the forward; u = SiLU(GN(y1)) is elementwise ----
+    PVS_TRY(pvs_node_tail_fwd(s, sy1, stats, nw, N, H, w.u));
 
     // ---- node_model backward ----
-    PVS_TRY(pvs_node_out_bwd(s, H, g_h_out, w.o, h, nw, F, d->att_act, N, w.g_o, g_h, w.gl, w.t1,
+    PVS_TRY(pvs_node_out_bwd(s, H, g_h_out, so, h, nw, F, d->att_act, N, w.g_o, g_h, w.gl, w.t1,
                              w.tg));
     if (natt) {
         if (gr.node_att_w)
@@ -313,15 +320,15 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
         PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.node_b2, w.g_o, H, nullptr, 0, nullptr, N, H,
                                      1.f, w.dslabs, false));
     // u = SiLU(GN(y1)) ; g_u becomes g_yn then g_y1 in place
-    PVS_TRY(pvs_node_tail_bwd1(s, w.g_u, w.y1, stats, nw, N, H, w.g_u));
+    PVS_TRY(pvs_node_tail_bwd1(s, w.g_u, sy1, stats, nw, N, H, w.g_u));
     if (gn) {
         PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, w.S1, w.g_u, H, nullptr, 0, nullptr, N, H, 1.f,
                                      w.dslabs, false));
-        PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_AB, w.S2, w.g_u, H, w.y1, H, nullptr, N, H, 1.f,
+        PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_AB, w.S2, w.g_u, H, sy1, H, nullptr, N, H, 1.f,
                                      w.dslabs, false));
         PVS_TRY(pvs_graphnorm_bwd_coefs(s, w.S1, w.S2, stats, nw, N, H, gr.gn_weight, gr.gn_bias,
                                         gr.gn_mean_scale, w.coefs));
-        PVS_TRY(pvs_node_tail_bwd2(s, w.g_u, w.y1, stats, nw, w.coefs, N, H, w.g_u));
+        PVS_TRY(pvs_node_tail_bwd2(s, w.g_u, sy1, stats, nw, w.coefs, N, H, w.g_u));
     }
     float* g_y1 = w.g_u;
     // y1 = h Wn1[:, :H]^T + Magg Wn1[:, H:]^T + bn1
@@ -342,7 +349,7 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     PVS_TRY(pvs_prep_edge_bwd(s, g_x_out, g->inv_deg, Magg, w.gM, N, H,
                               coord_bwd ? w.gxagg : nullptr, (eatt && soft) ? w.softD : nullptr));
     PvsEdgeBwdIO io;
-    io.PQ = w.PQ; io.x = x; io.m_prev = m_prev; io.att = att; io.gM = w.gM;
+    io.PQ = sPQ; io.x = x; io.m_prev = m_prev; io.att = att; io.gM = w.gM;
     io.gxagg = coord_bwd ? w.gxagg : nullptr;
     io.softD = (eatt && soft) ? w.softD : nullptr;
     io.g_m_out = g_m_out; io.gPQ = w.gPQ; io.gz1 = w.gz1; io.gd = w.gd; io.gx_row = w.gx_row;
