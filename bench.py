@@ -197,6 +197,11 @@ def main():
         step_flops = algorithmic_flops_per_step(
             n_nodes, n_edges, h, 3, layers, cfg['model']['edge_attention'],
             cfg['model']['node_attention'])
+        traffic = None
+        tfile = ROOT / 'profiles' / f'r01_{args.config}_traffic.json'
+        if tfile.exists():   # PMC passes cannot run inside this process: tools/measure_traffic.sh
+            kern = json.loads(tfile.read_text()).get('kernels', {})
+            traffic = kern.get('k_edge_bwd_mfma', {}).get('hbm_bytes_per_launch')
         out = {
             'metric': 'protein-ligand graphs/sec fwd+bwd (+Adam step), 3-layer EGNN ch=32, '
                       '~2k nodes r=10A' if args.config == 'cfg2' else
@@ -216,7 +221,7 @@ def main():
             'roofline': {
                 'bound': 'hbm', 'kernel': 'k_edge_bwd_mfma<1> (edge backward, one launch per layer)',
                 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+                'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                 'algorithmic_bytes_per_launch': dom_bytes,
                 'avg_launch_ms': round(dom_avg_ms, 4), 'launches': bwd_n,
                 'step_hbm_frac': round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
