@@ -73,8 +73,9 @@ int pvs_edge_mfma_supported(int H, uint32_t flags);
 int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,
                              int att_act, const PvsEdgeFwdIO& io);
 int pvs_edge_bwd_mfma_supported(int H, uint32_t flags, int n_attr);
+int pvs_edge_bwd_mfma_max_blocks(int H);
 int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,
-                             int att_act, const PvsEdgeBwdIO& io, int* n_slabs);
+                             int att_act, const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs);
 int pvs_edge_v0_supported(int H);
 int pvs_edge_v0_blocks(int N);
 int pvs_launch_edge_fwd_v0(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,
@@ -86,4 +87,4 @@ int pvs_launch_edge_bwd_v0(hipStream_t s, int H, const PvsGraph& g, const PvsEdg
 int pvs_node_gather_blocks(int N);
 int pvs_launch_node_gather(hipStream_t s, int H, const PvsGraph& g, bool wsums, const float* gz1,
                            const float* gd4, const float* gx_row, const float* g_x_out, float* gPQ,
-                           float* g_x, float* slabs, int* n_slabs);
+                           float* g_x, float* slabs, int n_lo, int n_hi, int* n_slabs);

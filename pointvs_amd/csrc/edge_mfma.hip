@@ -125,11 +125,13 @@ __device__ __forceinline__ float dot_tab(const float* __restrict__ tab, int hh, 
     return s + __shfl_xor(s, 32, 64);   // other half holds the other 16 channels of each block
 }
 
-__device__ __forceinline__ int chunk_begin(const PvsGraph& g, int k, int n_chunks) {
-    if (k <= 0) return 0;
-    if (k >= n_chunks) return g.n_edges;
-    const long long t = (long long)k * g.n_edges / n_chunks;
-    return g.rowptr[g.row[t]];   // start of the row that contains edge t: chunks are row-aligned
+// Wave chunks of the edge range [e_lo, e_hi) (row-aligned ends): chunk k starts at the row that
+// contains edge e_lo + k*(e_hi-e_lo)/n_chunks, so every row is owned by exactly one wave.
+__device__ __forceinline__ int chunk_begin(const PvsGraph& g, int k, int n_chunks, int e_lo, int e_hi) {
+    if (k <= 0) return e_lo;
+    if (k >= n_chunks) return e_hi;
+    const long long t = e_lo + (long long)k * (e_hi - e_lo) / n_chunks;
+    return max(e_lo, g.rowptr[g.row[t]]);
 }
 
 // Indices of one 32-edge tile (lane = edge slot j, both halves hold the same values).
@@ -266,7 +268,8 @@ __device__ __forceinline__ float4 sum_row_slots(float4 a) {
 
 template <int HB>
 __global__ void __launch_bounds__(kThreads)
-k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdIO io, int n_chunks) {
+k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdIO io, int n_chunks,
+                int e_lo, int e_hi) {
     constexpr int H = 32 * HB;
     constexpr int TS = H + 4;   // tile row stride (floats): conflict-free b128 writes / b32 reads
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -312,8 +315,8 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
 
     const int total_waves = gridDim.x * kWaves;
     for (int chunk = blockIdx.x * kWaves + wv; chunk < n_chunks; chunk += total_waves) {
-        const int e_begin = chunk_begin(g, chunk, n_chunks);
-        const int e_end = chunk_begin(g, chunk + 1, n_chunks);
+        const int e_begin = chunk_begin(g, chunk, n_chunks, e_lo, e_hi);
+        const int e_end = chunk_begin(g, chunk + 1, n_chunks, e_lo, e_hi);
         int cur_row = -1;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accx = acc;   // open row: lane = (row slot, quad)
         constexpr int QPR = H / 4;
@@ -464,7 +467,8 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
 // on the lane (one accumulator register each).
 template <int HB, bool ERES, bool EATT>
 __global__ void __launch_bounds__(kThreads, HB == 1 ? 2 : 1)
-k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks) {
+k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks,
+                int e_lo, int e_hi) {
     constexpr int H = 32 * HB;
     constexpr int TS = H + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -533,8 +537,8 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
 
     const int total_waves = gridDim.x * kWaves;
     for (int chunk = blockIdx.x * kWaves + wv; chunk < n_chunks; chunk += total_waves) {
-        const int e_begin = chunk_begin(g, chunk, n_chunks);
-        const int e_end = chunk_begin(g, chunk + 1, n_chunks);
+        const int e_begin = chunk_begin(g, chunk, n_chunks, e_lo, e_hi);
+        const int e_end = chunk_begin(g, chunk + 1, n_chunks, e_lo, e_hi);
         int cur_row = -1;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accx = acc;   // open row: lane = (row slot, quad)
         constexpr int QPR = H / 4;
@@ -914,11 +918,12 @@ int set_lds(K kernel, size_t lds) {
     return 0;
 }
 
-void pick_grid(int E, int* blocks, int* n_chunks) {
-    // one chunk = a few thousand edges; every wave gets the same number of chunks
-    long long b = ((long long)E + 4095) / 4096;
+void pick_grid(int E, int* blocks, int* n_chunks, int max_blocks = 1024) {
+    // a wave gets >= ~2048 edges where the range allows; chunks of <= ~4096 edges; every wave gets
+    // the same number of chunks
+    long long b = ((long long)E + 4 * 2048 - 1) / (4 * 2048);
     if (b < 1) b = 1;
-    if (b > 1024) b = 1024;
+    if (b > max_blocks) b = max_blocks;
     const long long waves = b * kWaves;
     long long per_wave = ((long long)E + waves * 4096 - 1) / (waves * 4096);
     if (per_wave < 1) per_wave = 1;
@@ -953,31 +958,28 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     const size_t lds = words * sizeof(float);
     if (HB == 1) {
         if (set_lds(k_edge_fwd_mfma<1>, lds)) return -2;
-        k_edge_fwd_mfma<1><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks);
+        k_edge_fwd_mfma<1><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
     } else {
         if (set_lds(k_edge_fwd_mfma<2>, lds)) return -2;
-        k_edge_fwd_mfma<2><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks);
+        k_edge_fwd_mfma<2><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
     }
     PVS_CHECK_LAUNCH();
     return 0;
 }
 
+int pvs_edge_bwd_mfma_max_blocks(int H) { return H == 32 ? 512 : 256; }
+
+// Edge backward over the CSR edge range [e_lo, e_hi) (row-aligned: the whole batch or one segment
+// of whole graphs). gPQ's row part and gx_row must have been zeroed by the caller (rows without
+// edges are never written). Writes *n_slabs per-block weight-gradient partials at io.slabs.
 int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,
-                             int att_act, const PvsEdgeBwdIO& io, int* n_slabs) {
+                             int att_act, const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs) {
     PVS_REQUIRE(w.n_attr <= 3, "MFMA edge backward supports up to 3 edge classes (got %d)", w.n_attr);
     PVS_REQUIRE(H == 32 || H == 64, "MFMA edge backward is built for H = 32, 64 (got %d)", H);
-    // rows without edges are never flushed
-    PVS_CHECK_HIP(hipMemsetAsync(io.gPQ, 0, sizeof(float) * 2 * (size_t)g.n_nodes * H, s));
-    PVS_CHECK_HIP(hipMemsetAsync(io.gx_row, 0, sizeof(float) * 3 * (size_t)g.n_nodes, s));
+    *n_slabs = 0;
+    if (e_hi <= e_lo) return 0;
     int blocks, n_chunks;
-    pick_grid(g.n_edges, &blocks, &n_chunks);
-    const int max_blocks = H == 32 ? 512 : 256;   // resident blocks: 2 per CU (H=32), 1 per CU (H=64)
-    if (blocks > max_blocks) {
-        blocks = max_blocks;
-        const long long waves = (long long)blocks * kWaves;
-        long long per_wave = ((long long)g.n_edges + waves * 4096 - 1) / (waves * 4096);
-        n_chunks = (int)(waves * (per_wave < 1 ? 1 : per_wave));
-    }
+    pick_grid(e_hi - e_lo, &blocks, &n_chunks, pvs_edge_bwd_mfma_max_blocks(H));   // resident blocks
     *n_slabs = blocks;
     PvsProfScope prof(s, PVS_PROF_EDGE_BWD);
     const PvsSlabLayout L = pvs_slab_layout(H);
@@ -990,7 +992,8 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
 #define PVS_BWD_LAUNCH(HBV, ER, EA)                                                               \
     do {                                                                                          \
         if (set_lds(k_edge_bwd_mfma<HBV, ER, EA>, lds)) return -2;                                \
-        k_edge_bwd_mfma<HBV, ER, EA><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks); \
+        k_edge_bwd_mfma<HBV, ER, EA><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, \
+                                                                   e_lo, e_hi);                  \
     } while (0)
 #define PVS_BWD_PICK(HBV)                               \
     do {                                                \

@@ -429,7 +429,8 @@ template <int H, bool WSUMS>
 __global__ void __launch_bounds__(kThreads)
 k_node_gather(PvsGraph g, const float* __restrict__ gz1, const float* __restrict__ gd4,
               const float* __restrict__ gx_row, const float* __restrict__ g_x_out,
-              float* __restrict__ gPQ, float* __restrict__ g_x, float* __restrict__ slabs) {
+              float* __restrict__ gPQ, float* __restrict__ g_x, float* __restrict__ slabs,
+              int n_lo, int n_hi) {
     constexpr int QPR = H / 4;
     constexpr int EPW = 64 / QPR;
     constexpr int UN = 4;
@@ -442,7 +443,7 @@ k_node_gather(PvsGraph g, const float* __restrict__ gz1, const float* __restrict
     auto fma4 = [](float4& a, const float4& v, float s) {
         a.x = fmaf(v.x, s, a.x); a.y = fmaf(v.y, s, a.y); a.z = fmaf(v.z, s, a.z); a.w = fmaf(v.w, s, a.w);
     };
-    for (int n = blockIdx.x * kWaves + wv; n < g.n_nodes; n += total_waves) {
+    for (int n = n_lo + blockIdx.x * kWaves + wv; n < n_hi; n += total_waves) {
         float4 accc = make_float4(0.f, 0.f, 0.f, 0.f);
         float axc = 0.f;     // lanes with quad < 3 own coordinate component `quad`
         const int p0 = g.colptr[n], p1 = g.colptr[n + 1];
@@ -591,17 +592,22 @@ int pvs_node_gather_blocks(int N) {
     return b > 512 ? 512 : b;
 }
 
+// Column gather over the node range [n_lo, n_hi) (whole batch or one segment of whole graphs).
 int pvs_launch_node_gather(hipStream_t s, int H, const PvsGraph& g, bool wsums, const float* gz1,
                            const float* gd4, const float* gx_row, const float* g_x_out, float* gPQ,
-                           float* g_x, float* slabs, int* n_slabs) {
-    const int blocks = wsums ? pvs_node_gather_blocks(g.n_nodes) : pvs_edge_v0_blocks(g.n_nodes);
+                           float* g_x, float* slabs, int n_lo, int n_hi, int* n_slabs) {
+    *n_slabs = 0;
+    if (n_hi <= n_lo) return 0;
+    const int blocks = wsums ? pvs_node_gather_blocks(n_hi - n_lo) : pvs_edge_v0_blocks(n_hi - n_lo);
     *n_slabs = wsums ? blocks : 0;
     PvsProfScope prof(s, PVS_PROF_COL_GATHER);
     PVS_DISPATCH_H(H, {
         if (wsums)
-            k_node_gather<HH, true><<<blocks, kThreads, 0, s>>>(g, gz1, gd4, gx_row, g_x_out, gPQ, g_x, slabs);
+            k_node_gather<HH, true><<<blocks, kThreads, 0, s>>>(g, gz1, gd4, gx_row, g_x_out, gPQ, g_x, slabs,
+                                                                n_lo, n_hi);
         else
-            k_node_gather<HH, false><<<blocks, kThreads, 0, s>>>(g, gz1, gd4, gx_row, g_x_out, gPQ, g_x, slabs);
+            k_node_gather<HH, false><<<blocks, kThreads, 0, s>>>(g, gz1, gd4, gx_row, g_x_out, gPQ, g_x, slabs,
+                                                                 n_lo, n_hi);
     });
     PVS_CHECK_LAUNCH();
     return 0;

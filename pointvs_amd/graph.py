@@ -7,6 +7,7 @@
 int64 one-hot; every layer's forward and backward of a step share one instance.
 """
 import collections
+import ctypes as C
 
 import torch
 
@@ -55,19 +56,36 @@ class Batch(Data):
         merged['batch'] = torch.cat(batch_vec)
         merged['ptr'] = torch.tensor(ptr, dtype=torch.long)
         merged['num_graphs'] = len(items)
+        # host-side per-graph sizes (plain lists survive .to(device)): let the backward pipeline
+        # whole-graph segments without a device->host sync
+        merged['graph_node_counts'] = [int(item.x.size(0)) for item in items]
+        merged['graph_edge_counts'] = [int(item.edge_index.size(1)) for item in items]
         return Batch(**merged)
 
 
 class PreparedGraph:
     """Device-resident CSR (by row = edge_index[0]) + CSC (by col) of one batch."""
 
-    def __init__(self, n_nodes, n_edges, n_edge_attr, tensors):
+    def __init__(self, n_nodes, n_edges, n_edge_attr, tensors, segments=None):
         self.n_nodes, self.n_edges, self.n_edge_attr = n_nodes, n_edges, n_edge_attr
         self.t = tensors  # keeps the storage alive for the struct's raw pointers
         g = _lib.PvsGraph()
         g.n_nodes, g.n_edges = n_nodes, n_edges
         for name in ('rowptr', 'row', 'col', 'etype', 'perm', 'colptr', 'cedge', 'inv_deg'):
             setattr(g, name, _lib.ptr(tensors.get(name)))
+        self._seg_arrays = None
+        if segments is not None:
+            node_counts, edge_counts = segments
+            if (len(node_counts) >= 2 and sum(node_counts) == n_nodes
+                    and sum(edge_counts) == n_edges):
+                n_seg = len(node_counts)
+                node_ptr = (C.c_int32 * (n_seg + 1))()
+                edge_ptr = (C.c_int32 * (n_seg + 1))()
+                for i in range(n_seg):
+                    node_ptr[i + 1] = node_ptr[i] + int(node_counts[i])
+                    edge_ptr[i + 1] = edge_ptr[i] + int(edge_counts[i])
+                self._seg_arrays = (node_ptr, edge_ptr)
+                g.n_segments, g.seg_node_ptr, g.seg_edge_ptr = n_seg, node_ptr, edge_ptr
         self.c = g
         self._status_checked = False
         self._status_host = None
@@ -110,8 +128,9 @@ class PreparedGraph:
 _PENDING = []
 
 
-def prepare_graph(edge_index, edge_attr, n_nodes):
-    """int64 COO `[2,E]` (+ int64 one-hot `[E,A]` or None) -> PreparedGraph on the same device."""
+def prepare_graph(edge_index, edge_attr, n_nodes, segments=None):
+    """int64 COO `[2,E]` (+ int64 one-hot `[E,A]` or None) -> PreparedGraph on the same device.
+    segments: optional (node_counts, edge_counts) per whole graph, host lists (see PvsGraph)."""
     _lib.require_hip(edge_index, edge_attr)
     lib = _lib.lib()
     if edge_index.dtype != torch.int64:
@@ -148,7 +167,7 @@ def prepare_graph(edge_index, edge_attr, n_nodes):
         _lib.ptr(t['perm']), _lib.ptr(t['colptr']), _lib.ptr(t['cedge']), _lib.ptr(t['inv_deg']),
         _lib.ptr(t['status']), _lib.ptr(ws), ws_bytes, stream)
     _lib.check(rc, 'pvs_graph_prepare')
-    return PreparedGraph(n_nodes, n_edges, n_attr, t)
+    return PreparedGraph(n_nodes, n_edges, n_attr, t, segments)
 
 
 _CACHE = collections.OrderedDict()
@@ -156,17 +175,17 @@ _CACHE_SIZE = 4
 CACHE_ENABLED = True   # bench.py turns this off: a training step prepares every batch afresh
 
 
-def prepared_for(edge_index, edge_attr, n_nodes):
+def prepared_for(edge_index, edge_attr, n_nodes, segments=None):
     """Cached `prepare_graph`: the L layers of a forward are called with the same edge tensors."""
     if not CACHE_ENABLED:
-        return prepare_graph(edge_index, edge_attr, n_nodes)
+        return prepare_graph(edge_index, edge_attr, n_nodes, segments)
     key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
            None if edge_attr is None else (edge_attr.data_ptr(), edge_attr._version), n_nodes)
     hit = _CACHE.get(key)
     if hit is not None:
         _CACHE.move_to_end(key)
         return hit[0]
-    pg = prepare_graph(edge_index, edge_attr, n_nodes)
+    pg = prepare_graph(edge_index, edge_attr, n_nodes, segments)
     _CACHE[key] = (pg, edge_index, edge_attr)  # hold the inputs so data_ptr keys stay unique
     while len(_CACHE) > _CACHE_SIZE:
         _CACHE.popitem(last=False)
