@@ -18,6 +18,8 @@
 #include "mfma_common.h"
 #include "profile.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -266,16 +268,94 @@ __device__ __forceinline__ float4 sum_row_slots(float4 a) {
     return a;
 }
 
-template <int HB>
+
+// ---- fp32 products as 6 bf16 MFMA terms ("bf16x3") -------------------------------------------------
+// x = hi + mid + lo with each part the next 8 significant bits of x (truncation: exact 24-bit
+// split), so a*b = hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi + O(2^-25 |a||b|): fp32-level
+// accuracy from v_mfma_f32_32x32x16_bf16 (fp32 accumulate), 12 bf16 MFMAs of 32 cycles per
+// 32x32x32 block instead of 16 fp32 MFMAs of 64 cycles, on the matrix cores proper.
+// k-step s of the bf16 instruction takes X-layout registers 8s..8s+7 as its 8 B-operand elements
+// (k = 8*hh + j'), and the A operand staged with the same channel order.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Bf16Parts { bf16x8 hi[2], mid[2], lo[2]; };
+
+__device__ __forceinline__ unsigned pvs_pack_hi16(float x0, float x1) {
+    // bf16 (truncated) of x0 in the low half, of x1 in the high half
+    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+
+__device__ __forceinline__ void split_bf16x3(const float (&v)[16], Bf16Parts& out) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        uint4 ph, pm, pl;
+        unsigned* h = reinterpret_cast<unsigned*>(&ph);
+        unsigned* m = reinterpret_cast<unsigned*>(&pm);
+        unsigned* l = reinterpret_cast<unsigned*>(&pl);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float x0 = v[8 * s + 2 * q], x1 = v[8 * s + 2 * q + 1];
+            const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
+            const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+            const float t0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+            const float t1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+            h[q] = pvs_pack_hi16(x0, x1);
+            m[q] = pvs_pack_hi16(r0, r1);
+            l[q] = pvs_pack_hi16(t0, t1);
+        }
+        out.hi[s] = __builtin_bit_cast(bf16x8, ph);
+        out.mid[s] = __builtin_bit_cast(bf16x8, pm);
+        out.lo[s] = __builtin_bit_cast(bf16x8, pl);
+    }
+}
+
+// Stage W[32][32] (row-major, W[out][in]) as bf16x3 A operands: dst[((part*2 + s)*64 + l)*4 .. +3]
+// (uint words) = 8 bf16 of W[l&31][ch(8s + j', l>>5)], j' = 0..7, part in {hi, mid, lo}.
+__device__ __forceinline__ void stage_weights_bf16x3(unsigned* dst, const float* __restrict__ W) {
+    for (int i = threadIdx.x; i < 2 * 64 * 4; i += kThreads) {
+        const int q = i & 3, l = (i >> 2) & 63, s = i >> 8;
+        const int o = l & 31, hh = l >> 5;
+        const float x0 = W[o * 32 + xch(8 * s + 2 * q, hh)], x1 = W[o * 32 + xch(8 * s + 2 * q + 1, hh)];
+        const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
+        const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+        const float t0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+        const float t1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+        dst[((0 * 2 + s) * 64 + l) * 4 + q] = pvs_pack_hi16(x0, x1);
+        dst[((1 * 2 + s) * 64 + l) * 4 + q] = pvs_pack_hi16(r0, r1);
+        dst[((2 * 2 + s) * 64 + l) * 4 + q] = pvs_pack_hi16(t0, t1);
+    }
+}
+
+__device__ __forceinline__ void mfma_chain_bf16x3(const unsigned* __restrict__ Wb, int lane,
+                                                  const float (&v)[16], f32x16& acc) {
+    Bf16Parts b;
+    split_bf16x3(v, b);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wb + ((0 * 2 + s) * 64 + lane) * 4));
+        const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wb + ((1 * 2 + s) * 64 + lane) * 4));
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wb + ((2 * 2 + s) * 64 + lane) * 4));
+        // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.hi[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.lo[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.mid[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.hi[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.mid[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.hi[s], acc, 0, 0, 0);
+    }
+}
+
+template <int HB, bool BF16X3>
 __global__ void __launch_bounds__(kThreads)
 k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdIO io, int n_chunks,
                 int e_lo, int e_hi) {
     constexpr int H = 32 * HB;
     constexpr int TS = H + 4;   // tile row stride (floats): conflict-free b128 writes / b32 reads
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int kWeightWords = BF16X3 ? 2 * 6 * 64 * 4 : 2 * H * H;
     float* W2s = smem;
     float* Wc1s = W2s + H * H;
-    float* b2t = Wc1s + H * H;
+    float* b2t = smem + kWeightWords;
     float* bc1t = b2t + H;
     float* wc2t = bc1t + H;
     float* wat = wc2t + H;
@@ -288,8 +368,17 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
     const bool eatt = flags & PVS_EDGE_ATTENTION;
     const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
 
-    stage_weights<HB>(W2s, w.w2, false);
-    if (upd) stage_weights<HB>(Wc1s, w.wc1, false);
+    // BF16X3 (H = 32 only): each matrix takes 3 parts x 2 k-steps x 64 lanes x 16 B = 6 KB
+    static_assert(!BF16X3 || HB == 1, "bf16x3 variant is built for H = 32");
+    unsigned* W2b = reinterpret_cast<unsigned*>(W2s);
+    unsigned* Wc1b = W2b + 6 * 64 * 4;
+    if constexpr (BF16X3) {
+        stage_weights_bf16x3(W2b, w.w2);
+        if (upd) stage_weights_bf16x3(Wc1b, w.wc1);
+    } else {
+        stage_weights<HB>(W2s, w.w2, false);
+        if (upd) stage_weights<HB>(Wc1s, w.wc1, false);
+    }
     for (int c = threadIdx.x; c < H; c += kThreads) {
         b2t[c] = w.b2[c];
         bc1t[c] = upd ? w.bc1[c] : 0.f;
@@ -374,7 +463,8 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[b][r] = bias[b][r];
-                mfma_chain<HB>(W2s, lane, a1, acc2, flags & kAblNoMfma);
+                if constexpr (BF16X3) mfma_chain_bf16x3(W2b, lane, a1[0], acc2[0]);
+                else mfma_chain<HB>(W2s, lane, a1, acc2, flags & kAblNoMfma);
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
@@ -415,7 +505,8 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) accc[b][r] = bias[b][r];
-                mfma_chain<HB>(Wc1s, lane, m, accc, flags & kAblNoMfma);
+                if constexpr (BF16X3) mfma_chain_bf16x3(Wc1b, lane, m[0], accc[0]);
+                else mfma_chain<HB>(Wc1s, lane, m, accc, flags & kAblNoMfma);
                 float q[HB][16];
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
@@ -953,15 +1044,21 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     pick_grid(g.n_edges, &blocks, &n_chunks);
     PvsProfScope prof(s, PVS_PROF_EDGE_FWD);
     const int HB = H / 32;
-    const size_t words = (size_t)2 * H * H + (5 + PVS_MAX_EDGE_ATTR) * H +
+    const char* bf = getenv("PVS_EGNN_BF16X3");
+    const bool bf16x3 = bf && bf[0] == '1' && H == 32;
+    const size_t words = (bf16x3 ? (size_t)2 * 6 * 64 * 4 : (size_t)2 * H * H) +
+                         (5 + PVS_MAX_EDGE_ATTR) * H +
                          (size_t)kWaves * (kTile * (H + 4) + kTile * 4 + kTile);
     const size_t lds = words * sizeof(float);
-    if (HB == 1) {
-        if (set_lds(k_edge_fwd_mfma<1>, lds)) return -2;
-        k_edge_fwd_mfma<1><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
+    if (HB == 1 && bf16x3) {
+        if (set_lds(k_edge_fwd_mfma<1, true>, lds)) return -2;
+        k_edge_fwd_mfma<1, true><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
+    } else if (HB == 1) {
+        if (set_lds(k_edge_fwd_mfma<1, false>, lds)) return -2;
+        k_edge_fwd_mfma<1, false><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
     } else {
-        if (set_lds(k_edge_fwd_mfma<2>, lds)) return -2;
-        k_edge_fwd_mfma<2><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
+        if (set_lds(k_edge_fwd_mfma<2, false>, lds)) return -2;
+        k_edge_fwd_mfma<2, false><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
     }
     PVS_CHECK_LAUNCH();
     return 0;
