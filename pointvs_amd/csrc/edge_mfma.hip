@@ -74,7 +74,7 @@ __device__ __forceinline__ void mfma_chain(const float* __restrict__ Ws, int lan
 template <int HB>
 __device__ __forceinline__ void stage_weights_nat(float* dst, const float* __restrict__ W) {
     constexpr int H = 32 * HB;
-    for (int i = threadIdx.x; i < H * H; i += kThreads) dst[(i / H) * (H + 1) + (i % H)] = W[i];
+    for (int i = threadIdx.x; i < H * H; i += blockDim.x) dst[(i / H) * (H + 1) + (i % H)] = W[i];
 }
 
 template <int HB, bool TRANSPOSE>
@@ -311,11 +311,15 @@ __device__ __forceinline__ void split_bf16x3(const float (&v)[16], Bf16Parts& ou
 
 // Stage W[32][32] (row-major, W[out][in]) as bf16x3 A operands: dst[((part*2 + s)*64 + l)*4 .. +3]
 // (uint words) = 8 bf16 of W[l&31][ch(8s + j', l>>5)], j' = 0..7, part in {hi, mid, lo}.
-__device__ __forceinline__ void stage_weights_bf16x3(unsigned* dst, const float* __restrict__ W) {
-    for (int i = threadIdx.x; i < 2 * 64 * 4; i += kThreads) {
+__device__ __forceinline__ void stage_weights_bf16x3(unsigned* dst, const float* __restrict__ W,
+                                                     bool transpose = false) {
+    // transpose: operand rows are the columns of W (Z = W^T V)
+    for (int i = threadIdx.x; i < 2 * 64 * 4; i += blockDim.x) {
         const int q = i & 3, l = (i >> 2) & 63, s = i >> 8;
         const int o = l & 31, hh = l >> 5;
-        const float x0 = W[o * 32 + xch(8 * s + 2 * q, hh)], x1 = W[o * 32 + xch(8 * s + 2 * q + 1, hh)];
+        const int k0 = xch(8 * s + 2 * q, hh), k1 = xch(8 * s + 2 * q + 1, hh);
+        const float x0 = transpose ? W[k0 * 32 + o] : W[o * 32 + k0];
+        const float x1 = transpose ? W[k1 * 32 + o] : W[o * 32 + k1];
         const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
         const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
         const float t0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
@@ -556,16 +560,26 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
 // gradients as products over the EDGE index (operands re-read edge-major from per-wave LDS tiles),
 // 96 MFMAs per 32x32 block in total. Vector gradients ride on the same LDS tiles with the channel
 // on the lane (one accumulator register each).
-template <int HB, bool ERES, bool EATT>
-__global__ void __launch_bounds__(kThreads, HB == 1 ? 2 : 1)
+template <int HB, bool ERES, bool EATT, bool BF16X3>
+__global__ void __launch_bounds__(BF16X3 ? 512 : kThreads, HB == 1 ? 2 : 1)
 k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks,
                 int e_lo, int e_hi) {
     constexpr int H = 32 * HB;
     constexpr int TS = H + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* W2n = smem;                    // W2 natural, padded rows: z2 = W2 a1, g_a1 = W2^T g_z2
-    float* Wc1n = W2n + H * (H + 1);      // Wc1 natural: zc = Wc1 m, g_m += Wc1^T g_zc
-    float* b2t = Wc1n + H * (H + 1);
+    // fp32 path: W2 / Wc1 natural with padded rows (one copy serves W and W^T products)
+    // BF16X3 path (H = 32, 512 threads): 4 operand matrices x 3 parts x 2 k-steps x 1 KB
+    static_assert(!BF16X3 || HB == 1, "bf16x3 variant is built for H = 32");
+    constexpr int NT = BF16X3 ? 512 : kThreads;
+    constexpr int NW = NT / 64;
+    constexpr int kWeightWords = BF16X3 ? 4 * 6 * 64 * 4 : 2 * H * (H + 1);
+    float* W2n = smem;
+    float* Wc1n = W2n + H * (H + 1);
+    unsigned* W2b = reinterpret_cast<unsigned*>(smem);      // z2 = W2 a1
+    unsigned* W2tb = W2b + 6 * 64 * 4;                      // g_a1 = W2^T g_z2
+    unsigned* Wc1b = W2tb + 6 * 64 * 4;                     // zc = Wc1 m
+    unsigned* Wc1tb = Wc1b + 6 * 64 * 4;                    // g_m += Wc1^T g_zc
+    float* b2t = smem + kWeightWords;
     float* bc1t = b2t + H;
     float* wc2t = bc1t + H;
     float* wat = wc2t + H;
@@ -579,9 +593,18 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     constexpr bool eatt = EATT;
     constexpr bool eres = ERES;
 
-    stage_weights_nat<HB>(W2n, w.w2);
-    if (upd) stage_weights_nat<HB>(Wc1n, w.wc1);
-    for (int c = threadIdx.x; c < H; c += kThreads) {
+    if constexpr (BF16X3) {
+        stage_weights_bf16x3(W2b, w.w2, false);
+        stage_weights_bf16x3(W2tb, w.w2, true);
+        if (upd) {
+            stage_weights_bf16x3(Wc1b, w.wc1, false);
+            stage_weights_bf16x3(Wc1tb, w.wc1, true);
+        }
+    } else {
+        stage_weights_nat<HB>(W2n, w.w2);
+        if (upd) stage_weights_nat<HB>(Wc1n, w.wc1);
+    }
+    for (int c = threadIdx.x; c < H; c += NT) {
         b2t[c] = w.b2[c];
         bc1t[c] = upd ? w.bc1[c] : 0.f;
         wc2t[c] = upd ? w.wc2[c] : 0.f;
@@ -626,8 +649,8 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     for (int b = 0; b < HB; ++b) g_b2[b] = g_bc1[b] = g_wa[b] = 0.f;
     float g_ba = 0.f, g_gate = 0.f;
 
-    const int total_waves = gridDim.x * kWaves;
-    for (int chunk = blockIdx.x * kWaves + wv; chunk < n_chunks; chunk += total_waves) {
+    const int total_waves = gridDim.x * NW;
+    for (int chunk = blockIdx.x * NW + wv; chunk < n_chunks; chunk += total_waves) {
         const int e_begin = chunk_begin(g, chunk, n_chunks, e_lo, e_hi);
         const int e_end = chunk_begin(g, chunk + 1, n_chunks, e_lo, e_hi);
         int cur_row = -1;
@@ -689,7 +712,8 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[b][r] = bias[b][r];
-                mfma_chain_nat<HB, false>(W2n, lane, a1, acc2, flags & kAblNoMfma);
+                if constexpr (BF16X3) mfma_chain_bf16x3(W2b, lane, a1[0], acc2[0]);
+                else mfma_chain_nat<HB, false>(W2n, lane, a1, acc2, flags & kAblNoMfma);
                 float dz2[HB][16], m[HB][16];     // SiLU'(z2) and the message
                 float m_new[ERES ? HB : 1][16], mp[ERES ? HB : 1][16];
 #pragma unroll
@@ -768,7 +792,8 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                     for (int b = 0; b < HB; ++b)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) accc[b][r] = bias2[b][r];
-                    mfma_chain_nat<HB, false>(Wc1n, lane, m, accc, flags & kAblNoMfma);
+                    if constexpr (BF16X3) mfma_chain_bf16x3(Wc1b, lane, m[0], accc[0]);
+                    else mfma_chain_nat<HB, false>(Wc1n, lane, m, accc, flags & kAblNoMfma);
                     float q[HB][16], dq[HB][16];
 #pragma unroll
                     for (int b = 0; b < HB; ++b)
@@ -801,7 +826,8 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                             *reinterpret_cast<float4*>(T2 + j * TS + 32 * b + 8 * gq + 4 * hh) =
                                 make_float4(g_zc[b][4 * gq], g_zc[b][4 * gq + 1], g_zc[b][4 * gq + 2],
                                             g_zc[b][4 * gq + 3]);
-                    mfma_chain_nat<HB, true>(Wc1n, lane, g_zc, gm, flags & kAblNoMfma);   // g_m += Wc1^T g_zc
+                    if constexpr (BF16X3) mfma_chain_bf16x3(Wc1tb, lane, g_zc[0], gm[0]);   // g_m += Wc1^T g_zc
+                    else mfma_chain_nat<HB, true>(Wc1n, lane, g_zc, gm, flags & kAblNoMfma);
                 }
                 if (hh == 0) { glb[j] = g_l; rowbuf[j] = i; }
                 pvs_wave_lds_sync();
@@ -875,7 +901,8 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ga1[b][r] = 0.f;
-                mfma_chain_nat<HB, true>(W2n, lane, g_z2, ga1, flags & kAblNoMfma);
+                if constexpr (BF16X3) mfma_chain_bf16x3(W2tb, lane, g_z2[0], ga1[0]);
+                else mfma_chain_nat<HB, true>(W2n, lane, g_z2, ga1, flags & kAblNoMfma);
                 float g_z1[HB][16];
                 assemble_z1<HB>(G, attrt, wrhot, ty, hh, rho, g_z1);
 #pragma unroll
@@ -943,7 +970,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     const PvsSlabLayout L = pvs_slab_layout(H);
     __syncthreads();
     float* slab = smem;
-    for (int i = threadIdx.x; i < L.total; i += kThreads) slab[i] = 0.f;
+    for (int i = threadIdx.x; i < L.total; i += NT) slab[i] = 0.f;
     __syncthreads();
     // X-layout g_wc2: sum over the 32 edge lanes of each half
 #pragma unroll
@@ -966,7 +993,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
         g_bc1[b] += __shfl_xor(g_bc1[b], 32, 64);
         g_wa[b] += __shfl_xor(g_wa[b], 32, 64);
     }
-    for (int turn = 0; turn < kWaves; ++turn) {
+    for (int turn = 0; turn < NW; ++turn) {
         if (wv == turn) {
 #pragma unroll
             for (int bo = 0; bo < HB; ++bo)
@@ -998,7 +1025,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
         __syncthreads();
     }
     float* dst = io.slabs + (size_t)blockIdx.x * L.total;
-    for (int i = threadIdx.x; i < L.total; i += kThreads) dst[i] = slab[i];
+    for (int i = threadIdx.x; i < L.total; i += NT) dst[i] = slab[i];
 }
 
 template <typename K>
@@ -1045,7 +1072,7 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     PvsProfScope prof(s, PVS_PROF_EDGE_FWD);
     const int HB = H / 32;
     const char* bf = getenv("PVS_EGNN_BF16X3");
-    const bool bf16x3 = bf && bf[0] == '1' && H == 32;
+    const bool bf16x3 = !(bf && bf[0] == '0') && H == 32;   // default for H = 32 (PVS_EGNN_BF16X3=0: fp32 MFMA)
     const size_t words = (bf16x3 ? (size_t)2 * 6 * 64 * 4 : (size_t)2 * H * H) +
                          (5 + PVS_MAX_EDGE_ATTR) * H +
                          (size_t)kWaves * (kTile * (H + 4) + kTile * 4 + kTile);
@@ -1075,32 +1102,49 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     PVS_REQUIRE(H == 32 || H == 64, "MFMA edge backward is built for H = 32, 64 (got %d)", H);
     *n_slabs = 0;
     if (e_hi <= e_lo) return 0;
+    const char* bf = getenv("PVS_EGNN_BF16X3");
+    const bool bf16x3 = !(bf && bf[0] == '0') && H == 32;
+    const int nt = bf16x3 ? 512 : kThreads, nw = nt / 64;
+    // resident blocks per launch: H=32 fp32: 2 x 256 threads per CU; bf16x3: 1 x 512; H=64: 1 x 256
     int blocks, n_chunks;
-    pick_grid(e_hi - e_lo, &blocks, &n_chunks, pvs_edge_bwd_mfma_max_blocks(H));   // resident blocks
+    {
+        const int E = e_hi - e_lo;
+        const int max_blocks = bf16x3 ? 256 : pvs_edge_bwd_mfma_max_blocks(H);
+        long long b = ((long long)E + (long long)nw * 2048 - 1) / ((long long)nw * 2048);
+        if (b < 1) b = 1;
+        if (b > max_blocks) b = max_blocks;
+        const long long waves = b * nw;
+        long long per_wave = ((long long)E + waves * 4096 - 1) / (waves * 4096);
+        if (per_wave < 1) per_wave = 1;
+        blocks = (int)b;
+        n_chunks = (int)(waves * per_wave);
+    }
     *n_slabs = blocks;
     PvsProfScope prof(s, PVS_PROF_EDGE_BWD);
     const PvsSlabLayout L = pvs_slab_layout(H);
-    size_t words = (size_t)2 * H * (H + 1) + (5 + PVS_MAX_EDGE_ATTR) * H +
-                   (size_t)kWaves * (3 * kTile * (H + 4) + kTile * 4 + 2 * kTile);
+    size_t words = (bf16x3 ? (size_t)4 * 6 * 64 * 4 : (size_t)2 * H * (H + 1)) +
+                   (5 + PVS_MAX_EDGE_ATTR) * H +
+                   (size_t)nw * (3 * kTile * (H + 4) + kTile * 4 + 2 * kTile);
     if (words < (size_t)L.total) words = L.total;
     const size_t lds = words * sizeof(float);
     const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
     const bool eatt = flags & PVS_EDGE_ATTENTION;
-#define PVS_BWD_LAUNCH(HBV, ER, EA)                                                               \
+#define PVS_BWD_LAUNCH(HBV, ER, EA, BF)                                                            \
     do {                                                                                          \
-        if (set_lds(k_edge_bwd_mfma<HBV, ER, EA>, lds)) return -2;                                \
-        k_edge_bwd_mfma<HBV, ER, EA><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, \
-                                                                   e_lo, e_hi);                  \
+        if (set_lds(k_edge_bwd_mfma<HBV, ER, EA, BF>, lds)) return -2;                            \
+        k_edge_bwd_mfma<HBV, ER, EA, BF><<<blocks, nt, lds, s>>>(g, w, flags, att_act, io, n_chunks, \
+                                                                 e_lo, e_hi);                    \
     } while (0)
-#define PVS_BWD_PICK(HBV)                               \
-    do {                                                \
-        if (eres && eatt) PVS_BWD_LAUNCH(HBV, true, true);   \
-        else if (eres) PVS_BWD_LAUNCH(HBV, true, false);     \
-        else if (eatt) PVS_BWD_LAUNCH(HBV, false, true);     \
-        else PVS_BWD_LAUNCH(HBV, false, false);              \
+#define PVS_BWD_PICK(HBV, BF)                                \
+    do {                                                     \
+        if (eres && eatt) PVS_BWD_LAUNCH(HBV, true, true, BF);    \
+        else if (eres) PVS_BWD_LAUNCH(HBV, true, false, BF);      \
+        else if (eatt) PVS_BWD_LAUNCH(HBV, false, true, BF);      \
+        else PVS_BWD_LAUNCH(HBV, false, false, BF);               \
     } while (0)
-    if (H == 32) PVS_BWD_PICK(1);
-    else PVS_BWD_PICK(2);
+    if (H == 32 && bf16x3) PVS_BWD_PICK(1, true);
+    else if (H == 32) PVS_BWD_PICK(1, false);
+    else PVS_BWD_PICK(2, false);
 #undef PVS_BWD_PICK
 #undef PVS_BWD_LAUNCH
     PVS_CHECK_LAUNCH();
