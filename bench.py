@@ -26,7 +26,11 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
+import faulthandler  # noqa: E402
+
 import numpy as np  # noqa: E402
+
+faulthandler.enable()
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -110,6 +114,8 @@ def main():
     ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3'])
     ap.add_argument('--batch', type=int, default=32, help='graphs per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', type=int, default=int(os.environ.get('PVS_BENCH_GRAPH', '0')),
+                    help='1: capture the whole training step in a hipGraph and time replays')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -142,6 +148,9 @@ def main():
     torch.manual_seed(0)
     model = SartorrasEGNN(Path('/tmp/pvs_bench'), 2e-3, 1e-4, silent=True, **cfg['model']).train()
     params = list(model.parameters())
+    use_graph = bool(args.graph) and world == 1
+    if use_graph:   # same Adam, step counter kept on the device so the step can be captured
+        model.optimiser = torch.optim.Adam(params, lr=2e-3, weight_decay=1e-4, capturable=True)
     reducer = GradAllReducer(params) if world > 1 else None
 
     def step():
@@ -155,21 +164,46 @@ def main():
         model.optimiser.step()
         return loss
 
-    for _ in range(args.warmup):
-        step()
-    lib.pvs_profile_reset()
-    lib.pvs_profile_enable(1)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    lib.pvs_profile_enable(0)
+    # Graph mode keeps every step (warm-up, capture, replays, the profiled eager steps) on ONE
+    # non-default stream: autograd's AccumulateGrad nodes remember the stream of their first
+    # backward, and a capture on a different stream than earlier eager steps faults in
+    # hipStreamEndCapture (ROCm 7.2 / torch 2.10).
+    work_stream = torch.cuda.Stream(dev) if use_graph else torch.cuda.current_stream(dev)
+    with torch.cuda.stream(work_stream):
+        for _ in range(max(args.warmup, 2 if use_graph else 0)):
+            step()
+        eager_step = step
+        if use_graph:
+            torch.cuda.synchronize(dev)
+            hip_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(hip_graph, stream=work_stream):
+                static_loss = eager_step()
+
+            def step():   # noqa: F811  (one graph launch = one full training step)
+                hip_graph.replay()
+                return static_loss
+            step()
+        lib.pvs_profile_reset()
+        lib.pvs_profile_enable(0 if use_graph else 1)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        lib.pvs_profile_enable(0)
+        prof_steps = args.steps
+        if use_graph:   # kernel timings of the same step, eager, after the timed replays
+            lib.pvs_profile_enable(1)
+            prof_steps = 3
+            for _ in range(prof_steps):
+                eager_step()
+            torch.cuda.synchronize(dev)
+            lib.pvs_profile_enable(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -217,7 +251,8 @@ def main():
                                    f'N={n_nodes} nodes E={n_edges} edges per rank, CLI-default '
                                    f'layer flags, Adam lr 2e-3 wd 1e-4 clip 1.0, random init',
                        'graphs_per_gpu': args.batch, 'global_batch': world * args.batch,
-                       'parallelism': f'dp{world}', 'final_loss': round(final_loss, 6)},
+                       'parallelism': f'dp{world}', 'final_loss': round(final_loss, 6),
+                       'launch': 'hipGraph replay of the whole step' if use_graph else 'eager'},
             'roofline': {
                 'bound': 'hbm', 'kernel': 'k_edge_bwd_mfma<1> (edge backward, one launch per layer)',
                 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -227,10 +262,10 @@ def main():
                 'step_hbm_frac': round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 'step_fp32_frac': round(step_flops / (ms_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5),
                 'kernel_ms_per_step': {
-                    'edge_fwd': round(fwd_ms / args.steps, 3),
-                    'edge_bwd': round(bwd_ms / args.steps, 3),
-                    'col_gather': round(col_ms / args.steps, 3),
-                    'graph_prepare': round(prep_ms / args.steps, 3)}},
+                    'edge_fwd': round(fwd_ms / prof_steps, 3),
+                    'edge_bwd': round(bwd_ms / prof_steps, 3),
+                    'col_gather': round(col_ms / prof_steps, 3),
+                    'graph_prepare': round(prep_ms / prof_steps, 3)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)

@@ -98,8 +98,8 @@ class PreparedGraph:
     def poll_status(self):
         """Asynchronous validation: the first call queues a D2H copy of the status word, later
         calls (or check_status) raise once it has landed. Never blocks the stream."""
-        if self._status_checked:
-            return
+        if self._status_checked or torch.cuda.is_current_stream_capturing():
+            return   # (no host-visible validation inside a captured step)
         if self._status_event is None:
             self._status_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
             self._status_host.copy_(self.t['status'], non_blocking=True)
