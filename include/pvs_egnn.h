@@ -195,6 +195,21 @@ int pvs_mean_pool_bwd(const float* g_pooled, const int32_t* graph_ptr, float* g_
                       int32_t n_graphs, int32_t n_nodes, int32_t width, pvs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * unsorted_segment_sum / unsorted_segment_mean (egnn_satorras.py:332-337 / :340-347) as standalone
+ * operators (inside the layers these sums are fused into the edge kernels).
+ *   data [E,C] fp32, ids [E] int64 in [0,N) -> out [N,C]; mean != 0 divides by max(count, 1).
+ *   ptr_out [N+1] int32 (caller-owned) receives the segment offsets, needed by the backward
+ *   g_data[e,:] = g_out[ids[e],:] (/ max(count,1)). status: device int32, bit0 = id out of range.
+ */
+size_t pvs_segment_workspace_bytes(int32_t n_rows, int32_t n_segments);
+int pvs_segment_reduce_fwd(const float* data, const int64_t* ids, int32_t n_rows, int32_t width,
+                           int32_t n_segments, int32_t mean, float* out, int32_t* ptr_out,
+                           int32_t* status, void* workspace, size_t workspace_bytes,
+                           pvs_stream_t stream);
+int pvs_segment_reduce_bwd(const float* g_out, const int64_t* ids, const int32_t* ptr, int32_t n_rows,
+                           int32_t width, int32_t mean, float* g_data, pvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement hook (no reference counterpart): when enabled, the library brackets its dominant
  * kernels ("edge_fwd", "edge_bwd", "col_gather", "graph_prepare") with HIP events on the launch
  * stream; pvs_profile_read waits for those events and returns the summed kernel time. Used by

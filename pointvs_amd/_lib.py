@@ -64,6 +64,12 @@ _PROTOTYPES = {
                                                                       C.c_void_p]),
     'pvs_mean_pool_fwd': (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 2 + [C.c_void_p]),
     'pvs_mean_pool_bwd': (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p]),
+    'pvs_segment_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32]),
+    'pvs_segment_reduce_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_size_t, C.c_void_p]),
+    'pvs_segment_reduce_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_void_p, C.c_void_p]),
     'pvs_profile_enable': (C.c_int, [C.c_int]),
     'pvs_profile_reset': (C.c_int, []),
     'pvs_profile_read': (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

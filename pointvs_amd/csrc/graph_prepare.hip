@@ -179,3 +179,104 @@ extern "C" int pvs_rows_to_sorted_order(const float* src, float* dst, const int3
     PVS_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// unsorted_segment_sum / unsorted_segment_mean (egnn_satorras.py:332-347) as standalone operators:
+// stable sort of the segment ids, then one wave per segment sums its rows in that fixed order
+// (deterministic, no atomics). The layers do not call these (their sums are fused into the edge
+// kernels); they exist for the module surface.
+namespace {
+
+__global__ void k_seg_extract(const int64_t* __restrict__ ids, int E, int N, int32_t* key, int32_t* iota,
+                              int32_t* status) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int64_t v = ids[e];
+    if (v < 0 || v >= N) { atomicOr(status, 1); v = 0; }
+    key[e] = (int32_t)v;
+    iota[e] = e;
+}
+
+__global__ void __launch_bounds__(256)
+k_segment_reduce(const float* __restrict__ data, const int32_t* __restrict__ perm,
+                 const int32_t* __restrict__ ptr, int N, int C, int mean, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (int n = wave; n < N; n += n_waves) {
+        const int p0 = ptr[n], p1 = ptr[n + 1];
+        const float scale = mean ? 1.0f / (float)(p1 - p0 > 1 ? p1 - p0 : 1) : 1.0f;
+        for (int c = lane; c < C; c += 64) {
+            float acc = 0.f;
+            for (int p = p0; p < p1; ++p) acc += data[(size_t)perm[p] * C + c];
+            out[(size_t)n * C + c] = acc * scale;
+        }
+    }
+}
+
+__global__ void k_segment_expand(const float* __restrict__ g_out, const int64_t* __restrict__ ids,
+                                 const int32_t* __restrict__ ptr, long long total, int C, int mean,
+                                 float* __restrict__ g_data) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i / C), c = (int)(i % C);
+        const int n = (int)ids[e];
+        float s = 1.f;
+        if (mean) { const int cnt = ptr[n + 1] - ptr[n]; s = 1.0f / (float)(cnt > 1 ? cnt : 1); }
+        g_data[i] = g_out[(size_t)n * C + c] * s;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t pvs_segment_workspace_bytes(int32_t n_rows, int32_t n_segments) {
+    const size_t e = (size_t)(n_rows > 0 ? n_rows : 1);
+    const size_t sort_bytes = sort_temp_bytes((int)e, key_bits(n_segments > 1 ? n_segments : 2));
+    return 4 * pvs_align_up(e * sizeof(int32_t), 256) + pvs_align_up((size_t)(n_segments + 1) * 4, 256) +
+           pvs_align_up(sort_bytes, 256) + 1024;
+}
+
+// forward: out[n,:] = sum (or mean) of data[e,:] with ids[e] == n.  ptr_out (int32 [N+1], caller
+// owned) receives the segment offsets and is what pvs_segment_reduce_bwd needs.
+extern "C" int pvs_segment_reduce_fwd(const float* data, const int64_t* ids, int32_t E, int32_t C,
+                                      int32_t N, int32_t mean, float* out, int32_t* ptr_out,
+                                      int32_t* status, void* workspace, size_t workspace_bytes,
+                                      pvs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PVS_REQUIRE(N > 0 && E >= 0 && C > 0, "pvs_segment_reduce_fwd: bad sizes");
+    PVS_REQUIRE(workspace_bytes >= pvs_segment_workspace_bytes(E, N), "segment workspace too small");
+    PvsArena a(workspace, workspace_bytes);
+    const size_t e = (size_t)(E > 0 ? E : 1);
+    int32_t* key = a.take<int32_t>(e);
+    int32_t* iota = a.take<int32_t>(e);
+    int32_t* key_s = a.take<int32_t>(e);
+    int32_t* perm = a.take<int32_t>(e);
+    const int bits = key_bits(N > 1 ? N : 2);
+    size_t sort_bytes = sort_temp_bytes((int)e, bits);
+    void* sort_tmp = a.take<char>(sort_bytes);
+    PVS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), stream));
+    if (E > 0) {
+        k_seg_extract<<<(E + 255) / 256, 256, 0, stream>>>(ids, E, N, key, iota, status);
+        PVS_CHECK_LAUNCH();
+        PVS_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, key, key_s, iota, perm, E,
+                                                         0, bits, stream));
+    }
+    k_lower_bounds<<<(N + 1 + 255) / 256, 256, 0, stream>>>(key_s, E, N, ptr_out, nullptr);
+    PVS_CHECK_LAUNCH();
+    int blocks = (N + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    k_segment_reduce<<<blocks, 256, 0, stream>>>(data, perm, ptr_out, N, C, mean, out);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pvs_segment_reduce_bwd(const float* g_out, const int64_t* ids, const int32_t* ptr,
+                                      int32_t E, int32_t C, int32_t mean, float* g_data,
+                                      pvs_stream_t stream) {
+    if (E <= 0) return 0;
+    const long long total = (long long)E * C;
+    int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    k_segment_expand<<<blocks, 256, 0, (hipStream_t)stream>>>(g_out, ids, ptr, total, C, mean, g_data);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}

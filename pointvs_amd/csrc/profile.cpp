@@ -16,14 +16,14 @@ PvsProfScope::PvsProfScope(hipStream_t stream, int id) : s(stream), rec(nullptr)
     if (!g_on) return;
     Rec* r = new Rec{id, nullptr, nullptr};
     if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) { delete r; return; }
-    hipEventRecord(r->a, s);
+    (void)hipEventRecord(r->a, s);
     rec = r;
 }
 
 PvsProfScope::~PvsProfScope() {
     if (!rec) return;
     Rec* r = (Rec*)rec;
-    hipEventRecord(r->b, s);
+    (void)hipEventRecord(r->b, s);
     std::lock_guard<std::mutex> lk(g_mu);
     g_recs.push_back(r);
 }
@@ -36,7 +36,7 @@ extern "C" int pvs_profile_enable(int on) {
 
 extern "C" int pvs_profile_reset(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (Rec* r : g_recs) { hipEventDestroy(r->a); hipEventDestroy(r->b); delete r; }
+    for (Rec* r : g_recs) { (void)hipEventDestroy(r->a); (void)hipEventDestroy(r->b); delete r; }
     g_recs.clear();
     return 0;
 }

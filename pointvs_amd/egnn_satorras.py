@@ -163,12 +163,52 @@ class EGNNLayer(nn.Module):
             None if natt is None else natt.weight, None if natt is None else natt.bias,
             getattr(self, 'edge_gate_parameter', None), getattr(self, 'node_gate_parameter', None))
 
+    _KERNEL_WIDTHS = (16, 32, 64)
+
+    def _padded_call(self, pg, h, coord, m_prev_sorted, need_m):
+        """Hidden sizes the kernels are not built for run zero-padded to the next built width.
+        Exact: a zero channel stays zero through SiLU, the products, GraphNorm (weight 0, bias 0)
+        and the gates, so the extra channels contribute nothing; padding/slicing are autograd ops."""
+        import torch.nn.functional as F
+        hid = self.hidden_nf
+        wide = next(w for w in self._KERNEL_WIDTHS if w >= hid)
+        pad = wide - hid
+        a = self.edges_in_d
+
+        def rows(t):   # pad the output-channel dimension
+            return None if t is None else F.pad(t, (0, 0, 0, pad)) if t.dim() == 2 else F.pad(t, (0, pad))
+
+        def cols(t):   # pad the input-channel dimension
+            return None if t is None else F.pad(t, (0, pad))
+
+        p = list(self._params())
+        w1 = p[0]
+        blocks = [w1[:, :hid]] + ([] if self.permutation_invariance else [w1[:, hid:2 * hid]])
+        tail = w1[:, (hid if self.permutation_invariance else 2 * hid):]
+        w1p = torch.cat([cols(b) for b in blocks] + [tail], dim=1)
+        wn1 = p[9]
+        wn1p = torch.cat([cols(wn1[:, :hid]), cols(wn1[:, hid:])], dim=1)
+        padded = [rows(w1p), rows(p[1]), rows(cols(p[2])), rows(p[3]), rows(cols(p[4])), rows(p[5]),
+                  cols(p[6]), cols(p[7]), p[8], rows(wn1p), rows(p[10]), rows(cols(p[11])), rows(p[12]),
+                  rows(p[13]), rows(p[14]), rows(p[15]), cols(p[16]), p[17], p[18], p[19]]
+        desc = (wide, a) + self._desc()[2:]
+        mp = None if m_prev_sorted is None else F.pad(m_prev_sorted, (0, pad))
+        h_out, x_out, m_sorted, att, natt = PF.egnn_layer(
+            F.pad(h, (0, pad)), coord, mp, pg, desc, need_m, tuple(padded))
+        return (h_out[:, :hid], x_out, None if m_sorted is None else m_sorted[:, :hid], att, natt)
+
     def forward_prepared(self, pg, h, coord, m_prev_sorted=None, need_m=False):
         """Layer on a PreparedGraph; edge tensors stay in CSR-sorted order (internal fast path)."""
         if not self.edge_residual:
             m_prev_sorted = None
-        h_out, x_out, m_sorted, att, natt = PF.egnn_layer(
-            h, coord, m_prev_sorted, pg, self._desc(), need_m, self._params())
+        if self.hidden_nf > max(self._KERNEL_WIDTHS):
+            raise NotImplementedError(f'hidden size {self.hidden_nf} > {max(self._KERNEL_WIDTHS)} is '
+                                      f'not built in libpvs_egnn.so')
+        if self.hidden_nf not in self._KERNEL_WIDTHS:
+            h_out, x_out, m_sorted, att, natt = self._padded_call(pg, h, coord, m_prev_sorted, need_m)
+        else:
+            h_out, x_out, m_sorted, att, natt = PF.egnn_layer(
+                h, coord, m_prev_sorted, pg, self._desc(), need_m, self._params())
         self._att_src = None if att is None else (
             lambda: PF.rows_to_input_order(att.detach()[:pg.n_edges].reshape(-1, 1), pg))
         self._natt_src = None if natt is None else (lambda: natt.detach().reshape(-1, 1))
@@ -294,11 +334,11 @@ class SartorrasEGNN(PNNGeometricBase):
 
 
 def unsorted_segment_sum(data, segment_ids, num_segments):
-    """egnn_satorras.py:332-337. Kept for the module surface; inside the layers the segment sums
-    are fused into the edge kernels."""
-    raise NotImplementedError('unsorted_segment_sum is fused into pvs_egnn_layer_fwd')
+    """egnn_satorras.py:332-337: rows of `data` summed per segment id (HIP, deterministic order).
+    Inside the layers this sum is fused into the edge kernels."""
+    return PF.segment_reduce(data, segment_ids, num_segments, mean=False)
 
 
 def unsorted_segment_mean(data, segment_ids, num_segments):
-    """egnn_satorras.py:340-347 (see unsorted_segment_sum)."""
-    raise NotImplementedError('unsorted_segment_mean is fused into pvs_egnn_layer_fwd')
+    """egnn_satorras.py:340-347: per-segment sum divided by max(count, 1)."""
+    return PF.segment_reduce(data, segment_ids, num_segments, mean=True)

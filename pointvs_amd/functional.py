@@ -220,3 +220,43 @@ class _MeanPoolFn(torch.autograd.Function):
 
 def mean_pool(h, graph_ptr):
     return _MeanPoolFn.apply(h, graph_ptr)
+
+
+class _SegmentReduceFn(torch.autograd.Function):
+    """unsorted_segment_sum / unsorted_segment_mean (egnn_satorras.py:332-347)."""
+
+    @staticmethod
+    def forward(ctx, data, segment_ids, num_segments, mean):
+        data = _f32c(data)
+        _lib.require_hip(data, segment_ids)
+        lib = _lib.lib()
+        ids = segment_ids.long().contiguous()
+        e, c = data.shape
+        dev = data.device
+        out = torch.empty((num_segments, c), dtype=torch.float32, device=dev)
+        ptr = torch.empty(num_segments + 1, dtype=torch.int32, device=dev)
+        status = torch.empty(1, dtype=torch.int32, device=dev)
+        ws_bytes = lib.pvs_segment_workspace_bytes(e, num_segments)
+        ws = _ws(ws_bytes, dev)
+        _lib.check(lib.pvs_segment_reduce_fwd(
+            _lib.ptr(data), _lib.ptr(ids), e, c, num_segments, 1 if mean else 0, _lib.ptr(out),
+            _lib.ptr(ptr), _lib.ptr(status), _lib.ptr(ws), ws_bytes, _stream(dev)),
+            'pvs_segment_reduce_fwd')
+        ctx.save_for_backward(ids, ptr)
+        ctx.mean, ctx.shape = mean, (e, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        ids, ptr = ctx.saved_tensors
+        g_out = _f32c(g_out)
+        e, c = ctx.shape
+        g_data = torch.empty((e, c), dtype=torch.float32, device=g_out.device)
+        _lib.check(_lib.lib().pvs_segment_reduce_bwd(
+            _lib.ptr(g_out), _lib.ptr(ids), _lib.ptr(ptr), e, c, 1 if ctx.mean else 0,
+            _lib.ptr(g_data), _stream(g_out.device)), 'pvs_segment_reduce_bwd')
+        return g_data, None, None, None
+
+
+def segment_reduce(data, segment_ids, num_segments, mean=False):
+    return _SegmentReduceFn.apply(data, segment_ids, int(num_segments), bool(mean))

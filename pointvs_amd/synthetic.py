@@ -39,7 +39,7 @@ def synthetic_graph(seed, n_nodes=2000, n_lig=30, edge_radius=10.0, density=0.05
     return Data(
         x=torch.from_numpy(feats), pos=torch.from_numpy(pts),
         edge_index=torch.from_numpy(np.vstack([e_rows, e_cols]).astype(np.int64)),
-        edge_attr=torch.nn.functional.one_hot(torch.from_numpy(e_type), 3),
+        edge_attr=torch.from_numpy(np.eye(3, dtype=np.int64)[e_type]),   # int64 one-hot(3)
         y=torch.tensor(seed % 2), lig_fname=f'lig_{seed}', rec_fname=f'rec_{seed}')
 
 

@@ -209,9 +209,45 @@ def test_invalid_inputs_raise():
     bad[1] = torch.tensor([1, 1, 0])
     with pytest.raises(ValueError):
         prepare_graph(torch.tensor([[0, 1, 2], [1, 2, 0]], device='cuda'), bad, 3).check_status()
-    with pytest.raises(RuntimeError, match='hidden size'):
-        model, _ = make_model(k=24)
+    with pytest.raises(NotImplementedError, match='hidden size'):
+        model, _ = make_model(k=96)
         model(random_graph(10, 20, 1).to('cuda'))
+
+
+@pytest.mark.parametrize('k', [8, 24, 40])
+def test_hidden_sizes_between_built_widths_are_zero_padded(k):
+    model, kw = make_model(seed=8, k=k, edge_attention=True, node_attention=True, residual=True,
+                           graphnorm=True, normalize=True, tanh=True)
+    g = random_graph(120, 1500, seed=3)
+    y, grads = gpu_run(model, g)
+    y_ref, _, g_ref = oracle_run(model, kw, g, dtype=torch.float64)
+    assert rel_err(y, y_ref.numpy()) < TOL
+    for pname, gr in grads.items():
+        if gr is None:
+            assert g_ref[pname] is None, pname
+        else:
+            assert gr.shape == tuple(g_ref[pname].shape)
+            assert rel_err(gr, g_ref[pname].numpy()) < TOL, pname
+
+
+def test_unsorted_segment_sum_and_mean():
+    """Module-level functions of egnn_satorras.py:332-347 as HIP operators, forward and backward."""
+    from oracle import egnn_oracle as orc
+    from pointvs_amd.egnn_satorras import unsorted_segment_mean, unsorted_segment_sum
+    rng = np.random.default_rng(0)
+    data = torch.from_numpy(rng.normal(size=(5000, 7)).astype(np.float32))
+    ids = torch.from_numpy(rng.integers(0, 300, 5000))
+    ids[:50] = 7          # a long segment; some segments stay empty
+    for fn, ref in ((unsorted_segment_sum, orc.segment_sum), (unsorted_segment_mean, orc.segment_mean)):
+        d_gpu = data.cuda().requires_grad_(True)
+        out = fn(d_gpu, ids.cuda(), 320)
+        d_ref = data.double().requires_grad_(True)
+        out_ref = ref(d_ref, ids, 320)
+        assert rel_err(out.detach().cpu().numpy(), out_ref.detach().numpy()) < 1e-6
+        w = torch.from_numpy(rng.normal(size=(320, 7)).astype(np.float32))
+        (out * w.cuda()).sum().backward()
+        (out_ref * w.double()).sum().backward()
+        assert rel_err(d_gpu.grad.cpu().numpy(), d_ref.grad.numpy()) < 1e-6
 
 
 def test_hipgraph_captured_step_matches_eager():
