@@ -153,8 +153,16 @@ def main():
         model.optimiser = torch.optim.Adam(params, lr=2e-3, weight_decay=1e-4, capturable=True)
     reducer = GradAllReducer(params) if world > 1 else None
 
+    # measured on MI355X: no gain (8.9 ms with and without; the sorts contend with the edge
+    # kernels), so off by default
+    prefetch = int(os.environ.get('PVS_BENCH_PREFETCH', '0')) and not use_graph
+    segs = (batch.graph_node_counts, batch.graph_edge_counts)
+
     def step():
         y_pred = model(batch).reshape(-1)
+        if prefetch:   # the next batch's CSR/CSC build (here: the same tensors) runs on a side
+            # stream under this batch's backward, as a data loader's look-ahead would arrange it
+            pgraph.prefetch_graph(batch.edge_index, batch.edge_attr, n_nodes, segs)
         loss = model.get_loss(y_true, y_pred)
         model.optimiser.zero_grad()
         loss.backward()

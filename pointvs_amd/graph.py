@@ -170,6 +170,45 @@ def prepare_graph(edge_index, edge_attr, n_nodes, segments=None):
     return PreparedGraph(n_nodes, n_edges, n_attr, t, segments)
 
 
+_PREFETCH = {}
+_PREFETCH_STREAM = {}
+
+
+def _graph_key(edge_index, edge_attr, n_nodes):
+    return (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
+            None if edge_attr is None else (edge_attr.data_ptr(), edge_attr._version), n_nodes)
+
+
+def prefetch_graph(edge_index, edge_attr, n_nodes, segments=None):
+    """Start `prepare_graph` for an upcoming batch on a side stream (e.g. while the current batch
+    is in its backward pass: the sorts are memory/latency-bound, the edge kernels ALU-bound). The
+    next `prepared_for` call with the same tensors picks the result up and orders the consumer
+    stream behind it. One outstanding prefetch per device."""
+    dev = edge_index.device
+    side = _PREFETCH_STREAM.get(dev)
+    if side is None:
+        side = _PREFETCH_STREAM[dev] = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))   # inputs may have been produced just now
+    with torch.cuda.stream(side):
+        pg = prepare_graph(edge_index, edge_attr, n_nodes, segments)
+        done = torch.cuda.Event()
+        done.record(side)
+    _PREFETCH[dev] = (_graph_key(edge_index, edge_attr, n_nodes), pg, done, edge_index, edge_attr)
+    return pg
+
+
+def _take_prefetched(edge_index, edge_attr, n_nodes):
+    hit = _PREFETCH.get(edge_index.device)
+    if hit is None or hit[0] != _graph_key(edge_index, edge_attr, n_nodes):
+        return None
+    del _PREFETCH[edge_index.device]
+    _, pg, done, _, _ = hit
+    torch.cuda.current_stream(edge_index.device).wait_event(done)
+    for t in pg.t.values():    # the side stream allocated these: tell the allocator who uses them now
+        t.record_stream(torch.cuda.current_stream(edge_index.device))
+    return pg
+
+
 _CACHE = collections.OrderedDict()
 _CACHE_SIZE = 4
 CACHE_ENABLED = True   # bench.py turns this off: a training step prepares every batch afresh
@@ -177,6 +216,9 @@ CACHE_ENABLED = True   # bench.py turns this off: a training step prepares every
 
 def prepared_for(edge_index, edge_attr, n_nodes, segments=None):
     """Cached `prepare_graph`: the L layers of a forward are called with the same edge tensors."""
+    pre = _take_prefetched(edge_index, edge_attr, n_nodes)
+    if pre is not None:
+        return pre
     if not CACHE_ENABLED:
         return prepare_graph(edge_index, edge_attr, n_nodes, segments)
     key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
