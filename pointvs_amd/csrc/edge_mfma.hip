@@ -1028,6 +1028,490 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     for (int i = threadIdx.x; i < L.total; i += NT) dst[i] = slab[i];
 }
 
+
+// ====================================================================================================
+// H = 32*HB, HB >= 2: a TEAM of HB waves shares one 32-edge tile. Wave cb owns channel block cb: all
+// elementwise work, its 32 output channels of every product and row block cb of the weight gradients
+// (the register footprint of the H = 32 kernel instead of HB^2 accumulator blocks per wave). The
+// other blocks of a product's input are read back in X layout from the edge-major LDS tiles the
+// weight-gradient products need anyway; per-edge scalars (dots over all channels) are summed through
+// a small LDS array. Teams of a workgroup run in lockstep (uniform trip count) because the only
+// barrier is the workgroup barrier.
+template <int HB>
+__device__ __forceinline__ void xread_block(const float* __restrict__ T, int j, int hh, int bi,
+                                            float (&v)[16]) {
+    constexpr int TS = 32 * HB + 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 q = *reinterpret_cast<const float4*>(T + j * TS + 32 * bi + 8 * g + 4 * hh);
+        v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+    }
+}
+
+template <int HB>
+__device__ __forceinline__ void xwrite_block(float* __restrict__ T, int j, int hh, int cb,
+                                             const float (&v)[16]) {
+    constexpr int TS = 32 * HB + 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(T + j * TS + 32 * cb + 8 * g + 4 * hh) =
+            make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
+
+// acc (output block cb) += sum over input blocks bi of W(cb,bi) v_bi ; v_cb from registers, the
+// other blocks from the tile T. Wn natural padded [H][H+1]; TRANSPOSE: W^T.
+template <int HB, bool TRANSPOSE>
+__device__ __forceinline__ void chain_team(const float* __restrict__ Wn, int lane, int cb,
+                                           const float (&own)[16], const float* __restrict__ T,
+                                           f32x16& acc) {
+    constexpr int H = 32 * HB, LD = H + 1;
+    const int j = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int bi = 0; bi < HB; ++bi) {
+        float v[16];
+        if (bi == cb) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[t] = own[t];
+        } else {
+            xread_block<HB>(T, j, hh, bi, v);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int kc = 32 * bi + (t & 3) + 8 * (t >> 2) + 4 * hh;
+            const float a = TRANSPOSE ? Wn[kc * LD + 32 * cb + j] : Wn[(32 * cb + j) * LD + kc];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v[t], acc, 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ float dot16_tab(const float* __restrict__ tab, int hh, const float (&v)[16]) {
+    float s = 0.f;   // tab points at this wave's channel block
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 w4 = *reinterpret_cast<const float4*>(tab + 8 * g + 4 * hh);
+        s = fmaf(w4.x, v[4 * g], s); s = fmaf(w4.y, v[4 * g + 1], s);
+        s = fmaf(w4.z, v[4 * g + 2], s); s = fmaf(w4.w, v[4 * g + 3], s);
+    }
+    return s + __shfl_xor(s, 32, 64);
+}
+
+__device__ __forceinline__ void load16_tab(const float* __restrict__ tab, int hh, float (&out)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(tab + 8 * g + 4 * hh);
+        out[4 * g] = v.x; out[4 * g + 1] = v.y; out[4 * g + 2] = v.z; out[4 * g + 3] = v.w;
+    }
+}
+
+template <int HB, bool ERES, bool EATT>
+__global__ void __launch_bounds__(512, 2)
+k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks,
+                int e_lo, int e_hi) {
+    constexpr int H = 32 * HB, TS = H + 4, NT = 512, NW = NT / 64, TEAMS = NW / HB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* W2n = smem;
+    float* Wc1n = W2n + H * (H + 1);
+    float* b2t = Wc1n + H * (H + 1);
+    float* bc1t = b2t + H;
+    float* wc2t = bc1t + H;
+    float* wat = wc2t + H;
+    float* wrhot = wat + H;
+    float* attrt = wrhot + H;                              // [PVS_MAX_EDGE_ATTR][H]
+    int* lens = reinterpret_cast<int*>(attrt + PVS_MAX_EDGE_ATTR * H);   // [TEAMS] (+pad to 16)
+    float* team_base = reinterpret_cast<float*>(lens + 16);
+    // per team: T0 (a1), T1 (m, then g_z1), T2 (g_zc, then g_z2), tx[32][4], glb[32], rowbuf[32],
+    //           pdA[HB][32], pdB[HB][32]
+    constexpr int kTeamFloats = 3 * kTile * TS + kTile * 4 + 2 * kTile + 2 * HB * kTile;
+
+    const bool upd = (flags & PVS_UPDATE_COORDS) && io.gxagg != nullptr;
+
+    stage_weights_nat<HB>(W2n, w.w2);
+    if (upd) stage_weights_nat<HB>(Wc1n, w.wc1);
+    for (int c = threadIdx.x; c < H; c += NT) {
+        b2t[c] = w.b2[c];
+        bc1t[c] = upd ? w.bc1[c] : 0.f;
+        wc2t[c] = upd ? w.wc2[c] : 0.f;
+        wat[c] = EATT ? w.wa[c] : 0.f;
+        wrhot[c] = w.w1[c * w.ld1 + w.off_rho];
+        for (int t = 0; t < PVS_MAX_EDGE_ATTR; ++t)
+            attrt[t * H + c] = t < w.n_attr ? w.w1[c * w.ld1 + w.off_rho + 1 + t] : 0.f;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int team = wv / HB, cb = wv % HB;
+    const int co = 32 * cb;                       // first channel of this wave's block
+    float* T0 = team_base + team * kTeamFloats;
+    float* T1 = T0 + kTile * TS;
+    float* T2 = T1 + kTile * TS;
+    float* tx = T2 + kTile * TS;
+    float* glb = tx + kTile * 4;
+    int* rowbuf = reinterpret_cast<int*>(glb + kTile);
+    float* pdA = reinterpret_cast<float*>(rowbuf + kTile);
+    float* pdB = pdA + HB * kTile;
+    const float bac = EATT ? w.ba[0] : 0.f;
+    float gate_raw = 0.f, gate = 1.f;
+    if (ERES && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
+        gate_raw = w.edge_gate[0];
+        gate = (flags & PVS_GATED_RESIDUAL) ? fmaxf(gate_raw, 0.f) : gate_raw;
+    }
+    auto sum_pd = [&](const float* pd) {
+        float s = 0.f;
+#pragma unroll
+        for (int b = 0; b < HB; ++b) s += pd[b * kTile + j];
+        return s;
+    };
+
+    // kernel-lifetime accumulators: row block cb of the two weight gradients, own-channel vectors
+    f32x16 gW2[HB], gWc1[HB];
+#pragma unroll
+    for (int bi = 0; bi < HB; ++bi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { gW2[bi][r] = 0.f; gWc1[bi][r] = 0.f; }
+    float g_wc2x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g_wc2x[r] = 0.f;
+    float g_b2 = 0.f, g_bc1 = 0.f, g_wa = 0.f, g_ba = 0.f, g_gate = 0.f;
+
+    for (int cbase = blockIdx.x * TEAMS; cbase < n_chunks; cbase += gridDim.x * TEAMS) {
+        const int chunk = cbase + team;
+        const int e_begin = chunk < n_chunks ? chunk_begin(g, chunk, n_chunks, e_lo, e_hi) : e_hi;
+        const int e_end = chunk < n_chunks ? chunk_begin(g, chunk + 1, n_chunks, e_lo, e_hi) : e_hi;
+        __syncthreads();
+        if (lane == 0 && cb == 0) lens[team] = e_end - e_begin;
+        __syncthreads();
+        int max_len = 0;
+#pragma unroll
+        for (int t = 0; t < TEAMS; ++t) max_len = max(max_len, lens[t]);
+        const int n_iter = (max_len + kTile - 1) / kTile;
+
+        int cur_row = -1;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accx = acc;
+        const int quad = lane % 8, rsub = lane / 8;
+        auto flush = [&](int row_id) {
+            if (row_id >= 0) {
+                const float4 tot = sum_row_slots<1>(acc);
+                if (rsub == 0) *reinterpret_cast<float4*>(io.gPQ + (size_t)row_id * 2 * H + co + 4 * quad) = tot;
+                const float4 tx4 = sum_row_slots<1>(accx);
+                if (lane == 0 && cb == 0) {
+                    io.gx_row[3 * row_id] = tx4.x;
+                    io.gx_row[3 * row_id + 1] = tx4.y;
+                    io.gx_row[3 * row_id + 2] = tx4.z;
+                }
+            }
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            accx = acc;
+        };
+
+        for (int it = 0; it < n_iter; ++it) {
+            const int e0 = e_begin + it * kTile;
+            const int e = e0 + j;
+            const bool valid = e < e_end;
+            const float vm = valid ? 1.f : 0.f;
+            int ee = valid ? e : e_end - 1;
+            ee = min(max(ee, 0), g.n_edges - 1);
+            const int i = g.row[ee], jn = g.col[ee];
+            const int ty = w.n_attr ? (int)g.etype[ee] : 0;
+            const int prev_row = (ee == e_begin || ee == 0) ? -1 : g.row[ee - 1];
+            const unsigned bmask = (unsigned)__ballot(valid && hh == 0 && i != prev_row);
+            const float d0 = io.x[3 * i] - io.x[3 * jn], d1 = io.x[3 * i + 1] - io.x[3 * jn + 1];
+            const float d2 = io.x[3 * i + 2] - io.x[3 * jn + 2];
+            const float rho = d0 * d0 + d1 * d1 + d2 * d2;
+            const float* Pp = io.PQ + (size_t)i * 2 * H + co;
+            const float* Qp = io.PQ + (size_t)jn * 2 * H + H + co;
+
+            auto z1_own = [&](float (&z)[16]) {
+                float pp[16], qq[16], aa[16], rr[16];
+                load16_tab(Pp, hh, pp);
+                load16_tab(Qp, hh, qq);
+                load16_tab(attrt + ty * H + co, hh, aa);
+                load16_tab(wrhot + co, hh, rr);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = pp[r] + qq[r] + fmaf(rr[r], rho, aa[r]);
+            };
+
+            // ---- recompute: a1 (own block) -> T0 ----
+            float a1[16];
+            z1_own(a1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a1[r] = pvs_silu(a1[r]);
+            xwrite_block<HB>(T0, j, hh, cb, a1);
+            if (cb == 0 && hh == 0) rowbuf[j] = i;
+            __syncthreads();                                                     // (1) T0 complete
+            // ---- z2 = W2 a1 + b2 (own output block) ----
+            float dz2[16], m[16];
+            float m_new[ERES ? 16 : 1], mp[ERES ? 16 : 1];
+            {
+                f32x16 acc2;
+                float bias[16];
+                load16_tab(b2t + co, hh, bias);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[r] = bias[r];
+                chain_team<HB, false>(W2n, lane, cb, a1, T0, acc2);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float z2 = acc2[r];
+                    const float sg = pvs_sigmoid(z2);
+                    dz2[r] = pvs_silu_grad(z2, sg);
+                    m[r] = z2 * sg;
+                    if constexpr (ERES) m_new[r] = m[r];
+                }
+            }
+            if constexpr (ERES) {
+                load16_tab(io.m_prev + (size_t)ee * H + co, hh, mp);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (flags & PVS_REZERO) m[r] = mp[r] + gate * m_new[r];
+                    else if (flags & PVS_GATED_RESIDUAL) m[r] = gate * m_new[r] + (1.f - gate) * mp[r];
+                    else m[r] = m_new[r] + mp[r];
+                }
+            }
+            xwrite_block<HB>(T1, j, hh, cb, m);
+            // ---- gradient wrt m (own block): external + attention + coordinate branch ----
+            f32x16 gm;
+            {
+                float init[16];
+                if (io.g_m_out) load16_tab(io.g_m_out + (size_t)ee * H + co, hh, init);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gm[r] = io.g_m_out ? init[r] * vm : 0.f;
+            }
+            float gMi[16];
+            load16_tab(io.gM + (size_t)i * H + co, hh, gMi);
+            if constexpr (EATT) {
+                float pl = dot16_tab(wat + co, hh, m);
+                float pdot = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pdot = fmaf(m[r], gMi[r], pdot);
+                pdot += __shfl_xor(pdot, 32, 64);
+                if (hh == 0) { pdA[cb * kTile + j] = pl; pdB[cb * kTile + j] = pdot; }
+            }
+            __syncthreads();                                                     // (2) T1, pd complete
+            float g_l = 0.f, aval = 1.f;
+            if constexpr (EATT) {
+                const float logit = sum_pd(pdA) + bac;
+                const float dot = sum_pd(pdB);
+                aval = io.att[ee];
+                g_l = pvs_att_act_grad(att_act, logit, aval) * dot * vm;
+                if (hh == 0 && cb == 0) { g_ba += g_l; glb[j] = g_l; }
+                float wax[16];
+                load16_tab(wat + co, hh, wax);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gm[r] += (aval * vm) * gMi[r] + g_l * wax[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gm[r] += vm * gMi[r];
+            }
+            float s_coord = 0.f, nrm = 1.f, gT0 = 0.f, gT1 = 0.f, gT2 = 0.f;
+            if (upd) {
+                gT0 = io.gxagg[3 * i]; gT1 = io.gxagg[3 * i + 1]; gT2 = io.gxagg[3 * i + 2];
+                f32x16 accc;
+                float bias2[16];
+                load16_tab(bc1t + co, hh, bias2);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accc[r] = bias2[r];
+                chain_team<HB, false>(Wc1n, lane, cb, m, T1, accc);
+                float q[16], dq[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float zc = accc[r];
+                    const float sg = pvs_sigmoid(zc);
+                    q[r] = zc * sg;
+                    dq[r] = pvs_silu_grad(zc, sg);
+                }
+                const float ps = dot16_tab(wc2t + co, hh, q);
+                __syncthreads();                                                 // (3a) pdA reads of (2) done
+                if (hh == 0) pdA[cb * kTile + j] = ps;
+                __syncthreads();                                                 // (3) pdA complete
+                float s = sum_pd(pdA);
+                float dact = 1.f;
+                if (flags & PVS_TANH) { s = pvs_tanh(s); dact = 1.f - s * s; }
+                if (flags & PVS_NORMALIZE) nrm = 1.f / (sqrtf(rho) + 1e-8f);
+                s_coord = s;
+                const float g_s = (d0 * gT0 + d1 * gT1 + d2 * gT2) * nrm * dact * vm;
+                float wc2x[16], g_zc[16];
+                load16_tab(wc2t + co, hh, wc2x);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    g_zc[r] = g_s * wc2x[r] * dq[r];
+                    g_wc2x[r] = fmaf(g_s, q[r], g_wc2x[r]);
+                }
+                xwrite_block<HB>(T2, j, hh, cb, g_zc);
+                __syncthreads();                                                 // (4) T2 = g_zc complete
+                chain_team<HB, true>(Wc1n, lane, cb, g_zc, T2, gm);              // g_m += Wc1^T g_zc
+            } else if (EATT) {
+                __syncthreads();                                                 // glb visible
+            }
+            // ---- Wc1 weight gradient (row block cb) + g_bc1 + g_wa ----
+            if (upd || EATT) {
+#pragma unroll
+                for (int sI = 0; sI < 16; ++sI) {
+                    const int el = 2 * sI + hh;
+                    const float av = upd ? T2[el * TS + co + j] : 0.f;
+                    float bv[HB];
+#pragma unroll
+                    for (int bi = 0; bi < HB; ++bi) bv[bi] = T1[el * TS + 32 * bi + j];
+                    g_bc1 += av;
+                    if constexpr (EATT) g_wa = fmaf(glb[el], T1[el * TS + co + j], g_wa);
+                    if (upd) {
+#pragma unroll
+                        for (int bi = 0; bi < HB; ++bi)
+                            gWc1[bi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[bi], gWc1[bi], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- edge residual, g_z2 ----
+            float g_z2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float gmv = gm[r];
+                float gnew = gmv;
+                if constexpr (ERES) {
+                    if (flags & PVS_REZERO) {
+                        gnew = gate * gmv;
+                        g_gate = fmaf(gmv, m_new[r], g_gate);
+                        mp[r] = gmv;
+                    } else if (flags & PVS_GATED_RESIDUAL) {
+                        gnew = gate * gmv;
+                        if (gate_raw > 0.f) g_gate = fmaf(gmv, m_new[r] - mp[r], g_gate);
+                        mp[r] = (1.f - gate) * gmv;
+                    } else {
+                        mp[r] = gmv;
+                    }
+                }
+                g_z2[r] = gnew * dz2[r];
+            }
+            if constexpr (ERES) {
+                if (valid) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+                        *reinterpret_cast<float4*>(io.g_m_prev + (size_t)e * H + co + 8 * gq + 4 * hh) =
+                            make_float4(mp[4 * gq], mp[4 * gq + 1], mp[4 * gq + 2], mp[4 * gq + 3]);
+                }
+            }
+            __syncthreads();                                                     // (5) T2 / T1 reads done
+            xwrite_block<HB>(T2, j, hh, cb, g_z2);
+            __syncthreads();                                                     // (6) T2 = g_z2 complete
+            // ---- g_a1 = W2^T g_z2 (own block); g_z1 = g_a1 * SiLU'(z1) ----
+            f32x16 ga1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ga1[r] = 0.f;
+            chain_team<HB, true>(W2n, lane, cb, g_z2, T2, ga1);
+            float g_z1[16];
+            z1_own(g_z1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                g_z1[r] = ga1[r] * pvs_silu_grad(g_z1[r], pvs_sigmoid(g_z1[r]));
+            const float prho = dot16_tab(wrhot + co, hh, g_z1);
+            if (hh == 0) pdA[cb * kTile + j] = prho;
+            // ---- W2 weight gradient (row block cb) + g_b2 ----
+#pragma unroll
+            for (int sI = 0; sI < 16; ++sI) {
+                const int el = 2 * sI + hh;
+                const float av = T2[el * TS + co + j];
+                g_b2 += av;
+#pragma unroll
+                for (int bi = 0; bi < HB; ++bi)
+                    gW2[bi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, T0[el * TS + 32 * bi + j], gW2[bi], 0, 0, 0);
+            }
+            __syncthreads();                                                     // (7) pdA complete; T1 free
+            const float g_rho = sum_pd(pdA);
+            const float k1 = s_coord * nrm * vm;
+            const float gd0 = fmaf(k1, gT0, 2.f * d0 * g_rho);
+            const float gd1 = fmaf(k1, gT1, 2.f * d1 * g_rho);
+            const float gd2 = fmaf(k1, gT2, 2.f * d2 * g_rho);
+            if (hh == 0 && cb == 0) {
+                *reinterpret_cast<float4*>(tx + j * 4) = make_float4(gd0, gd1, gd2, 0.f);
+                if (valid)
+                    *reinterpret_cast<float4*>(io.gd + (size_t)e * 4) =
+                        make_float4(gd0, gd1, gd2, pvs_pack_rho_type(rho, ty));
+            }
+            xwrite_block<HB>(T1, j, hh, cb, g_z1);
+            __syncthreads();                                                     // (8) T1 = g_z1, tx complete
+            // own 128-byte half-rows of g_z1 to HBM + row-side sums of the own channel block
+            {
+                float4 v[4], dx[4];
+                int seg[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int rl = k * 8 + rsub;
+                    v[k] = *reinterpret_cast<const float4*>(T1 + rl * TS + co + 4 * quad);
+                    dx[k] = *reinterpret_cast<const float4*>(tx + rl * 4);
+                    if (e0 + rl < e_end)
+                        *reinterpret_cast<float4*>(io.gz1 + (size_t)(e0 + rl) * H + co + 4 * quad) = v[k];
+                    const unsigned upto = rl == 31 ? 0xffffffffu : ((2u << rl) - 1u);
+                    seg[k] = __popc(bmask & upto);
+                }
+                unsigned bm = bmask;
+                for (int sgi = 0;; ++sgi) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float mk = seg[k] == sgi ? 1.f : 0.f;
+                        acc.x = fmaf(mk, v[k].x, acc.x); acc.y = fmaf(mk, v[k].y, acc.y);
+                        acc.z = fmaf(mk, v[k].z, acc.z); acc.w = fmaf(mk, v[k].w, acc.w);
+                        accx.x = fmaf(mk, dx[k].x, accx.x); accx.y = fmaf(mk, dx[k].y, accx.y);
+                        accx.z = fmaf(mk, dx[k].z, accx.z);
+                    }
+                    if (bm == 0u) break;
+                    flush(cur_row);
+                    const int pos = __builtin_ctz(bm);
+                    bm &= bm - 1u;
+                    cur_row = __builtin_amdgcn_readfirstlane(rowbuf[pos]);
+                }
+            }
+            __syncthreads();                                                     // (9) tile buffers free
+        }
+        flush(cur_row);
+    }
+
+    // ---- block reduction into one slab, fixed order ----
+    const PvsSlabLayout L = pvs_slab_layout(H);
+    __syncthreads();
+    float* slab = smem;
+    for (int i = threadIdx.x; i < L.total; i += NT) slab[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = g_wc2x[r];
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o, 64);
+        g_wc2x[r] = v;
+    }
+    g_ba += __shfl_xor(g_ba, 32, 64);
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) g_ba += __shfl_xor(g_ba, o, 64);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) g_gate += __shfl_xor(g_gate, o, 64);
+    g_b2 += __shfl_xor(g_b2, 32, 64);
+    g_bc1 += __shfl_xor(g_bc1, 32, 64);
+    g_wa += __shfl_xor(g_wa, 32, 64);
+    for (int turn = 0; turn < NW; ++turn) {
+        if (wv == turn) {
+#pragma unroll
+            for (int bi = 0; bi < HB; ++bi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = co + xch(r, hh), k = 32 * bi + j;
+                    slab[L.w2 + c * H + k] += gW2[bi][r];
+                    slab[L.wc1 + c * H + k] += gWc1[bi][r];
+                }
+            if (hh == 0) {
+                slab[L.b2 + co + j] += g_b2;
+                slab[L.bc1 + co + j] += g_bc1;
+                slab[L.wa + co + j] += g_wa;
+            }
+            if (j == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[L.wc2 + co + xch(r, hh)] += g_wc2x[r];
+            }
+            if (lane == 0) { slab[L.ba] += g_ba; slab[L.gate] += g_gate; }
+        }
+        __syncthreads();
+    }
+    float* dst = io.slabs + (size_t)blockIdx.x * L.total;
+    for (int i = threadIdx.x; i < L.total; i += NT) dst[i] = slab[i];
+}
+
 template <typename K>
 int set_lds(K kernel, size_t lds) {
     if (lds > 48 * 1024)
@@ -1142,9 +1626,39 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
         else if (eatt) PVS_BWD_LAUNCH(HBV, false, true, BF);      \
         else PVS_BWD_LAUNCH(HBV, false, false, BF);               \
     } while (0)
+    const char* tm = getenv("PVS_EGNN_TEAM");
+    const bool use_team = H == 64 && !(tm && tm[0] == '0');
     if (H == 32 && bf16x3) PVS_BWD_PICK(1, true);
     else if (H == 32) PVS_BWD_PICK(1, false);
-    else PVS_BWD_PICK(2, false);
+    else if (!use_team) PVS_BWD_PICK(2, false);
+    else {
+        // team kernel: 512 threads = 4 teams of 2 waves, one block per CU
+        constexpr int kTeams = 4;
+        const int E = e_hi - e_lo;
+        long long b = ((long long)E + (long long)kTeams * 2048 - 1) / ((long long)kTeams * 2048);
+        if (b < 1) b = 1;
+        if (b > 256) b = 256;
+        const long long teams = b * kTeams;
+        long long per_team = ((long long)E + teams * 4096 - 1) / (teams * 4096);
+        if (per_team < 1) per_team = 1;
+        blocks = (int)b;
+        n_chunks = (int)(teams * per_team);
+        *n_slabs = blocks;
+        size_t tw = (size_t)2 * H * (H + 1) + (5 + PVS_MAX_EDGE_ATTR) * H + 16 +
+                    (size_t)kTeams * (3 * kTile * (H + 4) + kTile * 4 + 2 * kTile + 2 * 2 * kTile);
+        if (tw < (size_t)L.total) tw = L.total;
+        const size_t tlds = tw * sizeof(float);
+#define PVS_TEAM_LAUNCH(ER, EA)                                                                    \
+    do {                                                                                          \
+        if (set_lds(k_edge_bwd_team<2, ER, EA>, tlds)) return -2;                                 \
+        k_edge_bwd_team<2, ER, EA><<<blocks, 512, tlds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi); \
+    } while (0)
+        if (eres && eatt) PVS_TEAM_LAUNCH(true, true);
+        else if (eres) PVS_TEAM_LAUNCH(true, false);
+        else if (eatt) PVS_TEAM_LAUNCH(false, true);
+        else PVS_TEAM_LAUNCH(false, false);
+#undef PVS_TEAM_LAUNCH
+    }
 #undef PVS_BWD_PICK
 #undef PVS_BWD_LAUNCH
     PVS_CHECK_LAUNCH();
