@@ -104,6 +104,14 @@ __device__ __forceinline__ float pvs_unpack_rho(float packed, int* ty) {
     return __uint_as_float(u & ~3u);
 }
 
+// XCD-aware block order: consecutive hardware block ids are dealt round-robin over the 8 XCDs
+// (MI355X_MICROARCH.md, workgroup dispatch), so blocks b and b+8 share an L2. Give each XCD a
+// CONTIGUOUS range of work items (graphs): the node rows an XCD gathers then fit its 4 MB L2 instead
+// of every L2 seeing every graph. Speed only - any placement is correct.
+__device__ __forceinline__ int pvs_xcd_block(int b, int nb) {
+    return (nb & 7) ? b : (b & 7) * (nb >> 3) + (b >> 3);
+}
+
 // Same-wave LDS hand-off: order this wave's LDS writes before its later LDS reads. LDS
 // instructions of one wave execute in issue order, so only the COMPILER must be kept from
 // reordering them: wavefront-scope fences emit no instruction. (A workgroup-scope release would

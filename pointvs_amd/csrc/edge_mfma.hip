@@ -407,7 +407,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
     }
 
     const int total_waves = gridDim.x * kWaves;
-    for (int chunk = blockIdx.x * kWaves + wv; chunk < n_chunks; chunk += total_waves) {
+    for (int chunk = pvs_xcd_block(blockIdx.x, gridDim.x) * kWaves + wv; chunk < n_chunks; chunk += total_waves) {
         const int e_begin = chunk_begin(g, chunk, n_chunks, e_lo, e_hi);
         const int e_end = chunk_begin(g, chunk + 1, n_chunks, e_lo, e_hi);
         int cur_row = -1;
@@ -650,7 +650,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     float g_ba = 0.f, g_gate = 0.f;
 
     const int total_waves = gridDim.x * NW;
-    for (int chunk = blockIdx.x * NW + wv; chunk < n_chunks; chunk += total_waves) {
+    for (int chunk = pvs_xcd_block(blockIdx.x, gridDim.x) * NW + wv; chunk < n_chunks; chunk += total_waves) {
         const int e_begin = chunk_begin(g, chunk, n_chunks, e_lo, e_hi);
         const int e_end = chunk_begin(g, chunk + 1, n_chunks, e_lo, e_hi);
         int cur_row = -1;
@@ -1174,7 +1174,7 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     for (int r = 0; r < 16; ++r) g_wc2x[r] = 0.f;
     float g_b2 = 0.f, g_bc1 = 0.f, g_wa = 0.f, g_ba = 0.f, g_gate = 0.f;
 
-    for (int cbase = blockIdx.x * TEAMS; cbase < n_chunks; cbase += gridDim.x * TEAMS) {
+    for (int cbase = pvs_xcd_block(blockIdx.x, gridDim.x) * TEAMS; cbase < n_chunks; cbase += gridDim.x * TEAMS) {
         const int chunk = cbase + team;
         const int e_begin = chunk < n_chunks ? chunk_begin(g, chunk, n_chunks, e_lo, e_hi) : e_hi;
         const int e_end = chunk < n_chunks ? chunk_begin(g, chunk + 1, n_chunks, e_lo, e_hi) : e_hi;
