@@ -114,6 +114,9 @@ def main():
     ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3'])
     ap.add_argument('--batch', type=int, default=32, help='graphs per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--infer', action='store_true',
+                    help='forward-only (torch.no_grad) throughput: the virtual-screening shape of '
+                         'BASELINE config 5; not the headline metric')
     ap.add_argument('--graph', type=int, default=int(os.environ.get('PVS_BENCH_GRAPH', '0')),
                     help='1: capture the whole training step in a hipGraph and time replays')
     args = ap.parse_args()
@@ -158,7 +161,13 @@ def main():
     prefetch = int(os.environ.get('PVS_BENCH_PREFETCH', '0')) and not use_graph
     segs = (batch.graph_node_counts, batch.graph_edge_counts)
 
+    def infer_step():
+        with torch.no_grad():
+            return model(batch).reshape(-1).sum()
+
     def step():
+        if args.infer:
+            return infer_step()
         y_pred = model(batch).reshape(-1)
         if prefetch:   # the next batch's CSR/CSC build (here: the same tensors) runs on a side
             # stream under this batch's backward, as a data loader's look-ahead would arrange it
@@ -245,7 +254,9 @@ def main():
             kern = json.loads(tfile.read_text()).get('kernels', {})
             traffic = kern.get('k_edge_bwd_mfma', {}).get('hbm_bytes_per_launch')
         out = {
-            'metric': 'protein-ligand graphs/sec fwd+bwd (+Adam step), 3-layer EGNN ch=32, '
+            'metric': 'protein-ligand graphs/sec forward only (inference), 3-layer EGNN ch=32, '
+                      '~2k nodes r=10A' if args.infer else
+                      'protein-ligand graphs/sec fwd+bwd (+Adam step), 3-layer EGNN ch=32, '
                       '~2k nodes r=10A' if args.config == 'cfg2' else
                       'protein-ligand graphs/sec fwd+bwd (+Adam step), 12-layer EGNN ch=64 '
                       'edge+node attention, ~2k nodes r=6A',

@@ -301,3 +301,107 @@ def test_hipgraph_captured_step_matches_eager():
     eager, graphed = run(False), run(True)
     for k in eager:
         assert rel_err(graphed[k], eager[k]) < 1e-6, k
+
+
+@pytest.mark.parametrize('flags', [
+    dict(), dict(edge_residual=True, residual=True),
+    dict(edge_residual=True, gated_residual=True, residual=True, edge_attention=True,
+         node_attention=True, normalize=True, tanh=True, graphnorm=True),
+    dict(edge_attention=True, softmax_attention=True, residual=True)])
+def test_layer_public_api_input_gradients(flags):
+    """EGNNLayer.forward called directly (reference signature): outputs in the caller's edge order and
+    the gradients wrt h, coord and edge_messages against autograd on the fp64 oracle layer."""
+    from oracle import egnn_oracle as orc
+    from pointvs_amd.egnn_satorras import EGNNLayer
+    torch.manual_seed(11)
+    hid = 32
+    layer = EGNNLayer(hid, hid, hid, edges_in_d=3, **flags).cuda()
+    rng = np.random.default_rng(5)
+    pairs = rng.integers(0, 90, size=(2, 1500))
+    g = random_graph(90, pairs[:, pairs[0] != pairs[1]], seed=21)   # no self loops: with normalize=True
+    # a zero-length edge has d(diff/(|diff|+1e-8))/dx = 1e8, which cancels only in exact arithmetic
+    h0 = torch.from_numpy(rng.normal(size=(90, hid)).astype(np.float32))
+    m0 = torch.from_numpy(rng.normal(size=(g.edge_index.shape[1], hid)).astype(np.float32))
+    wh = torch.from_numpy(rng.normal(size=(90, hid)).astype(np.float32))
+    wx = torch.from_numpy(rng.normal(size=(90, 3)).astype(np.float32))
+    wm = torch.from_numpy(rng.normal(size=m0.shape).astype(np.float32))
+
+    h = h0.cuda().requires_grad_(True)
+    x = g.pos.cuda().requires_grad_(True)
+    mm = m0.cuda().requires_grad_(True)
+    h1, x1, ea, m1 = layer(h, g.edge_index.cuda(), x, g.edge_attr.cuda(), mm)
+    assert ea is not None and m1.shape == m0.shape
+    ((h1 * wh.cuda()).sum() + (x1 * wx.cuda()).sum() + (m1 * wm.cuda()).sum()).backward()
+
+    sd = {'L.' + k: v.detach().cpu().double().requires_grad_(True) for k, v in layer.state_dict().items()}
+    kw = dict(orc.BUILD_NET_DEFAULTS, residual=True, normalize=False, tanh=False, graphnorm=False)  # EGNNLayer ctor defaults
+    kw.update(flags)
+    kw['edge_attention_here'] = kw['edge_attention']
+    kw['node_attention_here'] = kw['node_attention']
+    hr = h0.double().requires_grad_(True)
+    xr = g.pos.double().requires_grad_(True)
+    mr = m0.double().requires_grad_(True)
+    h2, x2, m2, _, _ = orc.egnn_layer(sd, 'L.', kw, hr, g.edge_index, xr, g.edge_attr, mr)
+    ((h2 * wh.double()).sum() + (x2 * wx.double()).sum() + (m2 * wm.double()).sum()).backward()
+    assert rel_err(h1.detach().cpu().numpy(), h2.detach().numpy()) < TOL
+    assert rel_err(x1.detach().cpu().numpy(), x2.detach().numpy()) < TOL
+    assert rel_err(m1.detach().cpu().numpy(), m2.detach().numpy()) < TOL
+    assert rel_err(h.grad.cpu().numpy(), hr.grad.numpy()) < TOL
+    assert rel_err(x.grad.cpu().numpy(), xr.grad.numpy()) < TOL
+    if flags.get('edge_residual'):
+        assert rel_err(mm.grad.cpu().numpy(), mr.grad.numpy()) < TOL
+    for name, p in layer.named_parameters():
+        ref = sd['L.' + name].grad
+        assert ref is not None and p.grad is not None, name
+        assert rel_err(p.grad.cpu().numpy(), ref.numpy()) < TOL, name
+
+
+def test_checkpoint_roundtrip_and_legacy_keys(tmp_path):
+    """save() writes the reference's checkpoint dict; load_weights() reads it back, including the
+    reference's legacy key names (point_neural_network_base.py:501-565)."""
+    import yaml
+    from pointvs_amd.egnn_satorras import SartorrasEGNN
+    kw = dict(BASE_KW, edge_attention=True, node_attention=True)
+    torch.manual_seed(1)
+    a = SartorrasEGNN(tmp_path / 'run', 2e-3, 1e-4, **kw)
+    a.save()
+    ckpt = tmp_path / 'run' / 'checkpoints' / 'pose_ckpt_epoch_0.pt'
+    assert ckpt.exists() and (tmp_path / 'run' / 'model_kwargs.yaml').exists()
+    assert yaml.safe_load((tmp_path / 'run' / 'model_kwargs.yaml').read_text())['k'] == 32
+    blob = torch.load(ckpt, map_location='cpu')
+    assert set(blob) == {'learning_rate', 'weight_decay', 'p_epoch', 'a_epoch', 'model_state_dict',
+                         'optimiser_state_dict'}
+    torch.manual_seed(2)
+    b = SartorrasEGNN(tmp_path / 'other', 2e-3, 1e-4, silent=True, **kw)
+    b.load_weights(ckpt)
+    for (k1, v1), (k2, v2) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1.cpu(), v2.cpu())
+    legacy = dict(blob)
+    legacy['model_state_dict'] = {k.replace('node_att_mlp', 'node_attention_mlp').replace(
+        'att_mlp.0', 'att_mlp.2') if 'node_att' not in k else k.replace('node_att_mlp', 'node_attention_mlp'): v
+        for k, v in blob['model_state_dict'].items()}
+    legacy['model_state_dict'] = {k.replace('layers.1.att_mlp', 'layers.1.edge_attention_mlp'): v
+                                  for k, v in legacy['model_state_dict'].items()}
+    torch.save(legacy, tmp_path / 'legacy.pt')
+    c = SartorrasEGNN(tmp_path / 'third', 2e-3, 1e-4, silent=True, **kw)
+    c.load_weights(tmp_path / 'legacy.pt')
+    for (k1, v1), (k3, v3) in zip(a.state_dict().items(), c.state_dict().items()):
+        assert torch.equal(v1.cpu(), v3.cpu()), k1
+
+
+def test_train_and_val_entry_points(tmp_path):
+    """train_model / val keep the reference's calling convention on a tiny synthetic loader."""
+    from pointvs_amd.egnn_multitask import MultitaskSatorrasEGNN
+    from pointvs_amd.graph import Batch
+    from pointvs_amd.synthetic import synthetic_graph
+    gs = [synthetic_graph(s, n_nodes=120, n_lig=10, edge_radius=6.0) for s in range(30, 36)]
+    loader = [Batch.from_data_list(gs[:3]), Batch.from_data_list(gs[3:])]
+    torch.manual_seed(3)
+    model = MultitaskSatorrasEGNN(tmp_path / 'm', 2e-3, 1e-4, **dict(BASE_KW, residual=True))
+    before = model.layers[1].edge_mlp[0].weight.detach().clone()
+    losses = model.train_model(loader, epochs=2)
+    assert len(losses) == 4 and all(np.isfinite(losses))
+    assert not torch.equal(before, model.layers[1].edge_mlp[0].weight.detach())
+    lines = model.val(loader, predictions_file=tmp_path / 'pred.txt')
+    assert len(lines) == 6 and (tmp_path / 'pred.txt').read_text().count('\n') == 6
+    assert (tmp_path / 'm' / 'checkpoints' / 'pose_ckpt_epoch_2.pt').exists()
