@@ -1,559 +1,8 @@
-// MFMA edge kernels for H = 32*HB (HB = 1, 2): the fast path of EGNNLayer's per-edge work.
-//
-// Tile = 32 consecutive CSR-sorted edges per wavefront. Activations live in the "X layout" of
-// v_mfma_f32_32x32x2_f32 accumulators: lane l = (edge slot j = l&31, half hh = l>>5), register t
-// of channel block b holds channel 32b + (t&3) + 8(t>>2) + 4hh. An accumulator in that layout is
-// directly the B operand of the next product over channels (k pairs {ch(t,0), ch(t,1)}), so the
-// edge-MLP chain  z1 -> SiLU -> W2 -> SiLU -> Wc1 -> SiLU  needs no lane movement; the weights
-// are staged once per workgroup in LDS in A-operand order (one ds_read_b32 per MFMA).
-// The first edge-MLP layer is algebraically split per node (P_i + Q_j + w_rho*rho + W_a[type]),
-// so the per-edge MFMA work is the HxH products only.
-// Per-row sums (the reference's scatter-sum / scatter-mean, egnn_satorras.py:332-347): each wave
-// owns a row-aligned, edge-balanced chunk of the CSR; a tile's weighted messages go through a
-// per-wave LDS tile and are re-read channel-per-lane, where segment boundaries are wave-uniform
-// scalars: no atomics, fixed summation order, bitwise reproducible.
-//
-// Layout maps validated lane-by-lane in tools/mfma_layout_check.py.
-#include "edge_kernels.h"
-#include "mfma_common.h"
-#include "profile.h"
-
-#include <stdlib.h>
+// MFMA edge backward kernels for H = 32*HB (HB = 1, 2); the forward kernel and the description of the
+// X layout live in edge_mfma_fwd.hip, the shared device helpers in edge_mfma_common.h.
+#include "edge_mfma_common.h"
 
 namespace {
-
-constexpr int kThreads = 256;
-constexpr int kWaves = 4;
-constexpr int kTile = 32;
-
-#ifndef PVS_PREFETCH
-#define PVS_PREFETCH 0   // gather tile t+1's node rows while tile t is reduced (0: gather at tile start)
-#endif
-
-// Timing-only ablation switches (PVS_ABLATE env, tools/ablate.py): results are wrong when set.
-constexpr uint32_t kAblNoMfma = 1u << 24, kAblNoSilu = 1u << 25, kAblNoReduce = 1u << 26,
-                   kAblNoGather = 1u << 27;
-
-// Stage W[H][H] (row-major, W[out][in]) for  Z = W V  (transpose=false)  or  Z = W^T V  (true)
-// in A-operand order: dst[((bo*HB + bi)*16 + t)*64 + l] = Wx[32bo + (l&31)][32bi + ch(t, l>>5)].
-template <int HB>
-__device__ __forceinline__ void stage_weights(float* dst, const float* __restrict__ W, bool transpose) {
-    constexpr int H = 32 * HB;
-    for (int i = threadIdx.x; i < H * H; i += kThreads) {
-        const int l = i & 63, t = (i >> 6) & 15, bb = i >> 10;
-        const int bi = bb % HB, bo = bb / HB;
-        const int o = 32 * bo + (l & 31), k = 32 * bi + xch(t, l >> 5);
-        dst[i] = transpose ? W[k * H + o] : W[o * H + k];
-    }
-}
-
-// acc[bo] += sum over (bi,t) of A-staged weights x v[bi][t]   (v in X layout)
-template <int HB>
-__device__ __forceinline__ void mfma_chain(const float* __restrict__ Ws, int lane,
-                                           const float (&v)[HB][16], f32x16 (&acc)[HB],
-                                           bool skip = false) {
-    if (skip) {   // ablation: keep the operands live, issue no MFMA
-#pragma unroll
-        for (int b = 0; b < HB; ++b) acc[b][0] += v[b][0];
-        return;
-    }
-#pragma unroll
-    for (int bo = 0; bo < HB; ++bo)
-#pragma unroll
-        for (int bi = 0; bi < HB; ++bi)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float a = Ws[((bo * HB + bi) * 16 + t) * 64 + lane];
-                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v[bi][t], acc[bo], 0, 0, 0);
-            }
-}
-
-// Natural row-major staging W[c*(H+1) + k] (row stride padded by one word): ONE copy serves both
-// Z = W V (lanes vary the row: stride H+1 -> distinct banks) and Z = W^T V (lanes vary the column:
-// consecutive words), halving the LDS the backward needs for its four operand orientations.
-template <int HB>
-__device__ __forceinline__ void stage_weights_nat(float* dst, const float* __restrict__ W) {
-    constexpr int H = 32 * HB;
-    for (int i = threadIdx.x; i < H * H; i += blockDim.x) dst[(i / H) * (H + 1) + (i % H)] = W[i];
-}
-
-template <int HB, bool TRANSPOSE>
-__device__ __forceinline__ void mfma_chain_nat(const float* __restrict__ Wn, int lane,
-                                               const float (&v)[HB][16], f32x16 (&acc)[HB],
-                                               bool skip = false) {
-    constexpr int H = 32 * HB, LD = H + 1;
-    if (skip) {
-#pragma unroll
-        for (int b = 0; b < HB; ++b) acc[b][0] += v[b][0];
-        return;
-    }
-    const int j = lane & 31, hh = lane >> 5;
-    const float* base = TRANSPOSE ? Wn + (4 * hh) * LD + j : Wn + j * LD + 4 * hh;
-#pragma unroll
-    for (int bo = 0; bo < HB; ++bo)
-#pragma unroll
-        for (int bi = 0; bi < HB; ++bi)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int kc = 32 * bi + (t & 3) + 8 * (t >> 2);   // + 4hh folded into base
-                const float a = TRANSPOSE ? base[kc * LD + 32 * bo] : base[(32 * bo) * LD + kc];
-                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v[bi][t], acc[bo], 0, 0, 0);
-            }
-}
-
-// value of a per-channel table at this lane's X-layout channels: out[b][4g+q] = tab[32b+8g+4hh+q]
-template <int HB>
-__device__ __forceinline__ void load_tab(const float* __restrict__ tab, int hh, float (&out)[HB][16]) {
-#pragma unroll
-    for (int b = 0; b < HB; ++b)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 v = *reinterpret_cast<const float4*>(tab + 32 * b + 8 * g + 4 * hh);
-            out[b][4 * g] = v.x; out[b][4 * g + 1] = v.y; out[b][4 * g + 2] = v.z; out[b][4 * g + 3] = v.w;
-        }
-}
-
-template <int HB>
-__device__ __forceinline__ float dot_tab(const float* __restrict__ tab, int hh, const float (&v)[HB][16]) {
-    float s = 0.f;
-#pragma unroll
-    for (int b = 0; b < HB; ++b)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 w = *reinterpret_cast<const float4*>(tab + 32 * b + 8 * g + 4 * hh);
-            s = fmaf(w.x, v[b][4 * g], s); s = fmaf(w.y, v[b][4 * g + 1], s);
-            s = fmaf(w.z, v[b][4 * g + 2], s); s = fmaf(w.w, v[b][4 * g + 3], s);
-        }
-    return s + __shfl_xor(s, 32, 64);   // other half holds the other 16 channels of each block
-}
-
-// Wave chunks of the edge range [e_lo, e_hi) (row-aligned ends): chunk k starts at the row that
-// contains edge e_lo + k*(e_hi-e_lo)/n_chunks, so every row is owned by exactly one wave.
-__device__ __forceinline__ int chunk_begin(const PvsGraph& g, int k, int n_chunks, int e_lo, int e_hi) {
-    if (k <= 0) return e_lo;
-    if (k >= n_chunks) return e_hi;
-    const long long t = e_lo + (long long)k * (e_hi - e_lo) / n_chunks;
-    return max(e_lo, g.rowptr[g.row[t]]);
-}
-
-// Indices of one 32-edge tile (lane = edge slot j, both halves hold the same values).
-struct TileIdx {
-    int e, ee, i, jn, ty, prev_row;
-    bool valid;
-};
-
-__device__ __forceinline__ TileIdx load_tile_idx(const PvsGraph& g, int n_attr, int e0, int e_begin,
-                                                 int e_end, int j) {
-    TileIdx t;
-    t.e = e0 + j;
-    t.valid = t.e < e_end;
-    t.ee = t.valid ? t.e : e_end - 1;
-    t.i = g.row[t.ee];
-    t.jn = g.col[t.ee];
-    if (n_attr & 0x100) { t.i &= 7; t.jn &= 7; }   // ablation: every gather hits 8 hot rows
-    t.ty = (n_attr & 0xff) ? (int)g.etype[t.ee] : 0;
-    t.prev_row = (t.ee == e_begin) ? -1 : g.row[t.ee - 1];
-    return t;
-}
-
-// Gathered node data of one tile in X layout: P_i and Q_j rows, coordinate difference.
-template <int HB>
-struct TileGather {
-    float P[HB][16], Q[HB][16];
-    float d0, d1, d2;
-};
-
-template <int HB>
-__device__ __forceinline__ void gather_tile(const float* __restrict__ PQ, const float* __restrict__ x,
-                                            const TileIdx& t, int hh, TileGather<HB>& G) {
-    constexpr int H = 32 * HB;
-    const float* Pp = PQ + (size_t)t.i * 2 * H + 4 * hh;
-    const float* Qp = PQ + (size_t)t.jn * 2 * H + H + 4 * hh;
-#pragma unroll
-    for (int b = 0; b < HB; ++b)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const float4 p = *reinterpret_cast<const float4*>(Pp + 32 * b + 8 * gq);
-            const float4 q = *reinterpret_cast<const float4*>(Qp + 32 * b + 8 * gq);
-            G.P[b][4 * gq] = p.x; G.P[b][4 * gq + 1] = p.y; G.P[b][4 * gq + 2] = p.z; G.P[b][4 * gq + 3] = p.w;
-            G.Q[b][4 * gq] = q.x; G.Q[b][4 * gq + 1] = q.y; G.Q[b][4 * gq + 2] = q.z; G.Q[b][4 * gq + 3] = q.w;
-        }
-    G.d0 = x[3 * t.i] - x[3 * t.jn];
-    G.d1 = x[3 * t.i + 1] - x[3 * t.jn + 1];
-    G.d2 = x[3 * t.i + 2] - x[3 * t.jn + 2];
-}
-
-// z1 = P_i + Q_j + w_rho * rho + W_a[type]  (X layout)
-template <int HB>
-__device__ __forceinline__ void assemble_z1(const TileGather<HB>& G, const float* __restrict__ attrt,
-                                            const float* __restrict__ wrhot, int ty, int hh, float rho,
-                                            float (&z1)[HB][16]) {
-    constexpr int H = 32 * HB;
-    const float* At = attrt + ty * H + 4 * hh;
-    const float* Rt = wrhot + 4 * hh;
-#pragma unroll
-    for (int b = 0; b < HB; ++b)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const float4 a = *reinterpret_cast<const float4*>(At + 32 * b + 8 * gq);
-            const float4 r = *reinterpret_cast<const float4*>(Rt + 32 * b + 8 * gq);
-            z1[b][4 * gq] = G.P[b][4 * gq] + G.Q[b][4 * gq] + fmaf(r.x, rho, a.x);
-            z1[b][4 * gq + 1] = G.P[b][4 * gq + 1] + G.Q[b][4 * gq + 1] + fmaf(r.y, rho, a.y);
-            z1[b][4 * gq + 2] = G.P[b][4 * gq + 2] + G.Q[b][4 * gq + 2] + fmaf(r.z, rho, a.z);
-            z1[b][4 * gq + 3] = G.P[b][4 * gq + 3] + G.Q[b][4 * gq + 3] + fmaf(r.w, rho, a.w);
-        }
-}
-
-
-// ---- row (segment) reduction of one edge-major LDS tile -------------------------------------------
-// T[32][TS] holds one H-vector per edge of the tile, tx[32][4] one float4 per edge, rowbuf[32] the
-// row id of each edge. Lane = (row slot rsub, 16-byte quad): each lane reads whole float4s, so the
-// same LDS reads feed both the per-row sums and (optionally) fully coalesced 128-byte row stores to
-// HBM. bmask bit e = "edge e starts a new row" (wave-uniform), so segments are handled by scalar
-// control flow: the first segment continues the carried row, every later one starts at a set bit.
-// acc/accx carry the open row's partial sums (per lane: its quad, summed over its row slots);
-// flush(row) reduces them over the row slots, stores and clears.
-template <int HB, class Flush, class RowStore>
-__device__ __forceinline__ void reduce_rows_tile(const float* __restrict__ T, const float* __restrict__ tx,
-                                                 const int* __restrict__ rowbuf, unsigned bmask, int lane,
-                                                 float4& acc, float4& accx, int& cur_row, Flush&& flush,
-                                                 RowStore&& store_row) {
-    constexpr int H = 32 * HB, TS = H + 4;
-    constexpr int QPR = H / 4, RPI = 64 / QPR, NK = kTile / RPI;
-    const int quad = lane % QPR, rsub = lane / QPR;
-    float4 v[NK], dx[NK];
-    int seg[NK];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int rl = k * RPI + rsub;
-        v[k] = *reinterpret_cast<const float4*>(T + rl * TS + 4 * quad);
-        dx[k] = *reinterpret_cast<const float4*>(tx + rl * 4);
-        store_row(rl, quad, v[k]);
-        const unsigned upto = rl == 31 ? 0xffffffffu : ((2u << rl) - 1u);
-        seg[k] = __popc(bmask & upto);
-    }
-    auto add4 = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
-    if (bmask == 0u) {
-#pragma unroll
-        for (int k = 0; k < NK; ++k) { add4(acc, v[k]); add4(accx, dx[k]); }
-        return;
-    }
-    unsigned bm = bmask;
-    for (int s = 0;; ++s) {
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const float m = seg[k] == s ? 1.f : 0.f;
-            acc.x = fmaf(m, v[k].x, acc.x); acc.y = fmaf(m, v[k].y, acc.y);
-            acc.z = fmaf(m, v[k].z, acc.z); acc.w = fmaf(m, v[k].w, acc.w);
-            accx.x = fmaf(m, dx[k].x, accx.x); accx.y = fmaf(m, dx[k].y, accx.y);
-            accx.z = fmaf(m, dx[k].z, accx.z);
-        }
-        if (bm == 0u) break;            // the last segment stays open (carried to the next tile)
-        flush(cur_row);
-        const int pos = __builtin_ctz(bm);
-        bm &= bm - 1u;
-        cur_row = __builtin_amdgcn_readfirstlane(rowbuf[pos]);
-    }
-}
-
-// sum a float4 over the row slots (lanes that share a quad)
-template <int HB>
-__device__ __forceinline__ float4 sum_row_slots(float4 a) {
-    constexpr int QPR = 8 * HB;
-#pragma unroll
-    for (int o = QPR; o < 64; o <<= 1) {
-        a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64);
-        a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
-    }
-    return a;
-}
-
-
-// ---- fp32 products as 6 bf16 MFMA terms ("bf16x3") -------------------------------------------------
-// x = hi + mid + lo with each part the next 8 significant bits of x (truncation: exact 24-bit
-// split), so a*b = hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi + O(2^-25 |a||b|): fp32-level
-// accuracy from v_mfma_f32_32x32x16_bf16 (fp32 accumulate), 12 bf16 MFMAs of 32 cycles per
-// 32x32x32 block instead of 16 fp32 MFMAs of 64 cycles, on the matrix cores proper.
-// k-step s of the bf16 instruction takes X-layout registers 8s..8s+7 as its 8 B-operand elements
-// (k = 8*hh + j'), and the A operand staged with the same channel order.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-struct Bf16Parts { bf16x8 hi[2], mid[2], lo[2]; };
-
-__device__ __forceinline__ unsigned pvs_pack_hi16(float x0, float x1) {
-    // bf16 (truncated) of x0 in the low half, of x1 in the high half
-    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
-}
-
-__device__ __forceinline__ void split_bf16x3(const float (&v)[16], Bf16Parts& out) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        uint4 ph, pm, pl;
-        unsigned* h = reinterpret_cast<unsigned*>(&ph);
-        unsigned* m = reinterpret_cast<unsigned*>(&pm);
-        unsigned* l = reinterpret_cast<unsigned*>(&pl);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float x0 = v[8 * s + 2 * q], x1 = v[8 * s + 2 * q + 1];
-            const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
-            const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
-            const float t0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
-            const float t1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-            h[q] = pvs_pack_hi16(x0, x1);
-            m[q] = pvs_pack_hi16(r0, r1);
-            l[q] = pvs_pack_hi16(t0, t1);
-        }
-        out.hi[s] = __builtin_bit_cast(bf16x8, ph);
-        out.mid[s] = __builtin_bit_cast(bf16x8, pm);
-        out.lo[s] = __builtin_bit_cast(bf16x8, pl);
-    }
-}
-
-// Stage W[32][32] (row-major, W[out][in]) as bf16x3 A operands: dst[((part*2 + s)*64 + l)*4 .. +3]
-// (uint words) = 8 bf16 of W[l&31][ch(8s + j', l>>5)], j' = 0..7, part in {hi, mid, lo}.
-__device__ __forceinline__ void stage_weights_bf16x3(unsigned* dst, const float* __restrict__ W,
-                                                     bool transpose = false) {
-    // transpose: operand rows are the columns of W (Z = W^T V)
-    for (int i = threadIdx.x; i < 2 * 64 * 4; i += blockDim.x) {
-        const int q = i & 3, l = (i >> 2) & 63, s = i >> 8;
-        const int o = l & 31, hh = l >> 5;
-        const int k0 = xch(8 * s + 2 * q, hh), k1 = xch(8 * s + 2 * q + 1, hh);
-        const float x0 = transpose ? W[k0 * 32 + o] : W[o * 32 + k0];
-        const float x1 = transpose ? W[k1 * 32 + o] : W[o * 32 + k1];
-        const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
-        const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
-        const float t0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
-        const float t1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-        dst[((0 * 2 + s) * 64 + l) * 4 + q] = pvs_pack_hi16(x0, x1);
-        dst[((1 * 2 + s) * 64 + l) * 4 + q] = pvs_pack_hi16(r0, r1);
-        dst[((2 * 2 + s) * 64 + l) * 4 + q] = pvs_pack_hi16(t0, t1);
-    }
-}
-
-__device__ __forceinline__ void mfma_chain_bf16x3(const unsigned* __restrict__ Wb, int lane,
-                                                  const float (&v)[16], f32x16& acc) {
-    Bf16Parts b;
-    split_bf16x3(v, b);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wb + ((0 * 2 + s) * 64 + lane) * 4));
-        const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wb + ((1 * 2 + s) * 64 + lane) * 4));
-        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wb + ((2 * 2 + s) * 64 + lane) * 4));
-        // smallest terms first
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.hi[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.lo[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.mid[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.hi[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.mid[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.hi[s], acc, 0, 0, 0);
-    }
-}
-
-template <int HB, bool BF16X3>
-__global__ void __launch_bounds__(kThreads)
-k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdIO io, int n_chunks,
-                int e_lo, int e_hi) {
-    constexpr int H = 32 * HB;
-    constexpr int TS = H + 4;   // tile row stride (floats): conflict-free b128 writes / b32 reads
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int kWeightWords = BF16X3 ? 2 * 6 * 64 * 4 : 2 * H * H;
-    float* W2s = smem;
-    float* Wc1s = W2s + H * H;
-    float* b2t = smem + kWeightWords;
-    float* bc1t = b2t + H;
-    float* wc2t = bc1t + H;
-    float* wat = wc2t + H;
-    float* wrhot = wat + H;
-    float* attrt = wrhot + H;                            // [PVS_MAX_EDGE_ATTR][H]
-    float* wave_base = attrt + PVS_MAX_EDGE_ATTR * H;    // per wave: tile[32][TS], tx[32][4], rowbuf[32]
-    constexpr int kWaveFloats = kTile * TS + kTile * 4 + kTile;
-
-    const bool upd = flags & PVS_UPDATE_COORDS;
-    const bool eatt = flags & PVS_EDGE_ATTENTION;
-    const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
-
-    // BF16X3 (H = 32 only): each matrix takes 3 parts x 2 k-steps x 64 lanes x 16 B = 6 KB
-    static_assert(!BF16X3 || HB == 1, "bf16x3 variant is built for H = 32");
-    unsigned* W2b = reinterpret_cast<unsigned*>(W2s);
-    unsigned* Wc1b = W2b + 6 * 64 * 4;
-    if constexpr (BF16X3) {
-        stage_weights_bf16x3(W2b, w.w2);
-        if (upd) stage_weights_bf16x3(Wc1b, w.wc1);
-    } else {
-        stage_weights<HB>(W2s, w.w2, false);
-        if (upd) stage_weights<HB>(Wc1s, w.wc1, false);
-    }
-    for (int c = threadIdx.x; c < H; c += kThreads) {
-        b2t[c] = w.b2[c];
-        bc1t[c] = upd ? w.bc1[c] : 0.f;
-        wc2t[c] = upd ? w.wc2[c] : 0.f;
-        wat[c] = eatt ? w.wa[c] : 0.f;
-        wrhot[c] = w.w1[c * w.ld1 + w.off_rho];
-        for (int t = 0; t < PVS_MAX_EDGE_ATTR; ++t)
-            attrt[t * H + c] = t < w.n_attr ? w.w1[c * w.ld1 + w.off_rho + 1 + t] : 0.f;
-    }
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int j = lane & 31, hh = lane >> 5;
-    float* tile = wave_base + wv * kWaveFloats;
-    float* tx = tile + kTile * TS;
-    int* rowbuf = reinterpret_cast<int*>(tx + kTile * 4);
-    const float bac = eatt ? w.ba[0] : 0.f;
-    float gate = 1.f;
-    if (eres && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
-        gate = w.edge_gate[0];
-        if (flags & PVS_GATED_RESIDUAL) gate = fmaxf(gate, 0.f);
-    }
-
-    const int total_waves = gridDim.x * kWaves;
-    for (int chunk = pvs_xcd_block(blockIdx.x, gridDim.x) * kWaves + wv; chunk < n_chunks; chunk += total_waves) {
-        const int e_begin = chunk_begin(g, chunk, n_chunks, e_lo, e_hi);
-        const int e_end = chunk_begin(g, chunk + 1, n_chunks, e_lo, e_hi);
-        int cur_row = -1;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accx = acc;   // open row: lane = (row slot, quad)
-        constexpr int QPR = H / 4;
-        const int quad = lane % QPR, rsub = lane / QPR;
-
-        auto flush = [&](int row_id) {
-            if (row_id >= 0) {
-                const float4 tot = sum_row_slots<HB>(acc);
-                if (rsub == 0) *reinterpret_cast<float4*>(io.Magg + (size_t)row_id * H + 4 * quad) = tot;
-                if (upd) {
-                    const float4 tx4 = sum_row_slots<HB>(accx);
-                    if (lane == 0) {
-                        const float inv = g.inv_deg[row_id];
-                        io.x_out[3 * row_id] = io.x[3 * row_id] + tx4.x * inv;
-                        io.x_out[3 * row_id + 1] = io.x[3 * row_id + 1] + tx4.y * inv;
-                        io.x_out[3 * row_id + 2] = io.x[3 * row_id + 2] + tx4.z * inv;
-                    }
-                }
-            }
-            acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            accx = acc;
-        };
-
-        // software pipeline: the gathers of tile t+1 are issued while tile t is being reduced
-        TileIdx I = load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_begin, e_begin, e_end, j);
-        TileGather<HB> G;
-        if (e_begin < e_end) gather_tile<HB>(io.PQ, io.x, I, hh, G);
-        for (int e0 = e_begin; e0 < e_end; e0 += kTile) {
-            const int e_next = (e0 + kTile < e_end) ? e0 + kTile : e0;
-            const TileIdx In = load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_next, e_begin, e_end, j);
-            const int e = I.e, ee = I.ee, i = I.i;
-            const bool valid = I.valid;
-            const unsigned long long ball = __ballot(valid && hh == 0 && i != I.prev_row);
-            const unsigned bmask = (unsigned)ball;
-#if !PVS_PREFETCH
-            gather_tile<HB>(io.PQ, io.x, I, hh, G);
-#endif
-            const float d0 = G.d0, d1 = G.d1, d2 = G.d2;
-            const float rho = d0 * d0 + d1 * d1 + d2 * d2;
-
-            // ---- first layer: z1 = P_i + Q_j + w_rho*rho + W_a[type]; a1 = SiLU(z1) ----
-            float a1[HB][16];
-            assemble_z1<HB>(G, attrt, wrhot, I.ty, hh, rho, a1);
-#pragma unroll
-            for (int b = 0; b < HB; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a1[b][r] = pvs_silu(a1[b][r]);
-            // ---- second layer on the matrix cores: m = SiLU(W2 a1 + b2) ----
-            float m[HB][16];
-            {
-                f32x16 acc2[HB];
-                float bias[HB][16];
-                load_tab<HB>(b2t, hh, bias);
-#pragma unroll
-                for (int b = 0; b < HB; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc2[b][r] = bias[b][r];
-                if constexpr (BF16X3) mfma_chain_bf16x3(W2b, lane, a1[0], acc2[0]);
-                else mfma_chain<HB>(W2s, lane, a1, acc2, flags & kAblNoMfma);
-#pragma unroll
-                for (int b = 0; b < HB; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) m[b][r] = pvs_silu(acc2[b][r]);
-            }
-            if (eres) {
-#pragma unroll
-                for (int b = 0; b < HB; ++b)
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const float4 mp = *reinterpret_cast<const float4*>(
-                            io.m_prev + (size_t)ee * H + 32 * b + 8 * gq + 4 * hh);
-                        const float mpv[4] = {mp.x, mp.y, mp.z, mp.w};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            float& mv = m[b][4 * gq + q];
-                            if (flags & PVS_REZERO) mv = mpv[q] + gate * mv;
-                            else if (flags & PVS_GATED_RESIDUAL) mv = gate * mv + (1.f - gate) * mpv[q];
-                            else mv = mv + mpv[q];
-                        }
-                    }
-            }
-            if (io.m_out && valid) {
-#pragma unroll
-                for (int b = 0; b < HB; ++b)
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq)
-                        *reinterpret_cast<float4*>(io.m_out + (size_t)e * H + 32 * b + 8 * gq + 4 * hh) =
-                            make_float4(m[b][4 * gq], m[b][4 * gq + 1], m[b][4 * gq + 2], m[b][4 * gq + 3]);
-            }
-            // ---- coordinate branch: s = wc2 . SiLU(Wc1 m + bc1) ----
-            float s = 0.f;
-            if (upd) {
-                f32x16 accc[HB];
-                float bias[HB][16];
-                load_tab<HB>(bc1t, hh, bias);
-#pragma unroll
-                for (int b = 0; b < HB; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) accc[b][r] = bias[b][r];
-                if constexpr (BF16X3) mfma_chain_bf16x3(Wc1b, lane, m[0], accc[0]);
-                else mfma_chain<HB>(Wc1s, lane, m, accc, flags & kAblNoMfma);
-                float q[HB][16];
-#pragma unroll
-                for (int b = 0; b < HB; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) q[b][r] = pvs_silu(accc[b][r]);
-                s = dot_tab<HB>(wc2t, hh, q);
-                if (flags & PVS_TANH) s = pvs_tanh(s);
-                if (flags & PVS_NORMALIZE) s = s / (sqrtf(rho) + 1e-8f);
-            }
-            // ---- attention gate ----
-            float a = 1.f;
-            if (eatt) {
-                a = pvs_att_act(att_act, dot_tab<HB>(wat, hh, m) + bac);
-                if (valid && hh == 0) io.att_out[e] = a;
-            }
-            // ---- hand the weighted messages to the channel-per-lane reduction ----
-            const float wgt = valid ? a : 0.f;
-#pragma unroll
-            for (int b = 0; b < HB; ++b)
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq)
-                    *reinterpret_cast<float4*>(tile + j * TS + 32 * b + 8 * gq + 4 * hh) =
-                        make_float4(wgt * m[b][4 * gq], wgt * m[b][4 * gq + 1], wgt * m[b][4 * gq + 2],
-                                    wgt * m[b][4 * gq + 3]);
-            if (hh == 0) {
-                const float sv = valid ? s : 0.f;
-                *reinterpret_cast<float4*>(tx + j * 4) = make_float4(d0 * sv, d1 * sv, d2 * sv, 0.f);
-                rowbuf[j] = i;
-            }
-#if PVS_PREFETCH
-            gather_tile<HB>(io.PQ, io.x, In, hh, G);   // next tile's rows fly during the reduction
-#endif
-            I = In;
-            pvs_wave_lds_sync();
-            if (!(flags & kAblNoReduce))
-                reduce_rows_tile<HB>(tile, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
-                                     [](int, int, const float4&) {});
-            pvs_wave_lds_sync();
-        }
-        flush(cur_row);
-    }
-}
-
 
 // Backward of the per-edge work on the matrix cores. Per 32-edge tile: recompute the forward
 // (2 products), back-propagate (2 transposed products) and accumulate the two HxH weight
@@ -1512,68 +961,8 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     for (int i = threadIdx.x; i < L.total; i += NT) dst[i] = slab[i];
 }
 
-template <typename K>
-int set_lds(K kernel, size_t lds) {
-    if (lds > 48 * 1024)
-        PVS_CHECK_HIP(hipFuncSetAttribute((const void*)kernel,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    return 0;
-}
-
-void pick_grid(int E, int* blocks, int* n_chunks, int max_blocks = 1024) {
-    // a wave gets >= ~2048 edges where the range allows; chunks of <= ~4096 edges; every wave gets
-    // the same number of chunks
-    long long b = ((long long)E + 4 * 2048 - 1) / (4 * 2048);
-    if (b < 1) b = 1;
-    if (b > max_blocks) b = max_blocks;
-    const long long waves = b * kWaves;
-    long long per_wave = ((long long)E + waves * 4096 - 1) / (waves * 4096);
-    if (per_wave < 1) per_wave = 1;
-    *blocks = (int)b;
-    *n_chunks = (int)(waves * per_wave);
-}
 
 }  // namespace
-
-int pvs_edge_mfma_supported(int H, uint32_t flags) {
-    if (H != 32 && H != 64) return 0;
-    if ((flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT)) return 0;   // generic path
-    return 1;
-}
-
-int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,
-                             int att_act, const PvsEdgeFwdIO& io) {
-    PVS_REQUIRE(w.n_attr <= PVS_MAX_EDGE_ATTR, "edge_attr classes %d > %d", w.n_attr,
-                PVS_MAX_EDGE_ATTR);
-    // rows without edges are never flushed: M = 0, x_out = x
-    PVS_CHECK_HIP(hipMemsetAsync(io.Magg, 0, sizeof(float) * (size_t)g.n_nodes * H, s));
-    if (flags & PVS_UPDATE_COORDS)
-        PVS_CHECK_HIP(hipMemcpyAsync(io.x_out, io.x, sizeof(float) * 3 * (size_t)g.n_nodes,
-                                     hipMemcpyDeviceToDevice, s));
-    if (g.n_edges == 0) return 0;
-    int blocks, n_chunks;
-    pick_grid(g.n_edges, &blocks, &n_chunks);
-    PvsProfScope prof(s, PVS_PROF_EDGE_FWD);
-    const int HB = H / 32;
-    const char* bf = getenv("PVS_EGNN_BF16X3");
-    const bool bf16x3 = !(bf && bf[0] == '0') && H == 32;   // default for H = 32 (PVS_EGNN_BF16X3=0: fp32 MFMA)
-    const size_t words = (bf16x3 ? (size_t)2 * 6 * 64 * 4 : (size_t)2 * H * H) +
-                         (5 + PVS_MAX_EDGE_ATTR) * H +
-                         (size_t)kWaves * (kTile * (H + 4) + kTile * 4 + kTile);
-    const size_t lds = words * sizeof(float);
-    if (HB == 1 && bf16x3) {
-        if (set_lds(k_edge_fwd_mfma<1, true>, lds)) return -2;
-        k_edge_fwd_mfma<1, true><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
-    } else if (HB == 1) {
-        if (set_lds(k_edge_fwd_mfma<1, false>, lds)) return -2;
-        k_edge_fwd_mfma<1, false><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
-    } else {
-        if (set_lds(k_edge_fwd_mfma<2, false>, lds)) return -2;
-        k_edge_fwd_mfma<2, false><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
-    }
-    PVS_CHECK_LAUNCH();
-    return 0;
-}
 
 int pvs_edge_bwd_mfma_max_blocks(int H) { return H == 32 ? 512 : 256; }
 

@@ -1,0 +1,363 @@
+// Device helpers shared by the MFMA edge kernels (edge_mfma_fwd.hip, edge_mfma.hip): weight staging,
+// X-layout MFMA chains, tile index/gather helpers, the row (segment) reduction of an edge-major LDS
+// tile and the bf16x3 split. See edge_mfma_fwd.hip for the layout description.
+#pragma once
+#include "edge_kernels.h"
+#include "mfma_common.h"
+#include "profile.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kTile = 32;
+
+#ifndef PVS_PREFETCH
+#define PVS_PREFETCH 0   // gather tile t+1's node rows while tile t is reduced (0: gather at tile start)
+#endif
+
+// Timing-only ablation switches (PVS_ABLATE env, tools/ablate.py): results are wrong when set.
+constexpr uint32_t kAblNoMfma = 1u << 24, kAblNoSilu = 1u << 25, kAblNoReduce = 1u << 26,
+                   kAblNoGather = 1u << 27;
+
+// Stage W[H][H] (row-major, W[out][in]) for  Z = W V  (transpose=false)  or  Z = W^T V  (true)
+// in A-operand order: dst[((bo*HB + bi)*16 + t)*64 + l] = Wx[32bo + (l&31)][32bi + ch(t, l>>5)].
+template <int HB>
+__device__ __forceinline__ void stage_weights(float* dst, const float* __restrict__ W, bool transpose) {
+    constexpr int H = 32 * HB;
+    for (int i = threadIdx.x; i < H * H; i += kThreads) {
+        const int l = i & 63, t = (i >> 6) & 15, bb = i >> 10;
+        const int bi = bb % HB, bo = bb / HB;
+        const int o = 32 * bo + (l & 31), k = 32 * bi + xch(t, l >> 5);
+        dst[i] = transpose ? W[k * H + o] : W[o * H + k];
+    }
+}
+
+// acc[bo] += sum over (bi,t) of A-staged weights x v[bi][t]   (v in X layout)
+template <int HB>
+__device__ __forceinline__ void mfma_chain(const float* __restrict__ Ws, int lane,
+                                           const float (&v)[HB][16], f32x16 (&acc)[HB],
+                                           bool skip = false) {
+    if (skip) {   // ablation: keep the operands live, issue no MFMA
+#pragma unroll
+        for (int b = 0; b < HB; ++b) acc[b][0] += v[b][0];
+        return;
+    }
+#pragma unroll
+    for (int bo = 0; bo < HB; ++bo)
+#pragma unroll
+        for (int bi = 0; bi < HB; ++bi)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float a = Ws[((bo * HB + bi) * 16 + t) * 64 + lane];
+                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v[bi][t], acc[bo], 0, 0, 0);
+            }
+}
+
+// Natural row-major staging W[c*(H+1) + k] (row stride padded by one word): ONE copy serves both
+// Z = W V (lanes vary the row: stride H+1 -> distinct banks) and Z = W^T V (lanes vary the column:
+// consecutive words), halving the LDS the backward needs for its four operand orientations.
+template <int HB>
+__device__ __forceinline__ void stage_weights_nat(float* dst, const float* __restrict__ W) {
+    constexpr int H = 32 * HB;
+    for (int i = threadIdx.x; i < H * H; i += blockDim.x) dst[(i / H) * (H + 1) + (i % H)] = W[i];
+}
+
+template <int HB, bool TRANSPOSE>
+__device__ __forceinline__ void mfma_chain_nat(const float* __restrict__ Wn, int lane,
+                                               const float (&v)[HB][16], f32x16 (&acc)[HB],
+                                               bool skip = false) {
+    constexpr int H = 32 * HB, LD = H + 1;
+    if (skip) {
+#pragma unroll
+        for (int b = 0; b < HB; ++b) acc[b][0] += v[b][0];
+        return;
+    }
+    const int j = lane & 31, hh = lane >> 5;
+    const float* base = TRANSPOSE ? Wn + (4 * hh) * LD + j : Wn + j * LD + 4 * hh;
+#pragma unroll
+    for (int bo = 0; bo < HB; ++bo)
+#pragma unroll
+        for (int bi = 0; bi < HB; ++bi)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kc = 32 * bi + (t & 3) + 8 * (t >> 2);   // + 4hh folded into base
+                const float a = TRANSPOSE ? base[kc * LD + 32 * bo] : base[(32 * bo) * LD + kc];
+                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v[bi][t], acc[bo], 0, 0, 0);
+            }
+}
+
+// value of a per-channel table at this lane's X-layout channels: out[b][4g+q] = tab[32b+8g+4hh+q]
+template <int HB>
+__device__ __forceinline__ void load_tab(const float* __restrict__ tab, int hh, float (&out)[HB][16]) {
+#pragma unroll
+    for (int b = 0; b < HB; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(tab + 32 * b + 8 * g + 4 * hh);
+            out[b][4 * g] = v.x; out[b][4 * g + 1] = v.y; out[b][4 * g + 2] = v.z; out[b][4 * g + 3] = v.w;
+        }
+}
+
+template <int HB>
+__device__ __forceinline__ float dot_tab(const float* __restrict__ tab, int hh, const float (&v)[HB][16]) {
+    float s = 0.f;
+#pragma unroll
+    for (int b = 0; b < HB; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 w = *reinterpret_cast<const float4*>(tab + 32 * b + 8 * g + 4 * hh);
+            s = fmaf(w.x, v[b][4 * g], s); s = fmaf(w.y, v[b][4 * g + 1], s);
+            s = fmaf(w.z, v[b][4 * g + 2], s); s = fmaf(w.w, v[b][4 * g + 3], s);
+        }
+    return s + __shfl_xor(s, 32, 64);   // other half holds the other 16 channels of each block
+}
+
+// Wave chunks of the edge range [e_lo, e_hi) (row-aligned ends): chunk k starts at the row that
+// contains edge e_lo + k*(e_hi-e_lo)/n_chunks, so every row is owned by exactly one wave.
+__device__ __forceinline__ int chunk_begin(const PvsGraph& g, int k, int n_chunks, int e_lo, int e_hi) {
+    if (k <= 0) return e_lo;
+    if (k >= n_chunks) return e_hi;
+    const long long t = e_lo + (long long)k * (e_hi - e_lo) / n_chunks;
+    return max(e_lo, g.rowptr[g.row[t]]);
+}
+
+// Indices of one 32-edge tile (lane = edge slot j, both halves hold the same values).
+struct TileIdx {
+    int e, ee, i, jn, ty, prev_row;
+    bool valid;
+};
+
+__device__ __forceinline__ TileIdx load_tile_idx(const PvsGraph& g, int n_attr, int e0, int e_begin,
+                                                 int e_end, int j) {
+    TileIdx t;
+    t.e = e0 + j;
+    t.valid = t.e < e_end;
+    t.ee = t.valid ? t.e : e_end - 1;
+    t.i = g.row[t.ee];
+    t.jn = g.col[t.ee];
+    if (n_attr & 0x100) { t.i &= 7; t.jn &= 7; }   // ablation: every gather hits 8 hot rows
+    t.ty = (n_attr & 0xff) ? (int)g.etype[t.ee] : 0;
+    t.prev_row = (t.ee == e_begin) ? -1 : g.row[t.ee - 1];
+    return t;
+}
+
+// Gathered node data of one tile in X layout: P_i and Q_j rows, coordinate difference.
+template <int HB>
+struct TileGather {
+    float P[HB][16], Q[HB][16];
+    float d0, d1, d2;
+};
+
+template <int HB>
+__device__ __forceinline__ void gather_tile(const float* __restrict__ PQ, const float* __restrict__ x,
+                                            const TileIdx& t, int hh, TileGather<HB>& G) {
+    constexpr int H = 32 * HB;
+    const float* Pp = PQ + (size_t)t.i * 2 * H + 4 * hh;
+    const float* Qp = PQ + (size_t)t.jn * 2 * H + H + 4 * hh;
+#pragma unroll
+    for (int b = 0; b < HB; ++b)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 p = *reinterpret_cast<const float4*>(Pp + 32 * b + 8 * gq);
+            const float4 q = *reinterpret_cast<const float4*>(Qp + 32 * b + 8 * gq);
+            G.P[b][4 * gq] = p.x; G.P[b][4 * gq + 1] = p.y; G.P[b][4 * gq + 2] = p.z; G.P[b][4 * gq + 3] = p.w;
+            G.Q[b][4 * gq] = q.x; G.Q[b][4 * gq + 1] = q.y; G.Q[b][4 * gq + 2] = q.z; G.Q[b][4 * gq + 3] = q.w;
+        }
+    G.d0 = x[3 * t.i] - x[3 * t.jn];
+    G.d1 = x[3 * t.i + 1] - x[3 * t.jn + 1];
+    G.d2 = x[3 * t.i + 2] - x[3 * t.jn + 2];
+}
+
+// z1 = P_i + Q_j + w_rho * rho + W_a[type]  (X layout)
+template <int HB>
+__device__ __forceinline__ void assemble_z1(const TileGather<HB>& G, const float* __restrict__ attrt,
+                                            const float* __restrict__ wrhot, int ty, int hh, float rho,
+                                            float (&z1)[HB][16]) {
+    constexpr int H = 32 * HB;
+    const float* At = attrt + ty * H + 4 * hh;
+    const float* Rt = wrhot + 4 * hh;
+#pragma unroll
+    for (int b = 0; b < HB; ++b)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 a = *reinterpret_cast<const float4*>(At + 32 * b + 8 * gq);
+            const float4 r = *reinterpret_cast<const float4*>(Rt + 32 * b + 8 * gq);
+            z1[b][4 * gq] = G.P[b][4 * gq] + G.Q[b][4 * gq] + fmaf(r.x, rho, a.x);
+            z1[b][4 * gq + 1] = G.P[b][4 * gq + 1] + G.Q[b][4 * gq + 1] + fmaf(r.y, rho, a.y);
+            z1[b][4 * gq + 2] = G.P[b][4 * gq + 2] + G.Q[b][4 * gq + 2] + fmaf(r.z, rho, a.z);
+            z1[b][4 * gq + 3] = G.P[b][4 * gq + 3] + G.Q[b][4 * gq + 3] + fmaf(r.w, rho, a.w);
+        }
+}
+
+
+// ---- row (segment) reduction of one edge-major LDS tile -------------------------------------------
+// T[32][TS] holds one H-vector per edge of the tile, tx[32][4] one float4 per edge, rowbuf[32] the
+// row id of each edge. Lane = (row slot rsub, 16-byte quad): each lane reads whole float4s, so the
+// same LDS reads feed both the per-row sums and (optionally) fully coalesced 128-byte row stores to
+// HBM. bmask bit e = "edge e starts a new row" (wave-uniform), so segments are handled by scalar
+// control flow: the first segment continues the carried row, every later one starts at a set bit.
+// acc/accx carry the open row's partial sums (per lane: its quad, summed over its row slots);
+// flush(row) reduces them over the row slots, stores and clears.
+template <int HB, class Flush, class RowStore>
+__device__ __forceinline__ void reduce_rows_tile(const float* __restrict__ T, const float* __restrict__ tx,
+                                                 const int* __restrict__ rowbuf, unsigned bmask, int lane,
+                                                 float4& acc, float4& accx, int& cur_row, Flush&& flush,
+                                                 RowStore&& store_row) {
+    constexpr int H = 32 * HB, TS = H + 4;
+    constexpr int QPR = H / 4, RPI = 64 / QPR, NK = kTile / RPI;
+    const int quad = lane % QPR, rsub = lane / QPR;
+    float4 v[NK], dx[NK];
+    int seg[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int rl = k * RPI + rsub;
+        v[k] = *reinterpret_cast<const float4*>(T + rl * TS + 4 * quad);
+        dx[k] = *reinterpret_cast<const float4*>(tx + rl * 4);
+        store_row(rl, quad, v[k]);
+        const unsigned upto = rl == 31 ? 0xffffffffu : ((2u << rl) - 1u);
+        seg[k] = __popc(bmask & upto);
+    }
+    auto add4 = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    if (bmask == 0u) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { add4(acc, v[k]); add4(accx, dx[k]); }
+        return;
+    }
+    unsigned bm = bmask;
+    for (int s = 0;; ++s) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const float m = seg[k] == s ? 1.f : 0.f;
+            acc.x = fmaf(m, v[k].x, acc.x); acc.y = fmaf(m, v[k].y, acc.y);
+            acc.z = fmaf(m, v[k].z, acc.z); acc.w = fmaf(m, v[k].w, acc.w);
+            accx.x = fmaf(m, dx[k].x, accx.x); accx.y = fmaf(m, dx[k].y, accx.y);
+            accx.z = fmaf(m, dx[k].z, accx.z);
+        }
+        if (bm == 0u) break;            // the last segment stays open (carried to the next tile)
+        flush(cur_row);
+        const int pos = __builtin_ctz(bm);
+        bm &= bm - 1u;
+        cur_row = __builtin_amdgcn_readfirstlane(rowbuf[pos]);
+    }
+}
+
+// sum a float4 over the row slots (lanes that share a quad)
+template <int HB>
+__device__ __forceinline__ float4 sum_row_slots(float4 a) {
+    constexpr int QPR = 8 * HB;
+#pragma unroll
+    for (int o = QPR; o < 64; o <<= 1) {
+        a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64);
+        a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+    }
+    return a;
+}
+
+
+// ---- fp32 products as 6 bf16 MFMA terms ("bf16x3") -------------------------------------------------
+// x = hi + mid + lo with each part the next 8 significant bits of x (truncation: exact 24-bit
+// split), so a*b = hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi + O(2^-25 |a||b|): fp32-level
+// accuracy from v_mfma_f32_32x32x16_bf16 (fp32 accumulate), 12 bf16 MFMAs of 32 cycles per
+// 32x32x32 block instead of 16 fp32 MFMAs of 64 cycles, on the matrix cores proper.
+// k-step s of the bf16 instruction takes X-layout registers 8s..8s+7 as its 8 B-operand elements
+// (k = 8*hh + j'), and the A operand staged with the same channel order.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Bf16Parts { bf16x8 hi[2], mid[2], lo[2]; };
+
+__device__ __forceinline__ unsigned pvs_pack_hi16(float x0, float x1) {
+    // bf16 (truncated) of x0 in the low half, of x1 in the high half
+    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+
+__device__ __forceinline__ void split_bf16x3(const float (&v)[16], Bf16Parts& out) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        uint4 ph, pm, pl;
+        unsigned* h = reinterpret_cast<unsigned*>(&ph);
+        unsigned* m = reinterpret_cast<unsigned*>(&pm);
+        unsigned* l = reinterpret_cast<unsigned*>(&pl);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float x0 = v[8 * s + 2 * q], x1 = v[8 * s + 2 * q + 1];
+            const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
+            const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+            const float t0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+            const float t1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+            h[q] = pvs_pack_hi16(x0, x1);
+            m[q] = pvs_pack_hi16(r0, r1);
+            l[q] = pvs_pack_hi16(t0, t1);
+        }
+        out.hi[s] = __builtin_bit_cast(bf16x8, ph);
+        out.mid[s] = __builtin_bit_cast(bf16x8, pm);
+        out.lo[s] = __builtin_bit_cast(bf16x8, pl);
+    }
+}
+
+// Stage W[32][32] (row-major, W[out][in]) as bf16x3 A operands: dst[((part*2 + s)*64 + l)*4 .. +3]
+// (uint words) = 8 bf16 of W[l&31][ch(8s + j', l>>5)], j' = 0..7, part in {hi, mid, lo}.
+__device__ __forceinline__ void stage_weights_bf16x3(unsigned* dst, const float* __restrict__ W,
+                                                     bool transpose = false) {
+    // transpose: operand rows are the columns of W (Z = W^T V)
+    for (int i = threadIdx.x; i < 2 * 64 * 4; i += blockDim.x) {
+        const int q = i & 3, l = (i >> 2) & 63, s = i >> 8;
+        const int o = l & 31, hh = l >> 5;
+        const int k0 = xch(8 * s + 2 * q, hh), k1 = xch(8 * s + 2 * q + 1, hh);
+        const float x0 = transpose ? W[k0 * 32 + o] : W[o * 32 + k0];
+        const float x1 = transpose ? W[k1 * 32 + o] : W[o * 32 + k1];
+        const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
+        const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+        const float t0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+        const float t1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+        dst[((0 * 2 + s) * 64 + l) * 4 + q] = pvs_pack_hi16(x0, x1);
+        dst[((1 * 2 + s) * 64 + l) * 4 + q] = pvs_pack_hi16(r0, r1);
+        dst[((2 * 2 + s) * 64 + l) * 4 + q] = pvs_pack_hi16(t0, t1);
+    }
+}
+
+__device__ __forceinline__ void mfma_chain_bf16x3(const unsigned* __restrict__ Wb, int lane,
+                                                  const float (&v)[16], f32x16& acc) {
+    Bf16Parts b;
+    split_bf16x3(v, b);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wb + ((0 * 2 + s) * 64 + lane) * 4));
+        const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wb + ((1 * 2 + s) * 64 + lane) * 4));
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wb + ((2 * 2 + s) * 64 + lane) * 4));
+        // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.hi[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.lo[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.mid[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.hi[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.mid[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.hi[s], acc, 0, 0, 0);
+    }
+}
+
+
+template <typename K>
+int set_lds(K kernel, size_t lds) {
+    if (lds > 48 * 1024)
+        PVS_CHECK_HIP(hipFuncSetAttribute((const void*)kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return 0;
+}
+
+void pick_grid(int E, int* blocks, int* n_chunks, int max_blocks = 1024) {
+    // a wave gets >= ~2048 edges where the range allows; chunks of <= ~4096 edges; every wave gets
+    // the same number of chunks
+    long long b = ((long long)E + 4 * 2048 - 1) / (4 * 2048);
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    const long long waves = b * kWaves;
+    long long per_wave = ((long long)E + waves * 4096 - 1) / (waves * 4096);
+    if (per_wave < 1) per_wave = 1;
+    *blocks = (int)b;
+    *n_chunks = (int)(waves * per_wave);
+}
+
+
+}  // namespace

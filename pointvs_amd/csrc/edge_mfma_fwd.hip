@@ -1,0 +1,269 @@
+// MFMA edge kernels for H = 32*HB (HB = 1, 2): the fast path of EGNNLayer's per-edge work.
+//
+// Tile = 32 consecutive CSR-sorted edges per wavefront. Activations live in the "X layout" of
+// v_mfma_f32_32x32x2_f32 accumulators: lane l = (edge slot j = l&31, half hh = l>>5), register t
+// of channel block b holds channel 32b + (t&3) + 8(t>>2) + 4hh. An accumulator in that layout is
+// directly the B operand of the next product over channels (k pairs {ch(t,0), ch(t,1)}), so the
+// edge-MLP chain  z1 -> SiLU -> W2 -> SiLU -> Wc1 -> SiLU  needs no lane movement; the weights
+// are staged once per workgroup in LDS in A-operand order (one ds_read_b32 per MFMA).
+// The first edge-MLP layer is algebraically split per node (P_i + Q_j + w_rho*rho + W_a[type]),
+// so the per-edge MFMA work is the HxH products only.
+// Per-row sums (the reference's scatter-sum / scatter-mean, egnn_satorras.py:332-347): each wave
+// owns a row-aligned, edge-balanced chunk of the CSR; a tile's weighted messages go through a
+// per-wave LDS tile and are re-read channel-per-lane, where segment boundaries are wave-uniform
+// scalars: no atomics, fixed summation order, bitwise reproducible.
+//
+// Layout maps validated lane-by-lane in tools/mfma_layout_check.py.
+#include "edge_mfma_common.h"
+
+namespace {
+
+template <int HB, bool BF16X3>
+__global__ void __launch_bounds__(kThreads)
+k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdIO io, int n_chunks,
+                int e_lo, int e_hi) {
+    constexpr int H = 32 * HB;
+    constexpr int TS = H + 4;   // tile row stride (floats): conflict-free b128 writes / b32 reads
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int kWeightWords = BF16X3 ? 2 * 6 * 64 * 4 : 2 * H * H;
+    float* W2s = smem;
+    float* Wc1s = W2s + H * H;
+    float* b2t = smem + kWeightWords;
+    float* bc1t = b2t + H;
+    float* wc2t = bc1t + H;
+    float* wat = wc2t + H;
+    float* wrhot = wat + H;
+    float* attrt = wrhot + H;                            // [PVS_MAX_EDGE_ATTR][H]
+    float* wave_base = attrt + PVS_MAX_EDGE_ATTR * H;    // per wave: tile[32][TS], tx[32][4], rowbuf[32]
+    constexpr int kWaveFloats = kTile * TS + kTile * 4 + kTile;
+
+    const bool upd = flags & PVS_UPDATE_COORDS;
+    const bool eatt = flags & PVS_EDGE_ATTENTION;
+    const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
+
+    // BF16X3 (H = 32 only): each matrix takes 3 parts x 2 k-steps x 64 lanes x 16 B = 6 KB
+    static_assert(!BF16X3 || HB == 1, "bf16x3 variant is built for H = 32");
+    unsigned* W2b = reinterpret_cast<unsigned*>(W2s);
+    unsigned* Wc1b = W2b + 6 * 64 * 4;
+    if constexpr (BF16X3) {
+        stage_weights_bf16x3(W2b, w.w2);
+        if (upd) stage_weights_bf16x3(Wc1b, w.wc1);
+    } else {
+        stage_weights<HB>(W2s, w.w2, false);
+        if (upd) stage_weights<HB>(Wc1s, w.wc1, false);
+    }
+    for (int c = threadIdx.x; c < H; c += kThreads) {
+        b2t[c] = w.b2[c];
+        bc1t[c] = upd ? w.bc1[c] : 0.f;
+        wc2t[c] = upd ? w.wc2[c] : 0.f;
+        wat[c] = eatt ? w.wa[c] : 0.f;
+        wrhot[c] = w.w1[c * w.ld1 + w.off_rho];
+        for (int t = 0; t < PVS_MAX_EDGE_ATTR; ++t)
+            attrt[t * H + c] = t < w.n_attr ? w.w1[c * w.ld1 + w.off_rho + 1 + t] : 0.f;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    float* tile = wave_base + wv * kWaveFloats;
+    float* tx = tile + kTile * TS;
+    int* rowbuf = reinterpret_cast<int*>(tx + kTile * 4);
+    const float bac = eatt ? w.ba[0] : 0.f;
+    float gate = 1.f;
+    if (eres && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
+        gate = w.edge_gate[0];
+        if (flags & PVS_GATED_RESIDUAL) gate = fmaxf(gate, 0.f);
+    }
+
+    const int total_waves = gridDim.x * kWaves;
+    for (int chunk = pvs_xcd_block(blockIdx.x, gridDim.x) * kWaves + wv; chunk < n_chunks; chunk += total_waves) {
+        const int e_begin = chunk_begin(g, chunk, n_chunks, e_lo, e_hi);
+        const int e_end = chunk_begin(g, chunk + 1, n_chunks, e_lo, e_hi);
+        int cur_row = -1;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accx = acc;   // open row: lane = (row slot, quad)
+        constexpr int QPR = H / 4;
+        const int quad = lane % QPR, rsub = lane / QPR;
+
+        auto flush = [&](int row_id) {
+            if (row_id >= 0) {
+                const float4 tot = sum_row_slots<HB>(acc);
+                if (rsub == 0) *reinterpret_cast<float4*>(io.Magg + (size_t)row_id * H + 4 * quad) = tot;
+                if (upd) {
+                    const float4 tx4 = sum_row_slots<HB>(accx);
+                    if (lane == 0) {
+                        const float inv = g.inv_deg[row_id];
+                        io.x_out[3 * row_id] = io.x[3 * row_id] + tx4.x * inv;
+                        io.x_out[3 * row_id + 1] = io.x[3 * row_id + 1] + tx4.y * inv;
+                        io.x_out[3 * row_id + 2] = io.x[3 * row_id + 2] + tx4.z * inv;
+                    }
+                }
+            }
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            accx = acc;
+        };
+
+        // software pipeline: the gathers of tile t+1 are issued while tile t is being reduced
+        TileIdx I = load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_begin, e_begin, e_end, j);
+        TileGather<HB> G;
+        if (e_begin < e_end) gather_tile<HB>(io.PQ, io.x, I, hh, G);
+        for (int e0 = e_begin; e0 < e_end; e0 += kTile) {
+            const int e_next = (e0 + kTile < e_end) ? e0 + kTile : e0;
+            const TileIdx In = load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_next, e_begin, e_end, j);
+            const int e = I.e, ee = I.ee, i = I.i;
+            const bool valid = I.valid;
+            const unsigned long long ball = __ballot(valid && hh == 0 && i != I.prev_row);
+            const unsigned bmask = (unsigned)ball;
+#if !PVS_PREFETCH
+            gather_tile<HB>(io.PQ, io.x, I, hh, G);
+#endif
+            const float d0 = G.d0, d1 = G.d1, d2 = G.d2;
+            const float rho = d0 * d0 + d1 * d1 + d2 * d2;
+
+            // ---- first layer: z1 = P_i + Q_j + w_rho*rho + W_a[type]; a1 = SiLU(z1) ----
+            float a1[HB][16];
+            assemble_z1<HB>(G, attrt, wrhot, I.ty, hh, rho, a1);
+#pragma unroll
+            for (int b = 0; b < HB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a1[b][r] = pvs_silu(a1[b][r]);
+            // ---- second layer on the matrix cores: m = SiLU(W2 a1 + b2) ----
+            float m[HB][16];
+            {
+                f32x16 acc2[HB];
+                float bias[HB][16];
+                load_tab<HB>(b2t, hh, bias);
+#pragma unroll
+                for (int b = 0; b < HB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[b][r] = bias[b][r];
+                if constexpr (BF16X3) mfma_chain_bf16x3(W2b, lane, a1[0], acc2[0]);
+                else mfma_chain<HB>(W2s, lane, a1, acc2, flags & kAblNoMfma);
+#pragma unroll
+                for (int b = 0; b < HB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m[b][r] = pvs_silu(acc2[b][r]);
+            }
+            if (eres) {
+#pragma unroll
+                for (int b = 0; b < HB; ++b)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const float4 mp = *reinterpret_cast<const float4*>(
+                            io.m_prev + (size_t)ee * H + 32 * b + 8 * gq + 4 * hh);
+                        const float mpv[4] = {mp.x, mp.y, mp.z, mp.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float& mv = m[b][4 * gq + q];
+                            if (flags & PVS_REZERO) mv = mpv[q] + gate * mv;
+                            else if (flags & PVS_GATED_RESIDUAL) mv = gate * mv + (1.f - gate) * mpv[q];
+                            else mv = mv + mpv[q];
+                        }
+                    }
+            }
+            if (io.m_out && valid) {
+#pragma unroll
+                for (int b = 0; b < HB; ++b)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+                        *reinterpret_cast<float4*>(io.m_out + (size_t)e * H + 32 * b + 8 * gq + 4 * hh) =
+                            make_float4(m[b][4 * gq], m[b][4 * gq + 1], m[b][4 * gq + 2], m[b][4 * gq + 3]);
+            }
+            // ---- coordinate branch: s = wc2 . SiLU(Wc1 m + bc1) ----
+            float s = 0.f;
+            if (upd) {
+                f32x16 accc[HB];
+                float bias[HB][16];
+                load_tab<HB>(bc1t, hh, bias);
+#pragma unroll
+                for (int b = 0; b < HB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accc[b][r] = bias[b][r];
+                if constexpr (BF16X3) mfma_chain_bf16x3(Wc1b, lane, m[0], accc[0]);
+                else mfma_chain<HB>(Wc1s, lane, m, accc, flags & kAblNoMfma);
+                float q[HB][16];
+#pragma unroll
+                for (int b = 0; b < HB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) q[b][r] = pvs_silu(accc[b][r]);
+                s = dot_tab<HB>(wc2t, hh, q);
+                if (flags & PVS_TANH) s = pvs_tanh(s);
+                if (flags & PVS_NORMALIZE) s = s / (sqrtf(rho) + 1e-8f);
+            }
+            // ---- attention gate ----
+            float a = 1.f;
+            if (eatt) {
+                a = pvs_att_act(att_act, dot_tab<HB>(wat, hh, m) + bac);
+                if (valid && hh == 0) io.att_out[e] = a;
+            }
+            // ---- hand the weighted messages to the channel-per-lane reduction ----
+            const float wgt = valid ? a : 0.f;
+#pragma unroll
+            for (int b = 0; b < HB; ++b)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *reinterpret_cast<float4*>(tile + j * TS + 32 * b + 8 * gq + 4 * hh) =
+                        make_float4(wgt * m[b][4 * gq], wgt * m[b][4 * gq + 1], wgt * m[b][4 * gq + 2],
+                                    wgt * m[b][4 * gq + 3]);
+            if (hh == 0) {
+                const float sv = valid ? s : 0.f;
+                *reinterpret_cast<float4*>(tx + j * 4) = make_float4(d0 * sv, d1 * sv, d2 * sv, 0.f);
+                rowbuf[j] = i;
+            }
+#if PVS_PREFETCH
+            gather_tile<HB>(io.PQ, io.x, In, hh, G);   // next tile's rows fly during the reduction
+#endif
+            I = In;
+            pvs_wave_lds_sync();
+            if (!(flags & kAblNoReduce))
+                reduce_rows_tile<HB>(tile, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
+                                     [](int, int, const float4&) {});
+            pvs_wave_lds_sync();
+        }
+        flush(cur_row);
+    }
+}
+
+
+
+}  // namespace
+
+int pvs_edge_mfma_supported(int H, uint32_t flags) {
+    if (H != 32 && H != 64) return 0;
+    if ((flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT)) return 0;   // generic path
+    return 1;
+}
+
+int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,
+                             int att_act, const PvsEdgeFwdIO& io) {
+    PVS_REQUIRE(w.n_attr <= PVS_MAX_EDGE_ATTR, "edge_attr classes %d > %d", w.n_attr,
+                PVS_MAX_EDGE_ATTR);
+    // rows without edges are never flushed: M = 0, x_out = x
+    PVS_CHECK_HIP(hipMemsetAsync(io.Magg, 0, sizeof(float) * (size_t)g.n_nodes * H, s));
+    if (flags & PVS_UPDATE_COORDS)
+        PVS_CHECK_HIP(hipMemcpyAsync(io.x_out, io.x, sizeof(float) * 3 * (size_t)g.n_nodes,
+                                     hipMemcpyDeviceToDevice, s));
+    if (g.n_edges == 0) return 0;
+    int blocks, n_chunks;
+    pick_grid(g.n_edges, &blocks, &n_chunks);
+    PvsProfScope prof(s, PVS_PROF_EDGE_FWD);
+    const int HB = H / 32;
+    const char* bf = getenv("PVS_EGNN_BF16X3");
+    const bool bf16x3 = !(bf && bf[0] == '0') && H == 32;   // default for H = 32 (PVS_EGNN_BF16X3=0: fp32 MFMA)
+    const size_t words = (bf16x3 ? (size_t)2 * 6 * 64 * 4 : (size_t)2 * H * H) +
+                         (5 + PVS_MAX_EDGE_ATTR) * H +
+                         (size_t)kWaves * (kTile * (H + 4) + kTile * 4 + kTile);
+    const size_t lds = words * sizeof(float);
+    if (HB == 1 && bf16x3) {
+        if (set_lds(k_edge_fwd_mfma<1, true>, lds)) return -2;
+        k_edge_fwd_mfma<1, true><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
+    } else if (HB == 1) {
+        if (set_lds(k_edge_fwd_mfma<1, false>, lds)) return -2;
+        k_edge_fwd_mfma<1, false><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
+    } else {
+        if (set_lds(k_edge_fwd_mfma<2, false>, lds)) return -2;
+        k_edge_fwd_mfma<2, false><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
+    }
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
