@@ -23,3 +23,22 @@ int pvs_launch_colreduce(hipStream_t s, int mode, float* out, const float* A, in
 // out[map(o)] (=|+=) sum_g slabs[g*width + o], o < width; map(o) = (o / inner) * ldo + o % inner
 int pvs_launch_reduce_slabs(hipStream_t s, float* out, int ldo, int inner, const float* slabs,
                             int n_slabs, int width, bool accumulate);
+
+// All node-level weight gradients of one EGNNLayer backward in one pass over the N rows (H = 32, 64):
+//   node_w2 = g_o^T u, node_w1 = g_y1^T [h | Magg], edge_w1[:, P/Q columns] = [gP | gQ]^T h and the
+//   bias gradients node_b2 / node_b1 / edge_b1 = column sums of g_o / g_y1 / gP.
+// Replaces five tsgemm + three colreduce launches (and their slab reductions) by one product
+// kernel, one slab reduction and one scatter. slabs: pvs_node_wgrads_slab_floats(N, H) floats.
+struct PvsNodeWgradIn {
+    const float *g_o, *g_y1, *gPQ;   // [N,H], [N,H], [N,2H] (P part | Q part)
+    const float *u, *h, *Magg;       // [N,H] each
+};
+struct PvsNodeWgradOut {
+    float *node_w2, *node_w1, *edge_w1;     // required
+    float *node_b2, *node_b1, *edge_b1;     // NULL to skip
+    int ld1, off_q, perm;                   // edge_w1 row stride, column of the Q block, P/Q share columns
+};
+int pvs_node_wgrads_supported(int H);
+size_t pvs_node_wgrads_slab_floats(int N, int H);
+int pvs_launch_node_wgrads(hipStream_t s, int H, int N, const PvsNodeWgradIn& in, const PvsNodeWgradOut& out,
+                           float* slabs);

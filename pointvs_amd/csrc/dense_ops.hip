@@ -322,6 +322,112 @@ k_tsgemm_mfma(float* __restrict__ slabs, const float* __restrict__ A, int lda,
     }
 }
 
+// ---- fused node-level weight gradients (see dense_ops.h) ----
+// Products (A, B): (g_o, u) (g_y1, h) (g_y1, Magg) (gP, h) (gQ, h); column sums of g_o, g_y1, gP.
+// blockIdx.y = 32x32 sub-block (bo, bi) of every product; per wave 5 accumulators; rows as the MFMA
+// k index, operands straight from row-major HBM (as k_tsgemm_mfma).
+constexpr int kWgProducts = 5, kWgBias = 3;
+constexpr int kWgSlab = kWgProducts * 1024 + kWgBias * 32;   // floats per (row block, sub-block)
+constexpr int kWgRowsPerBlock = 256;
+
+template <int HB>
+__global__ void __launch_bounds__(kThreads)
+k_node_wgrads(float* __restrict__ slabs, PvsNodeWgradIn in, int N) {
+    constexpr int H = 32 * HB;
+    __shared__ float red[kWgSlab];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int bo = blockIdx.y / HB, bi = blockIdx.y % HB;
+    const int r0 = blockIdx.x * kWgRowsPerBlock;
+    const int r1 = min(N, r0 + kWgRowsPerBlock);
+    const float* A0 = in.g_o + 32 * bo + j;
+    const float* A1 = in.g_y1 + 32 * bo + j;
+    const float* A2 = in.gPQ + 32 * bo + j;
+    const float* A3 = in.gPQ + H + 32 * bo + j;
+    const float* B0 = in.u + 32 * bi + j;
+    const float* B1 = in.h + 32 * bi + j;
+    const float* B2 = in.Magg + 32 * bi + j;
+    f32x16_t acc[kWgProducts];
+#pragma unroll
+    for (int p = 0; p < kWgProducts; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f;
+    constexpr int UN = 4;
+    for (int n0 = r0 + wv * 2 * UN; n0 < r1; n0 += kThreads / 64 * 2 * UN) {
+        float a0[UN], a1[UN], a2[UN], a3[UN], b0[UN], b1[UN], b2[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int n = n0 + 2 * u + hh;
+            const bool ok = n < r1;
+            const size_t nh = (size_t)n * H, n2h = (size_t)n * 2 * H;
+            a0[u] = ok ? A0[nh] : 0.f;
+            a1[u] = ok ? A1[nh] : 0.f;
+            a2[u] = ok ? A2[n2h] : 0.f;
+            a3[u] = ok ? A3[n2h] : 0.f;
+            b0[u] = ok ? B0[nh] : 0.f;
+            b1[u] = ok ? B1[nh] : 0.f;
+            b2[u] = ok ? B2[nh] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b2[u], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[u], b1[u], acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[u], b1[u], acc[4], 0, 0, 0);
+            bs0 += a0[u]; bs1 += a1[u]; bs2 += a2[u];
+        }
+    }
+    bs0 += __shfl_xor(bs0, 32, 64); bs1 += __shfl_xor(bs1, 32, 64); bs2 += __shfl_xor(bs2, 32, 64);
+    for (int i = threadIdx.x; i < kWgSlab; i += kThreads) red[i] = 0.f;
+    __syncthreads();
+    for (int turn = 0; turn < kThreads / 64; ++turn) {   // fixed wave order
+        if (wv == turn) {
+#pragma unroll
+            for (int p = 0; p < kWgProducts; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    red[(p * 32 + c) * 32 + j] += acc[p][r];
+                }
+            if (hh == 0) {
+                red[kWgProducts * 1024 + j] += bs0;
+                red[kWgProducts * 1024 + 32 + j] += bs1;
+                red[kWgProducts * 1024 + 64 + j] += bs2;
+            }
+        }
+        __syncthreads();
+    }
+    float* dst = slabs + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * kWgSlab;
+    for (int i = threadIdx.x; i < kWgSlab; i += kThreads) dst[i] = red[i];
+}
+
+template <int HB>
+__global__ void k_node_wgrads_scatter(const float* __restrict__ gsum, PvsNodeWgradOut out) {
+    constexpr int H = 32 * HB;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (int i = tid; i < H * H; i += stride) {
+        const int c = i / H, k = i % H;
+        const float* b = gsum + (size_t)((c >> 5) * HB + (k >> 5)) * kWgSlab + (c & 31) * 32 + (k & 31);
+        out.node_w2[(size_t)c * H + k] = b[0];
+        out.node_w1[(size_t)c * 2 * H + k] = b[1024];
+        out.node_w1[(size_t)c * 2 * H + H + k] = b[2 * 1024];
+        if (out.perm) {
+            out.edge_w1[(size_t)c * out.ld1 + k] = b[3 * 1024] + b[4 * 1024];
+        } else {
+            out.edge_w1[(size_t)c * out.ld1 + k] = b[3 * 1024];
+            out.edge_w1[(size_t)c * out.ld1 + out.off_q + k] = b[4 * 1024];
+        }
+    }
+    for (int c = tid; c < H; c += stride) {
+        const float* b = gsum + (size_t)((c >> 5) * HB) * kWgSlab + kWgProducts * 1024 + (c & 31);
+        if (out.node_b2) out.node_b2[c] = b[0];
+        if (out.node_b1) out.node_b1[c] = b[32];
+        if (out.edge_b1) out.edge_b1[c] = b[64];
+    }
+}
+
 int grid_for(long long work_items, int per_block) {
     long long b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -409,6 +515,34 @@ int pvs_launch_tsgemm_tn(hipStream_t s, float* out, int ldo, const float* A, int
         k_tsgemm_tn<32><<<blocks, kThreads, lds, s>>>(slabs, A, lda, B, ldb, N, C, K, rpb);
     PVS_CHECK_LAUNCH();
     return pvs_launch_reduce_slabs(s, out, ldo, K, slabs, blocks, CK, accumulate);
+}
+
+int pvs_node_wgrads_supported(int H) { return H == 32 || H == 64; }
+
+static int wg_row_blocks(int N) { return (N + kWgRowsPerBlock - 1) / kWgRowsPerBlock; }
+
+size_t pvs_node_wgrads_slab_floats(int N, int H) {
+    const int hb = H / 32 > 0 ? H / 32 : 1;
+    // per-row-block partials + the reduced sums behind them
+    return ((size_t)wg_row_blocks(N) + 1) * hb * hb * kWgSlab;
+}
+
+int pvs_launch_node_wgrads(hipStream_t s, int H, int N, const PvsNodeWgradIn& in, const PvsNodeWgradOut& out,
+                           float* slabs) {
+    PVS_REQUIRE(pvs_node_wgrads_supported(H), "node_wgrads: H = %d unsupported", H);
+    PVS_REQUIRE(out.node_w2 && out.node_w1 && out.edge_w1, "node_wgrads: NULL weight gradient");
+    const int hb = H / 32, rb = wg_row_blocks(N);
+    const int width = hb * hb * kWgSlab;
+    float* gsum = slabs + (size_t)rb * width;
+    if (hb == 1) k_node_wgrads<1><<<dim3(rb, 1), kThreads, 0, s>>>(slabs, in, N);
+    else k_node_wgrads<2><<<dim3(rb, 4), kThreads, 0, s>>>(slabs, in, N);
+    PVS_CHECK_LAUNCH();
+    k_reduce_slabs<<<(width + 31) / 32, kThreads, 0, s>>>(gsum, width, width, slabs, rb, width, 1.0f, 0);
+    PVS_CHECK_LAUNCH();
+    if (hb == 1) k_node_wgrads_scatter<1><<<4, kThreads, 0, s>>>(gsum, out);
+    else k_node_wgrads_scatter<2><<<16, kThreads, 0, s>>>(gsum, out);
+    PVS_CHECK_LAUNCH();
+    return 0;
 }
 
 int pvs_launch_colreduce(hipStream_t s, int mode, float* out, const float* A, int lda, const float* B,

@@ -142,7 +142,7 @@ size_t carve_fwd(PvsArena& a, const Dims& m, FwdWs* w) {
 
 struct BwdWs {
     float *PQ, *y1, *u, *o, *g_o, *g_u, *gM, *t1, *tg, *gl, *gxagg, *softD, *gPQ, *gz1, *gd, *gx_row;
-    float *eslabs, *gsum, *dslabs, *S1, *S2, *coefs, *gvec, *nslabs, *nsum;
+    float *eslabs, *gsum, *dslabs, *S1, *S2, *coefs, *gvec, *nslabs, *nsum, *wslabs;
 };
 
 size_t carve_bwd(PvsArena& a, const Dims& m, BwdWs* w) {
@@ -174,6 +174,7 @@ size_t carve_bwd(PvsArena& a, const Dims& m, BwdWs* w) {
     t.gvec = a.take<float>(m.H);
     t.nslabs = a.take<float>((size_t)kMaxStages * 512 * 4 * m.H);
     t.nsum = a.take<float>(4 * (size_t)m.H);
+    t.wslabs = a.take<float>(pvs_node_wgrads_supported(m.H) ? pvs_node_wgrads_slab_floats(m.N, m.H) : 4);
     if (w) *w = t;
     return a.off;
 }
@@ -329,6 +330,9 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     const bool gn = F & PVS_GRAPHNORM, natt = F & PVS_NODE_ATTENTION;
     const bool gates = (F & PVS_RESIDUAL) && (F & (PVS_REZERO | PVS_GATED_RESIDUAL));
     const bool coord_bwd = (F & PVS_UPDATE_COORDS) && g_x_out;
+    // all node-level weight gradients in one pass at the end (H = 32, 64, the usual full set of grads)
+    const bool fused_wgrads = pvs_node_wgrads_supported(H) && gr.node_w2 && gr.node_w1 && gr.edge_w1 &&
+                              !getenv("PVS_EGNN_SPLIT_WGRADS");
 
     // ---- node-level forward: PQ, y1, o were kept by the forward; u = SiLU(GN(y1)) is elementwise ----
     PVS_TRY(pvs_node_tail_fwd(s, sy1, stats, nw, N, H, w.u));
@@ -352,9 +356,9 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     // o = u Wn2^T + bn2
     PVS_TRY(pvs_launch_linear(s, w.g_u, H, w.g_o, H, p->node_w2, 1, H, nullptr, nullptr, 0, nullptr, 0,
                               0, N, H, 0, H, false));
-    if (gr.node_w2)
+    if (gr.node_w2 && !fused_wgrads)
         PVS_TRY(pvs_launch_tsgemm_tn(s, gr.node_w2, H, w.g_o, H, w.u, H, N, H, H, w.dslabs, false));
-    if (gr.node_b2)
+    if (gr.node_b2 && !fused_wgrads)
         PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.node_b2, w.g_o, H, nullptr, 0, nullptr, N, H,
                                      1.f, w.dslabs, false));
     // u = SiLU(GN(y1)) ; g_u becomes g_yn then g_y1 in place
@@ -374,12 +378,12 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
                               0, 0, N, H, 0, H, true));
     PVS_TRY(pvs_launch_linear(s, w.gM, H, g_y1, H, p->node_w1 + H, 1, 2 * H, nullptr, nullptr, 0,
                               nullptr, 0, 0, N, H, 0, H, false));
-    if (gr.node_w1) {
+    if (gr.node_w1 && !fused_wgrads) {
         PVS_TRY(pvs_launch_tsgemm_tn(s, gr.node_w1, 2 * H, g_y1, H, h, H, N, H, H, w.dslabs, false));
         PVS_TRY(pvs_launch_tsgemm_tn(s, gr.node_w1 + H, 2 * H, g_y1, H, Magg, H, N, H, H, w.dslabs,
                                      false));
     }
-    if (gr.node_b1)
+    if (gr.node_b1 && !fused_wgrads)
         PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.node_b1, g_y1, H, nullptr, 0, nullptr, N, H,
                                      1.f, w.dslabs, false));
 
@@ -463,13 +467,22 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
                               nullptr, 0, 0, N, H, 0, H, true));
     PVS_TRY(pvs_launch_linear(s, g_h, H, w.gPQ + H, 2 * H, p->edge_w1 + m.off_q, 1, m.ld1, nullptr,
                               nullptr, 0, nullptr, 0, 0, N, H, 0, H, true));
-    if (gr.edge_w1) {
+    if (fused_wgrads) {
+        PvsNodeWgradIn wi;
+        wi.g_o = w.g_o; wi.g_y1 = g_y1; wi.gPQ = w.gPQ; wi.u = w.u; wi.h = h; wi.Magg = Magg;
+        PvsNodeWgradOut wo;
+        wo.node_w2 = gr.node_w2; wo.node_w1 = gr.node_w1; wo.edge_w1 = gr.edge_w1;
+        wo.node_b2 = gr.node_b2; wo.node_b1 = gr.node_b1; wo.edge_b1 = gr.edge_b1;
+        wo.ld1 = m.ld1; wo.off_q = m.off_q; wo.perm = m.perm ? 1 : 0;
+        PVS_TRY(pvs_launch_node_wgrads(s, H, N, wi, wo, w.wslabs));
+    }
+    if (gr.edge_w1 && !fused_wgrads) {
         PVS_TRY(pvs_launch_tsgemm_tn(s, gr.edge_w1, m.ld1, w.gPQ, 2 * H, h, H, N, H, H, w.dslabs,
                                      false));
         PVS_TRY(pvs_launch_tsgemm_tn(s, gr.edge_w1 + m.off_q, m.ld1, w.gPQ + H, 2 * H, h, H, N, H, H,
                                      w.dslabs, m.perm));
     }
-    if (gr.edge_b1)
+    if (gr.edge_b1 && !fused_wgrads)
         PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.edge_b1, w.gPQ, 2 * H, nullptr, 0, nullptr,
                                      N, H, 1.f, w.dslabs, false));
     k_finalize_edge_grads<<<4, 256, 0, s>>>(w.gsum, L, H, m.A, m.ld1, m.off_rho, gr,
