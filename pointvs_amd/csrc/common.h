@@ -31,6 +31,18 @@ void pvs_set_error(const char* fmt, ...);
 
 static inline size_t pvs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// 16-byte store / load of data that is written once and read once by a later kernel (per-edge
+// gradients): non-temporal, so the stream does not displace the gathered node rows in L2
+// (measured: cfg2 backward + column gather -0.16 ms/step).
+typedef float pvs_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pvs_store_nt(float* p, const float4& v) {
+    __builtin_nontemporal_store(pvs_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<pvs_f4*>(p));
+}
+__device__ __forceinline__ float4 pvs_load_nt(const float* p) {
+    const pvs_f4 v = __builtin_nontemporal_load(reinterpret_cast<const pvs_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // Bump allocator over the caller's workspace (256-B aligned pieces).
 struct PvsArena {
     char* base;

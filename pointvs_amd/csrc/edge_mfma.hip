@@ -371,8 +371,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 if (hh == 0) {
                     *reinterpret_cast<float4*>(tx + j * 4) = make_float4(gd0, gd1, gd2, 0.f);
                     if (valid)
-                        *reinterpret_cast<float4*>(io.gd + (size_t)e * 4) =
-                            make_float4(gd0, gd1, gd2, pvs_pack_rho_type(rho, ty));
+                        pvs_store_nt(io.gd + (size_t)e * 4, make_float4(gd0, gd1, gd2, pvs_pack_rho_type(rho, ty)));
                 }
                 pvs_wave_lds_sync();      // T2 = g_z2 visible; T1 (m) no longer needed
                 // ---- W2 weight gradient + g_b2 ----
@@ -405,8 +404,8 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 if (!(flags & kAblNoReduce))
                     reduce_rows_tile<HB>(T1, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
                                          [&](int rl, int q, const float4& v) {
-                                             if (e0 + rl < e_end)
-                                                 *reinterpret_cast<float4*>(io.gz1 + (size_t)(e0 + rl) * H + 4 * q) = v;
+                                             if (e0 + rl < e_end)   // streamed once: non-temporal
+                                                 pvs_store_nt(io.gz1 + (size_t)(e0 + rl) * H + 4 * q, v);
                                          });
                 I = In;
                 pvs_wave_lds_sync();
@@ -886,8 +885,7 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                     const int rl = k * 8 + rsub;
                     v[k] = *reinterpret_cast<const float4*>(T1 + rl * TS + co + 4 * quad);
                     dx[k] = *reinterpret_cast<const float4*>(tx + rl * 4);
-                    if (e0 + rl < e_end)
-                        *reinterpret_cast<float4*>(io.gz1 + (size_t)(e0 + rl) * H + co + 4 * quad) = v[k];
+                    if (e0 + rl < e_end) pvs_store_nt(io.gz1 + (size_t)(e0 + rl) * H + co + 4 * quad, v[k]);
                     const unsigned upto = rl == 31 ? 0xffffffffu : ((2u << rl) - 1u);
                     seg[k] = __popc(bmask & upto);
                 }

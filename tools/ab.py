@@ -8,7 +8,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 libs = [a.split('=', 1) for a in sys.argv[1:] if '=' in a]
-rounds = 3
+rounds = int(os.environ.get("AB_ROUNDS", "3"))
 res = {n: [] for n, _ in libs}
 for r in range(rounds):
     for name, path in libs:
