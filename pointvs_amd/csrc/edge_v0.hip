@@ -433,7 +433,10 @@ k_node_gather(PvsGraph g, const float* __restrict__ gz1, const float* __restrict
               int n_lo, int n_hi) {
     constexpr int QPR = H / 4;
     constexpr int EPW = 64 / QPR;
-    constexpr int UN = 4;
+#ifndef PVS_NG_UN
+#define PVS_NG_UN 8
+#endif
+    constexpr int UN = PVS_NG_UN;
     __shared__ float red[kWaves][4 * H];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int quad = lane % QPR, sub = lane / QPR;
@@ -589,7 +592,10 @@ int pvs_launch_edge_bwd_v0(hipStream_t s, int H, const PvsGraph& g, const PvsEdg
 
 int pvs_node_gather_blocks(int N) {
     int b = pvs_edge_v0_blocks(N);
-    return b > 512 ? 512 : b;
+#ifndef PVS_NG_BLOCKS
+#define PVS_NG_BLOCKS 512
+#endif
+    return b > PVS_NG_BLOCKS ? PVS_NG_BLOCKS : b;
 }
 
 // Column gather over the node range [n_lo, n_hi) (whole batch or one segment of whole graphs).
