@@ -117,6 +117,10 @@ def main():
     ap.add_argument('--infer', action='store_true',
                     help='forward-only (torch.no_grad) throughput: the virtual-screening shape of '
                          'BASELINE config 5; not the headline metric')
+    ap.add_argument('--build-graph', action='store_true',
+                    help='build the radius graph on the GPU from the coordinates every step '
+                         '(pvs_radius_graph_*, SURVEY §8f row 1) instead of parsing the resident int64 '
+                         'COO + one-hot; not the headline configuration (one host sync per step)')
     ap.add_argument('--graph', type=int, default=int(os.environ.get('PVS_BENCH_GRAPH', '0')),
                     help='1: capture the whole training step in a hipGraph and time replays')
     args = ap.parse_args()
@@ -151,7 +155,7 @@ def main():
     torch.manual_seed(0)
     model = SartorrasEGNN(Path('/tmp/pvs_bench'), 2e-3, 1e-4, silent=True, **cfg['model']).train()
     params = list(model.parameters())
-    use_graph = bool(args.graph) and world == 1
+    use_graph = bool(args.graph) and world == 1 and not args.build_graph
     if use_graph:   # same Adam, step counter kept on the device so the step can be captured
         model.optimiser = torch.optim.Adam(params, lr=2e-3, weight_decay=1e-4, capturable=True)
     reducer = GradAllReducer(params) if world > 1 else None
@@ -165,7 +169,12 @@ def main():
         with torch.no_grad():
             return model(batch).reshape(-1).sum()
 
+    if args.build_graph:
+        from pointvs_amd.radius_graph import attach_radius_graph
+
     def step():
+        if args.build_graph:
+            attach_radius_graph(batch, cfg['graph']['edge_radius'])
         if args.infer:
             return infer_step()
         y_pred = model(batch).reshape(-1)

@@ -134,6 +134,42 @@ int pvs_graph_prepare(const int64_t* edge_index, const int64_t* edge_attr, int32
                       int32_t* colptr, int32_t* cedge, float* inv_deg, int32_t* status,
                       void* workspace, size_t workspace_bytes, pvs_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Radius graph straight from coordinates: generate_edges of the reference
+ * (preprocessing.py:68-155, the prune=False body) fused with the COO -> CSR/CSC step, so the
+ * int64 edge list and the int64 one-hot never exist. Same result, array for array, as
+ * pvs_graph_prepare on the reference's own output for the same atoms:
+ *   inter block: pairs with 1e-7 < d < inter_radius and bp_i != bp_j (class 1), row-major;
+ *   intra block: all pairs with 1e-7 < d < intra_radius (class 2 if both bp == 1, else 0), row-major;
+ *   perm = position of each CSR-sorted edge in [inter block | intra block] (the reference's order).
+ * d is the float64 cdist distance (same operation order, no FMA): identical `<` decisions.
+ *   pos [N,3] fp32, bp [N] uint8 (0 ligand / 1 receptor), graph_ptr [B+1] int32 node offsets of the
+ *   batch's graphs (pairs are only formed inside a graph).
+ * Two steps because E is data dependent: _count runs the O(n_g^2) distance tests once, leaves a
+ * 64-bit neighbour mask per (row, 64-column chunk) in `state` and fills rowptr/inter_ptr/intra_ptr
+ * ([N+1] each); the caller reads rowptr[N] = E back, allocates, and _fill expands the masks.
+ * max_graph_nodes = node count of the largest graph of the batch (sizes the masks).
+ */
+size_t pvs_radius_graph_state_bytes(int32_t n_nodes, int32_t n_graphs, int32_t max_graph_nodes);
+size_t pvs_radius_graph_workspace_bytes(int32_t n_nodes, int32_t n_graphs, int32_t n_edges);
+int pvs_radius_graph_count(const float* pos, const uint8_t* bp, const int32_t* graph_ptr, int32_t n_graphs,
+                           int32_t n_nodes, int32_t max_graph_nodes, double inter_radius, double intra_radius,
+                           int32_t* rowptr, int32_t* inter_ptr, int32_t* intra_ptr,
+                           void* state, size_t state_bytes, pvs_stream_t stream);
+int pvs_radius_graph_fill(const uint8_t* bp, const int32_t* graph_ptr, int32_t n_graphs, int32_t n_nodes,
+                          int32_t max_graph_nodes, int32_t n_edges,
+                          const int32_t* rowptr, const int32_t* inter_ptr, const int32_t* intra_ptr,
+                          int32_t* row, int32_t* col, uint8_t* etype, int32_t* perm,
+                          int32_t* colptr, int32_t* cedge, float* inv_deg,
+                          const void* state, size_t state_bytes,
+                          void* workspace, size_t workspace_bytes, pvs_stream_t stream);
+
+/* One sweep of min-label propagation over a CSR (labels start as node ids; repeat until *changed
+ * stays 0): connected components for the `prune` option of generate_edges
+ * (preprocessing.py:139-151), driven from the host side (pointvs_amd/radius_graph.py). */
+int pvs_graph_min_label_step(const int32_t* rowptr, const int32_t* col, int32_t n_nodes, int32_t* labels,
+                             int32_t* changed, pvs_stream_t stream);
+
 /* dst[perm[e], :] = src[e, :]  (sorted -> input edge order), width floats per row.
  * Gives EGNNLayer.forward's 4th return value `edge_feat` and `att_val` in the reference's order. */
 int pvs_rows_to_input_order(const float* src, float* dst, const int32_t* perm, int32_t n_edges,

@@ -45,6 +45,15 @@ _PROTOTYPES = {
     'pvs_graph_prepare_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32]),
     'pvs_graph_prepare': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] +
                           [C.c_void_p] * 9 + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    'pvs_radius_graph_state_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    'pvs_radius_graph_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    'pvs_radius_graph_count': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_size_t, C.c_void_p]),
+    'pvs_radius_graph_fill': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32] +
+                              [C.c_void_p] * 10 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'pvs_graph_min_label_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]),
     'pvs_rows_to_input_order': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                           C.c_void_p]),
     'pvs_rows_to_sorted_order': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,

@@ -144,6 +144,41 @@ extern "C" int pvs_graph_prepare(const int64_t* edge_index, const int64_t* edge_
     return 0;
 }
 
+// CSC of an existing CSR (shared with the radius-graph builder): cedge = CSR positions grouped by
+// column, stable; colptr = offsets.
+namespace {
+__global__ void k_iota(int E, int32_t* iota) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < E) iota[p] = p;
+}
+}  // namespace
+
+size_t pvs_build_csc_workspace_bytes(int N, int E) {
+    const size_t e = (size_t)(E > 0 ? E : 1);
+    return 2 * pvs_align_up(e * sizeof(int32_t), 256) +
+           pvs_align_up(sort_temp_bytes((int)e, key_bits(N > 1 ? N : 2)), 256) + 512;
+}
+
+int pvs_build_csc(hipStream_t stream, const int32_t* col, int E, int N, int32_t* colptr, int32_t* cedge,
+                  void* workspace, size_t workspace_bytes) {
+    PVS_REQUIRE(workspace_bytes >= pvs_build_csc_workspace_bytes(N, E) - 512, "build_csc: workspace too small");
+    PvsArena a(workspace, workspace_bytes);
+    const size_t e = (size_t)(E > 0 ? E : 1);
+    int32_t* iota = a.take<int32_t>(e);
+    int32_t* keys = a.take<int32_t>(e);
+    const int bits = key_bits(N > 1 ? N : 2);
+    size_t tb = sort_temp_bytes((int)e, bits);
+    void* tmp = a.take<char>(tb);
+    if (E > 0) {
+        k_iota<<<(E + 255) / 256, 256, 0, stream>>>(E, iota);
+        PVS_CHECK_LAUNCH();
+        PVS_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, col, keys, iota, cedge, E, 0, bits, stream));
+    }
+    k_lower_bounds<<<(N + 1 + 255) / 256, 256, 0, stream>>>(keys, E, N, colptr, nullptr);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
 namespace {
 template <bool TO_INPUT>
 __global__ void k_permute_rows(const float* __restrict__ src, float* __restrict__ dst,

@@ -42,7 +42,9 @@ class PNNGeometricBase(PointNeuralNetworkBase):
         segments = None
         if hasattr(graph, 'graph_node_counts') and hasattr(graph, 'graph_edge_counts'):
             segments = (graph.graph_node_counts, graph.graph_edge_counts)
-        pg = prepared_for(edges, edge_attributes, n_nodes, segments)
+        pg = getattr(graph, 'prepared', None)     # built on the GPU (radius_graph.attach_radius_graph)
+        if pg is None:
+            pg = prepared_for(edges, edge_attributes, n_nodes, segments)
         pg.poll_status()
         feats, _, _ = self.embed_prepared(pg, feats, coords)
         return feats, pg, graph_ptr, n_graphs

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 GOLDEN_DIR = Path(__file__).resolve().parent / 'golden'
-CASES = sorted(p.stem for p in GOLDEN_DIR.glob('*.npz'))
+CASES = sorted(p.stem for p in GOLDEN_DIR.glob('c[0-9]_*.npz'))   # model cases (edges_*.npz: radius graphs)
 
 
 class GoldenCase:

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import egnn_oracle as orc
-from tests._golden import CASES, GoldenCase, rel_err
+from tests._golden import CASES, GOLDEN_DIR as GOLDEN, GoldenCase, rel_err
 
 TOL = 2e-6   # fp32 CPU vs fp32 CPU, same op order up to fused/unfused cat-linear
 
@@ -48,3 +48,32 @@ def test_fp64_arbiter_agrees_with_fp32_reference():
     y64, _, _ = orc.forward_backward(c.sd, c.cfg, c.x, c.pos, c.edge_index, c.edge_attr,
                                      c.batch, c.y_true, dtype=torch.float64)
     assert rel_err(y64.numpy(), c.out['logits']) < 1e-5
+
+
+# ---- radius-graph builder oracle -------------------------------------------
+def test_generate_edges_oracle_matches_reference_test_vectors():
+    """The reference's own expected arrays (test/test_preprocessing_fns.py:32-71)."""
+    import json
+    from oracle.generate_edges_oracle import generate_edges
+    d = json.loads((GOLDEN / 'generate_edges_reference_tests.json').read_text())
+    xyz = np.stack([d['struct']['x'], d['struct']['y'], d['struct']['z']], axis=1).astype(np.float64)
+    for key, prune in (('no_prune', False), ('prune', True)):
+        keep, (rows, cols), attrs = generate_edges(xyz, d['struct']['bp'], d['inter_radius'],
+                                                   d['intra_radius'], prune=prune)
+        assert rows.tolist() == d[key]['rows'] and cols.tolist() == d[key]['cols']
+        assert attrs.tolist() == d[key]['attrs']
+    assert keep.tolist() == list(range(8))
+
+
+@pytest.mark.parametrize('name', ['edges_small', 'edges_small_prune', 'edges_default_radii', 'edges_r10',
+                                  'edges_bonds', 'edges_no_inter'])
+def test_generate_edges_oracle_matches_reference_outputs(name):
+    """Outputs of the reference function itself on seeded random structures
+    (tests/golden/make_golden_edges.py)."""
+    from oracle.generate_edges_oracle import generate_edges
+    z = np.load(GOLDEN / f'{name}.npz')
+    keep, (rows, cols), attrs = generate_edges(z['xyz'], z['bp'], float(z['inter']), float(z['intra']),
+                                               prune=bool(z['prune']))
+    assert np.array_equal(keep, z['keep'])
+    assert np.array_equal(rows, z['rows']) and np.array_equal(cols, z['cols'])
+    assert np.array_equal(attrs, z['attrs'])
