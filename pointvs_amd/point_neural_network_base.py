@@ -9,6 +9,7 @@ Progress bars, wandb and the predictions-file writer are outside the hot-path sc
 plain logging.
 """
 import math
+import os
 import time
 from abc import abstractmethod
 from collections import OrderedDict
