@@ -84,7 +84,11 @@ class PointNeuralNetworkBase(nn.Module):
         y_pred[torch.where(y_true == -1)] = -1
         return 3 * self.regression_loss(y_pred, y_true.to(y_pred.device))
 
-    def backprop(self, y_true, y_pred):
+    def backprop(self, y_true, y_pred, sync=True):
+        """One optimisation step (:417-429). sync=True is the reference's contract: returns the loss
+        as a float and stops on NaN, at the price of a host round trip per step. sync=False returns
+        the loss tensor and leaves the check to the caller (train_model checks every
+        `log_interval` steps, so the GPU never waits for the host inside the loop)."""
         loss = self.get_loss(y_true, y_pred)
         self.optimiser.zero_grad()
         loss.backward()
@@ -92,10 +96,22 @@ class PointNeuralNetworkBase(nn.Module):
             self.grad_sync()
         torch.nn.utils.clip_grad_value_(self.parameters(), 1.0)
         self.optimiser.step()
+        if not sync:
+            return loss.detach()
         loss_ = float(loss.detach().cpu())
         if math.isnan(loss_):
             raise FloatingPointError('We have hit a NaN loss value.')
         return loss_
+
+    @staticmethod
+    def _drain_losses(pending, losses):
+        """Device loss tensors -> floats (one transfer), NaN check as in backprop."""
+        if pending:
+            vals = torch.stack(pending).cpu().tolist()
+            pending.clear()
+            if any(math.isnan(v) for v in vals):
+                raise FloatingPointError('We have hit a NaN loss value.')
+            losses.extend(vals)
 
     def training_setup(self, data_loader, epochs, model_task=None):
         if self.use_1cycle:
@@ -114,12 +130,16 @@ class PointNeuralNetworkBase(nn.Module):
         losses = []
         for _ in range(init_epoch, epochs):
             self.train()
+            pending = []
             for self.batch, graph in enumerate(data_loader):
                 y_pred, y_true, _, _ = self.unpack_input_data_and_predict(graph)
-                losses.append(self.backprop(y_true, y_pred))
+                pending.append(self.backprop(y_true, y_pred, sync=False))
                 if self.scheduler is not None:
                     self.scheduler.step()
                 self.global_iter += 1
+                if len(pending) >= self.log_interval:
+                    self._drain_losses(pending, losses)
+            self._drain_losses(pending, losses)
             self.eval()
             if 'regression' in self.model_task:
                 self.a_epoch += 1
@@ -136,12 +156,14 @@ class PointNeuralNetworkBase(nn.Module):
         predictions_file = Path(predictions_file or self.predictions_file)
         lines = []
         self.eval()
+        held = []      # predictions stay on the device until the loop is over: no sync per batch
         for self.batch, graph in enumerate(data_loader):
             y_pred, y_true, ligands, receptors = self.unpack_input_data_and_predict(graph)
             if self.model_task == 'classification':
                 y_pred = torch.sigmoid(y_pred)
-            for yt, yp, lig, rec in zip(y_true.reshape(-1).tolist(), y_pred.reshape(-1).tolist(),
-                                        ligands, receptors):
+            held.append((y_true.reshape(-1), y_pred.reshape(-1), ligands, receptors))
+        for y_true, y_pred, ligands, receptors in held:
+            for yt, yp, lig, rec in zip(y_true.tolist(), y_pred.tolist(), ligands, receptors):
                 lines.append(f'{yt:.3f} | {yp:.3f} {rec} {lig}')
         predictions_file.parent.mkdir(parents=True, exist_ok=True)
         predictions_file.write_text('\n'.join(lines) + '\n')
