@@ -288,6 +288,13 @@ def main():
                 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                 'algorithmic_bytes_per_launch': dom_bytes,
                 'avg_launch_ms': round(dom_avg_ms, 4), 'launches': bwd_n,
+                # the kernel is ALU-bound (SURVEY §8d "the fused path is fp32-MFMA-bound"): its
+                # executed HxH products (2 recompute + 2 dgrad + 2 wgrad = 12 H^2 flop/edge) against
+                # the fp32 matrix peak, beside the HBM fraction north_star asks for
+                'kernel_fp32': {'achieved': round(12.0 * h * h * n_edges / (dom_avg_ms * 1e-3) / 1e12, 2)
+                                if dom_avg_ms > 0 else 0.0, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                'frac': round(12.0 * h * h * n_edges / (dom_avg_ms * 1e-3) / 1e12
+                                              / FP32_PEAK_TFLOPS, 5) if dom_avg_ms > 0 else 0.0},
                 'step_hbm_frac': round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 'step_fp32_frac': round(step_flops / (ms_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5),
                 'kernel_ms_per_step': {

@@ -148,18 +148,29 @@ k_reduce_slabs(float* __restrict__ out, int ldo, int inner, const float* __restr
     }
 }
 
-__global__ void __launch_bounds__(kThreads)
+constexpr int kPoolThreads = 1024;
+// One workgroup per graph; thread = (row slot, channel), 4 independent partial sums per thread so
+// that 4 * (1024 / width) rows are in flight; fixed summation order.
+__global__ void __launch_bounds__(kPoolThreads)
 k_mean_pool_fwd(const float* __restrict__ h, const int32_t* __restrict__ gptr,
                 float* __restrict__ pooled, int width) {
-    __shared__ float part[kThreads];
+    __shared__ float part[kPoolThreads];
     const int g = blockIdx.x, tid = threadIdx.x;
     const int n0 = gptr[g], n1 = gptr[g + 1];
-    const int R = kThreads / width;
+    const int R = kPoolThreads / width;
     const int c = tid % width, r = tid / width;
-    float acc = 0.f;
-    if (r < R)
-        for (int n = n0 + r; n < n1; n += R) acc += h[(size_t)n * width + c];
-    part[tid] = acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (r < R) {
+        int n = n0 + r;
+        for (; n + 3 * R < n1; n += 4 * R) {
+            a0 += h[(size_t)n * width + c];
+            a1 += h[(size_t)(n + R) * width + c];
+            a2 += h[(size_t)(n + 2 * R) * width + c];
+            a3 += h[(size_t)(n + 3 * R) * width + c];
+        }
+        for (; n < n1; n += R) a0 += h[(size_t)n * width + c];
+    }
+    part[tid] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (tid < width) {
         float s = 0.f;
@@ -599,7 +610,7 @@ extern "C" int pvs_mean_pool_fwd(const float* h, const int32_t* graph_ptr, float
                                  int32_t B, int32_t width, pvs_stream_t stream) {
     PVS_REQUIRE(width >= 1 && width <= kThreads, "mean_pool: width %d unsupported", width);
     if (B <= 0) return 0;
-    k_mean_pool_fwd<<<B, kThreads, 0, (hipStream_t)stream>>>(h, graph_ptr, pooled, width);
+    k_mean_pool_fwd<<<B, kPoolThreads, 0, (hipStream_t)stream>>>(h, graph_ptr, pooled, width);
     PVS_CHECK_LAUNCH();
     return 0;
 }

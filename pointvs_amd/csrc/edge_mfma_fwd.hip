@@ -227,6 +227,18 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
 
 }  // namespace
 
+namespace {
+__global__ void k_init_fwd(float* __restrict__ Magg, const float* __restrict__ x, float* __restrict__ x_out,
+                           int N, int H) {
+    const int qpr = H / 4;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = t / qpr, q = t - n * qpr;
+    if (n >= N) return;
+    *reinterpret_cast<float4*>(Magg + (size_t)n * H + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q == 0 && x) { x_out[3 * n] = x[3 * n]; x_out[3 * n + 1] = x[3 * n + 1]; x_out[3 * n + 2] = x[3 * n + 2]; }
+}
+}  // namespace
+
 int pvs_edge_mfma_supported(int H, uint32_t flags) {
     if (H != 32 && H != 64) return 0;
     if ((flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT)) return 0;   // generic path
@@ -238,10 +250,12 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     PVS_REQUIRE(w.n_attr <= PVS_MAX_EDGE_ATTR, "edge_attr classes %d > %d", w.n_attr,
                 PVS_MAX_EDGE_ATTR);
     // rows without edges are never flushed: M = 0, x_out = x
-    PVS_CHECK_HIP(hipMemsetAsync(io.Magg, 0, sizeof(float) * (size_t)g.n_nodes * H, s));
-    if (flags & PVS_UPDATE_COORDS)
-        PVS_CHECK_HIP(hipMemcpyAsync(io.x_out, io.x, sizeof(float) * 3 * (size_t)g.n_nodes,
-                                     hipMemcpyDeviceToDevice, s));
+    {
+        const long long threads = (long long)g.n_nodes * (H / 4);
+        k_init_fwd<<<(int)((threads + 255) / 256), 256, 0, s>>>(io.Magg, (flags & PVS_UPDATE_COORDS) ? io.x : nullptr,
+                                                                io.x_out, g.n_nodes, H);
+        PVS_CHECK_LAUNCH();
+    }
     if (g.n_edges == 0) return 0;
     int blocks, n_chunks;
     pick_grid(g.n_edges, &blocks, &n_chunks);

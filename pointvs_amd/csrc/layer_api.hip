@@ -388,8 +388,11 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
                                      1.f, w.dslabs, false));
 
     // ---- edge backward ----
+    const bool mfma_bwd = pvs_use_mfma() && pvs_edge_bwd_mfma_supported(H, F, m.A);
+    // (MFMA path: rows without edges are never written by the edge kernel: cleared here)
     PVS_TRY(pvs_prep_edge_bwd(s, g_x_out, g->inv_deg, Magg, w.gM, N, H,
-                              coord_bwd ? w.gxagg : nullptr, (eatt && soft) ? w.softD : nullptr));
+                              coord_bwd ? w.gxagg : nullptr, (eatt && soft) ? w.softD : nullptr,
+                              mfma_bwd ? w.gPQ : nullptr, mfma_bwd ? w.gx_row : nullptr));
     PvsEdgeBwdIO io;
     io.PQ = sPQ; io.x = x; io.m_prev = m_prev; io.att = att; io.gM = w.gM;
     io.gxagg = coord_bwd ? w.gxagg : nullptr;
@@ -397,13 +400,9 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     io.g_m_out = g_m_out; io.gPQ = w.gPQ; io.gz1 = w.gz1; io.gd = w.gd; io.gx_row = w.gx_row;
     io.g_m_prev = eres ? g_m_prev : nullptr; io.slabs = w.eslabs;
     int n_slabs = 0;
-    const bool mfma_bwd = pvs_use_mfma() && pvs_edge_bwd_mfma_supported(H, F, m.A);
     const PvsSlabLayout L = pvs_slab_layout(H);
     int n_nslabs = 0;
     if (mfma_bwd) {
-        // rows without edges are never written by the edge kernel
-        PVS_CHECK_HIP(hipMemsetAsync(w.gPQ, 0, sizeof(float) * 2 * (size_t)N * H, s));
-        PVS_CHECK_HIP(hipMemsetAsync(w.gx_row, 0, sizeof(float) * 3 * (size_t)N, s));
         const uint32_t Fk = F | pvs_ablate_bits();
         PvsPipe* pipe = nullptr;
         int n_stage = 1;

@@ -34,6 +34,7 @@ int pvs_node_tail_bwd2(hipStream_t s, const float* g_yn, const float* y1, const 
                        const PvsNodeW& w, const float* coefs, int N, int H, float* g_y1);
 // gxagg = g_x_out * inv_deg (if g_x_out), softD = rowdot(Magg, gM) (if softD)
 int pvs_prep_edge_bwd(hipStream_t s, const float* g_x_out, const float* inv_deg, const float* Magg,
-                      const float* gM, int N, int H, float* gxagg, float* softD);
+                      const float* gM, int N, int H, float* gxagg, float* softD, float* zero_gPQ,
+                      float* zero_gx_row);
 // out[0] = sum_i v[i]
 int pvs_sum_vec(hipStream_t s, const float* v, int n, float* out);

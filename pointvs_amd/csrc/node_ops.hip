@@ -173,11 +173,20 @@ __global__ void k_node_tail_bwd2(const float* __restrict__ g_yn, const float* __
     }
 }
 
+// thread = (node, 16-byte quad of its H channels): quad 0 does the per-node work, every thread
+// clears its piece of the row part of gPQ (rows without edges are never written by the MFMA edge
+// backward), so no separate memsets are needed
 __global__ void k_prep_edge_bwd(const float* __restrict__ g_x_out, const float* __restrict__ inv_deg,
                                 const float* __restrict__ Magg, const float* __restrict__ gM, int N,
-                                int H, float* __restrict__ gxagg, float* __restrict__ softD) {
-    int n = blockIdx.x * blockDim.x + threadIdx.x;
+                                int H, float* __restrict__ gxagg, float* __restrict__ softD,
+                                float* __restrict__ zero_gPQ, float* __restrict__ zero_gx_row) {
+    const int qpr = H / 4;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = t / qpr, q = t - n * qpr;
     if (n >= N) return;
+    if (zero_gPQ) *reinterpret_cast<float4*>(zero_gPQ + (size_t)n * 2 * H + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q != 0) return;
+    if (zero_gx_row) { zero_gx_row[3 * n] = 0.f; zero_gx_row[3 * n + 1] = 0.f; zero_gx_row[3 * n + 2] = 0.f; }
     if (gxagg) {
         const float inv = inv_deg[n];
         gxagg[3 * n] = g_x_out[3 * n] * inv;
@@ -281,9 +290,12 @@ int pvs_node_tail_bwd2(hipStream_t s, const float* g_yn, const float* y1, const 
 }
 
 int pvs_prep_edge_bwd(hipStream_t s, const float* g_x_out, const float* inv_deg, const float* Magg,
-                      const float* gM, int N, int H, float* gxagg, float* softD) {
-    if (!gxagg && !softD) return 0;
-    k_prep_edge_bwd<<<(N + 255) / 256, 256, 0, s>>>(g_x_out, inv_deg, Magg, gM, N, H, gxagg, softD);
+                      const float* gM, int N, int H, float* gxagg, float* softD, float* zero_gPQ,
+                      float* zero_gx_row) {
+    if (!gxagg && !softD && !zero_gPQ && !zero_gx_row) return 0;
+    const long long threads = (long long)N * (H / 4);
+    k_prep_edge_bwd<<<(int)((threads + 255) / 256), 256, 0, s>>>(g_x_out, inv_deg, Magg, gM, N, H, gxagg, softD,
+                                                                 zero_gPQ, zero_gx_row);
     PVS_CHECK_LAUNCH();
     return 0;
 }
