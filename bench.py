@@ -106,12 +106,66 @@ def cpu_baseline(cfg, seconds_budget=15.0):
                       f'{n_cpu}-CPU host, torch {torch.__version__} CPU'}
 
 
+def screening_bench(args, rank, world, dev):
+    """BASELINE config 5: poses/s of the forward pass (torch.no_grad) with the radius graph of every
+    pose built on the GPU from its coordinates. One step = one batch of `--batch` poses; every rank
+    screens its own poses (no collective: pose shards are independent)."""
+    from pointvs_amd.egnn_satorras import SartorrasEGNN
+    from pointvs_amd.radius_graph import PoseBatcher
+    from pointvs_amd.synthetic import CONFIGS, random_poses, screening_set
+    cfg = CONFIGS['cfg2']
+    lig, rec, feats = screening_set()
+    torch.manual_seed(0)
+    model = SartorrasEGNN(Path('/tmp/pvs_bench'), 2e-3, 1e-4, silent=True, **cfg['model']).eval()
+    batcher = PoseBatcher(rec.to(dev), feats, lig.shape[0], args.batch, cfg['graph']['edge_radius'])
+    n_steps = args.warmup + args.steps
+    poses = random_poses(lig, n_steps * args.batch, seed=7 + rank, device=dev).view(n_steps, args.batch, -1, 3)
+    scores = []
+
+    def step(k):
+        with torch.no_grad():
+            scores.append(torch.sigmoid(model(batcher.load(poses[k])).reshape(-1)))
+
+    for k in range(args.warmup):
+        step(k)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.warmup, n_steps):
+        step(k)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        e = batcher.batch.prepared.n_edges
+        print(json.dumps({
+            'metric': 'ligand poses/sec, forward only (virtual-screening sweep), 3-layer EGNN ch=32, one '
+                      'receptor of 1970 atoms, r=10A, graphs built on the GPU',
+            'value': round(world * args.batch * args.steps / elapsed, 2), 'unit': 'graphs/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'cfg5: {args.batch} poses/GPU per step, 30-atom ligand + 1970-atom receptor, '
+                                   f'E={e} edges in the last batch, radius graph from coordinates every step',
+                       'graphs_per_gpu': args.batch, 'global_batch': world * args.batch, 'parallelism': f'dp{world}',
+                       'mean_score': round(float(torch.cat(scores[-args.steps:]).mean()), 6)}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3'])
+    ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg5'],
+                    help='cfg5: virtual-screening sweep (BASELINE config 5): forward only, random poses '
+                         'of one ligand against one receptor, graphs built on the GPU per batch')
     ap.add_argument('--batch', type=int, default=32, help='graphs per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--infer', action='store_true',
@@ -142,6 +196,8 @@ def main():
     from pointvs_amd.egnn_satorras import SartorrasEGNN
     from pointvs_amd.synthetic import CONFIGS, synthetic_batch
 
+    if args.config == 'cfg5':
+        return screening_bench(args, rank, world, dev)
     cfg = CONFIGS[args.config]
     lib = _lib.lib()
     pgraph.CACHE_ENABLED = False        # every step prepares its batch, as a fresh batch would

@@ -25,8 +25,11 @@ class PNNGeometricBase(PointNeuralNetworkBase):
         """Input features -> final node embeddings."""
 
     def unpack_graph(self, graph):
-        return (graph.x.float().to(DEVICE), graph.edge_index.to(DEVICE),
-                graph.pos.float().to(DEVICE), graph.edge_attr.to(DEVICE), graph.batch.to(DEVICE))
+        edges = getattr(graph, 'edge_index', None)      # None when the graph was built on the GPU
+        attrs = getattr(graph, 'edge_attr', None)
+        return (graph.x.float().to(DEVICE), None if edges is None else edges.to(DEVICE),
+                graph.pos.float().to(DEVICE), None if attrs is None else attrs.to(DEVICE),
+                graph.batch.to(DEVICE))
 
     def _embed_graph(self, graph):
         feats, edges, coords, edge_attributes, batch = self.unpack_graph(graph)

@@ -128,3 +128,31 @@ def attach_radius_graph(batch, inter_radius, intra_radius=None):
     batch.prepared = radius_graph(batch.pos, batch.x[:, -1], batch.ptr, inter_radius, intra_radius,
                                   max_graph_nodes=max_nodes)
     return batch
+
+
+class PoseBatcher:
+    """Virtual-screening batches (BASELINE config 5): B poses of one ligand against one receptor as
+    a PyG-style batch whose graph is built on the GPU. The receptor rows, the features, `ptr` and
+    `batch` are laid out once; per batch only the ligand coordinates are written."""
+
+    def __init__(self, rec_pos, feats, n_lig, batch_size, edge_radius, intra_radius=None):
+        from .graph import Batch
+        dev = rec_pos.device
+        n = n_lig + rec_pos.shape[0]
+        self.n_lig, self.n, self.b = n_lig, n, batch_size
+        self.edge_radius, self.intra_radius = edge_radius, intra_radius
+        pos = torch.empty((batch_size, n, 3), dtype=torch.float32, device=dev)
+        pos[:, n_lig:] = rec_pos
+        self._pos = pos
+        ptr = torch.arange(batch_size + 1, dtype=torch.int64) * n
+        self.batch = Batch(
+            x=feats.to(dev).repeat(batch_size, 1), pos=pos.view(-1, 3), edge_index=None, edge_attr=None,
+            batch=torch.arange(batch_size, device=dev).repeat_interleave(n), ptr=ptr,
+            y=torch.zeros(batch_size, device=dev), lig_fname=['pose'] * batch_size,
+            rec_fname=['receptor'] * batch_size, num_graphs=batch_size,
+            graph_node_counts=[n] * batch_size)
+
+    def load(self, lig_poses):
+        """lig_poses [B, n_lig, 3] (device) -> the batch with its graph attached."""
+        self._pos[:, :self.n_lig] = lig_poses
+        return attach_radius_graph(self.batch, self.edge_radius, self.intra_radius)

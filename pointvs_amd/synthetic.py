@@ -50,6 +50,32 @@ def synthetic_batch(cfg_id, batch_size, first_graph=0, **graph_kwargs):
     return Batch.from_data_list(graphs)
 
 
+def screening_set(seed=5000, n_nodes=2000, n_lig=30, density=0.05, n_feats=12):
+    """BASELINE config 5: one receptor cloud (n_nodes - n_lig points) and one
+    ligand (the n_lig points nearest the centre) whose rigid poses are screened. Returns
+    (lig_pos [n_lig,3], rec_pos [n_rec,3], feats [n_nodes,F] with the ligand rows first)."""
+    g = synthetic_graph(seed, n_nodes=n_nodes, n_lig=n_lig, edge_radius=1.0, density=density, n_feats=n_feats)
+    return g.pos[:n_lig].clone(), g.pos[n_lig:].clone(), g.x.clone()
+
+
+def random_poses(lig_pos, n_poses, seed, max_shift=6.0, device=None):
+    """n_poses random rigid transforms of the ligand: uniform rotation about its centroid, centroid
+    moved to a uniform point of the centre ball of radius max_shift. Returns [n_poses, n_lig, 3]."""
+    gen = torch.Generator(device='cpu').manual_seed(seed)
+    q = torch.randn(n_poses, 4, generator=gen)
+    q = q / q.norm(dim=1, keepdim=True)
+    w, x, y, z = q.unbind(1)
+    rot = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                       2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                       2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
+    direction = torch.randn(n_poses, 3, generator=gen)
+    direction = direction / direction.norm(dim=1, keepdim=True)
+    shift = direction * (max_shift * torch.rand(n_poses, 1, generator=gen) ** (1.0 / 3.0))
+    centred = lig_pos - lig_pos.mean(0, keepdim=True)
+    poses = torch.einsum('pij,nj->pni', rot, centred) + shift[:, None, :]
+    return poses.to(device) if device is not None else poses
+
+
 # BASELINE.json configs (SURVEY.md §8d)
 CONFIGS = {
     'cfg2': dict(cfg_id=2, graph=dict(n_nodes=2000, n_lig=30, edge_radius=10.0),
