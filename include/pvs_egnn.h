@@ -126,6 +126,7 @@ int pvs_version(void);
  *   status: device int32[1], 0 on success, bit0 = index out of range, bit1 = edge_attr row not
  *   one-hot; checked by the caller whenever it next synchronises.
  * Output arrays are the members of PvsGraph (caller-allocated with the sizes given there).
+ * colptr / cedge may both be NULL for forward-only use (skips the second sort).
  */
 size_t pvs_graph_prepare_workspace_bytes(int32_t n_nodes, int32_t n_edges);
 int pvs_graph_prepare(const int64_t* edge_index, const int64_t* edge_attr, int32_t n_edge_attr,
@@ -149,6 +150,8 @@ int pvs_graph_prepare(const int64_t* edge_index, const int64_t* edge_attr, int32
  * 64-bit neighbour mask per (row, 64-column chunk) in `state` and fills rowptr/inter_ptr/intra_ptr
  * ([N+1] each); the caller reads rowptr[N] = E back, allocates, and _fill expands the masks.
  * max_graph_nodes = node count of the largest graph of the batch (sizes the masks).
+ * colptr / cedge may both be NULL (forward-only use: only the backward reads the by-column lists;
+ * skips the radix sort); pvs_egnn_layer_bwd then refuses the graph.
  */
 size_t pvs_radius_graph_state_bytes(int32_t n_nodes, int32_t n_graphs, int32_t max_graph_nodes);
 size_t pvs_radius_graph_workspace_bytes(int32_t n_nodes, int32_t n_graphs, int32_t n_edges);

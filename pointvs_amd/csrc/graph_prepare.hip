@@ -114,6 +114,7 @@ extern "C" int pvs_graph_prepare(const int64_t* edge_index, const int64_t* edge_
     PVS_REQUIRE(n_edge_attr >= 0 && n_edge_attr <= 255, "pvs_graph_prepare: bad n_edge_attr %d",
                 n_edge_attr);
     PVS_REQUIRE(n_edge_attr == 0 || (edge_attr && etype), "pvs_graph_prepare: edge_attr/etype NULL");
+    PVS_REQUIRE((colptr == nullptr) == (cedge == nullptr), "pvs_graph_prepare: colptr and cedge go together");
     PvsArena arena(workspace, workspace_bytes);
     PrepWs w;
     carve(arena, N, E, &w);
@@ -133,14 +134,18 @@ extern "C" int pvs_graph_prepare(const int64_t* edge_index, const int64_t* edge_
         k_gather_sorted<<<(E + T - 1) / T, T, 0, stream>>>(perm, w.col32, w.etype_in, E, col,
                                                            n_edge_attr ? etype : nullptr, w.iota);
         PVS_CHECK_LAUNCH();
-        tb = w.sort_bytes;
-        PVS_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(w.sort_tmp, tb, col, w.keys_tmp, w.iota,
-                                                         cedge, E, 0, bits, stream));
+        if (cedge) {   // by-column lists: only the backward reads them
+            tb = w.sort_bytes;
+            PVS_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(w.sort_tmp, tb, col, w.keys_tmp, w.iota,
+                                                             cedge, E, 0, bits, stream));
+        }
     }
     k_lower_bounds<<<(N + 1 + T - 1) / T, T, 0, stream>>>(row, E, N, rowptr, inv_deg);
     PVS_CHECK_LAUNCH();
-    k_lower_bounds<<<(N + 1 + T - 1) / T, T, 0, stream>>>(w.keys_tmp, E, N, colptr, nullptr);
-    PVS_CHECK_LAUNCH();
+    if (cedge) {
+        k_lower_bounds<<<(N + 1 + T - 1) / T, T, 0, stream>>>(w.keys_tmp, E, N, colptr, nullptr);
+        PVS_CHECK_LAUNCH();
+    }
     return 0;
 }
 

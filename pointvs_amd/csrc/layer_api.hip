@@ -307,6 +307,8 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     hipStream_t s = (hipStream_t)stream_;
     PVS_TRY(check_desc(d, g, p));
     PVS_REQUIRE(h && x && saved && g_h_out && g_h && gr_, "pvs_egnn_layer_bwd: NULL tensor");
+    PVS_REQUIRE(g->n_edges == 0 || (g->colptr && g->cedge),
+                "pvs_egnn_layer_bwd: graph was built without the by-column lists (forward-only)");
     const uint32_t F = d->flags;
     const bool eatt = F & PVS_EDGE_ATTENTION, soft = F & PVS_SOFTMAX_ATT;
     const bool eres = (F & PVS_EDGE_RESIDUAL) && m_prev;

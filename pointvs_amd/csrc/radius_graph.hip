@@ -327,8 +327,9 @@ extern "C" int pvs_radius_graph_fill(const uint8_t* bp, const int32_t* graph_ptr
                                      const void* state, size_t state_bytes,
                                      void* workspace, size_t workspace_bytes, pvs_stream_t stream_) {
     hipStream_t s = (hipStream_t)stream_;
-    PVS_REQUIRE(bp && graph_ptr && rowptr && inter_ptr && intra_ptr && row && col && etype && perm && colptr &&
-                cedge && inv_deg && state, "pvs_radius_graph_fill: NULL");
+    PVS_REQUIRE(bp && graph_ptr && rowptr && inter_ptr && intra_ptr && row && col && etype && perm && inv_deg &&
+                state, "pvs_radius_graph_fill: NULL");
+    PVS_REQUIRE((colptr == nullptr) == (cedge == nullptr), "pvs_radius_graph_fill: colptr and cedge go together");
     PVS_REQUIRE(N > 0 && n_graphs > 0 && E >= 0, "pvs_radius_graph_fill: bad sizes");
     PvsArena arena(const_cast<void*>(state), state_bytes);
     RgState w;
@@ -339,6 +340,7 @@ extern "C" int pvs_radius_graph_fill(const uint8_t* bp, const int32_t* graph_ptr
                                                                 rowptr, inter_ptr, intra_ptr, row, col, etype,
                                                                 perm, inv_deg, N);
     PVS_CHECK_LAUNCH();
+    if (!cedge) return 0;     // forward-only use: the by-column lists are only read by the backward
     return pvs_build_csc(s, col, E, N, colptr, cedge, workspace, workspace_bytes);
 }
 

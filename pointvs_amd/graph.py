@@ -128,9 +128,13 @@ class PreparedGraph:
 _PENDING = []
 
 
-def prepare_graph(edge_index, edge_attr, n_nodes, segments=None):
+def prepare_graph(edge_index, edge_attr, n_nodes, segments=None, need_backward=None):
     """int64 COO `[2,E]` (+ int64 one-hot `[E,A]` or None) -> PreparedGraph on the same device.
-    segments: optional (node_counts, edge_counts) per whole graph, host lists (see PvsGraph)."""
+    segments: optional (node_counts, edge_counts) per whole graph, host lists (see PvsGraph).
+    need_backward=False (default: torch.is_grad_enabled()) skips the by-column lists that only the
+    backward reads."""
+    if need_backward is None:
+        need_backward = torch.is_grad_enabled()
     _lib.require_hip(edge_index, edge_attr)
     lib = _lib.lib()
     if edge_index.dtype != torch.int64:
@@ -152,19 +156,20 @@ def prepare_graph(edge_index, edge_attr, n_nodes, segments=None):
     t = {
         'rowptr': torch.empty(n_nodes + 1, **i32), 'row': torch.empty(e_alloc, **i32),
         'col': torch.empty(e_alloc, **i32), 'perm': torch.empty(e_alloc, **i32),
-        'colptr': torch.empty(n_nodes + 1, **i32), 'cedge': torch.empty(e_alloc, **i32),
         'inv_deg': torch.empty(n_nodes, dtype=torch.float32, device=dev),
         'status': torch.empty(1, **i32),
     }
     if n_attr:
         t['etype'] = torch.empty(e_alloc, dtype=torch.uint8, device=dev)
+    if need_backward:
+        t['colptr'], t['cedge'] = torch.empty(n_nodes + 1, **i32), torch.empty(e_alloc, **i32)
     ws_bytes = lib.pvs_graph_prepare_workspace_bytes(n_nodes, n_edges)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     rc = lib.pvs_graph_prepare(
         _lib.ptr(edge_index), _lib.ptr(edge_attr), n_attr, n_nodes, n_edges,
         _lib.ptr(t['rowptr']), _lib.ptr(t['row']), _lib.ptr(t['col']), _lib.ptr(t.get('etype')),
-        _lib.ptr(t['perm']), _lib.ptr(t['colptr']), _lib.ptr(t['cedge']), _lib.ptr(t['inv_deg']),
+        _lib.ptr(t['perm']), _lib.ptr(t.get('colptr')), _lib.ptr(t.get('cedge')), _lib.ptr(t['inv_deg']),
         _lib.ptr(t['status']), _lib.ptr(ws), ws_bytes, stream)
     _lib.check(rc, 'pvs_graph_prepare')
     return PreparedGraph(n_nodes, n_edges, n_attr, t, segments)
@@ -190,7 +195,7 @@ def prefetch_graph(edge_index, edge_attr, n_nodes, segments=None):
         side = _PREFETCH_STREAM[dev] = torch.cuda.Stream(dev)
     side.wait_stream(torch.cuda.current_stream(dev))   # inputs may have been produced just now
     with torch.cuda.stream(side):
-        pg = prepare_graph(edge_index, edge_attr, n_nodes, segments)
+        pg = prepare_graph(edge_index, edge_attr, n_nodes, segments, need_backward=True)
         done = torch.cuda.Event()
         done.record(side)
     _PREFETCH[dev] = (_graph_key(edge_index, edge_attr, n_nodes), pg, done, edge_index, edge_attr)
@@ -222,7 +227,8 @@ def prepared_for(edge_index, edge_attr, n_nodes, segments=None):
     if not CACHE_ENABLED:
         return prepare_graph(edge_index, edge_attr, n_nodes, segments)
     key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
-           None if edge_attr is None else (edge_attr.data_ptr(), edge_attr._version), n_nodes)
+           None if edge_attr is None else (edge_attr.data_ptr(), edge_attr._version), n_nodes,
+           torch.is_grad_enabled())      # a forward-only graph has no by-column lists
     hit = _CACHE.get(key)
     if hit is not None:
         _CACHE.move_to_end(key)

@@ -18,13 +18,18 @@ def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-def radius_graph(pos, bp, graph_ptr=None, inter_radius=4.0, intra_radius=None, max_graph_nodes=None):
+def radius_graph(pos, bp, graph_ptr=None, inter_radius=4.0, intra_radius=None, max_graph_nodes=None,
+                 need_backward=None):
     """pos [N,3] fp32, bp [N] (0 ligand / 1 receptor), graph_ptr [B+1] node offsets of the batch's
     graphs (None: one graph). Returns a PreparedGraph identical, array for array, to
     prepare_graph(edge_index, one_hot(edge_attr, 3)) of the reference's generate_edges output for
     each graph (prune=False), graphs concatenated PyG style. intra_radius=None means "no
     estimate_bonds": intra_radius = inter_radius (data_loaders.py:359-360). max_graph_nodes: size
-    of the largest graph if the caller knows it (Batch.graph_node_counts), else read from graph_ptr."""
+    of the largest graph if the caller knows it (Batch.graph_node_counts), else read from graph_ptr.
+    need_backward=False (default: `torch.is_grad_enabled()`) skips the by-column lists that only the
+    backward reads (one radix sort less)."""
+    if need_backward is None:
+        need_backward = torch.is_grad_enabled()
     _lib.require_hip(pos, bp)
     lib = _lib.lib()
     if pos.dtype != torch.float32:
@@ -55,16 +60,17 @@ def radius_graph(pos, bp, graph_ptr=None, inter_radius=4.0, intra_radius=None, m
     t = {
         'rowptr': rowptr, 'row': torch.empty(e_alloc, **i32), 'col': torch.empty(e_alloc, **i32),
         'etype': torch.empty(e_alloc, dtype=torch.uint8, device=dev), 'perm': torch.empty(e_alloc, **i32),
-        'colptr': torch.empty(n + 1, **i32), 'cedge': torch.empty(e_alloc, **i32),
         'inv_deg': torch.empty(n, dtype=torch.float32, device=dev),
         'status': torch.zeros(1, **i32), 'inter_ptr': inter_ptr, 'intra_ptr': intra_ptr,
     }
+    if need_backward:
+        t['colptr'], t['cedge'] = torch.empty(n + 1, **i32), torch.empty(e_alloc, **i32)
     ws_bytes = lib.pvs_radius_graph_workspace_bytes(n, n_graphs, n_edges)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     _lib.check(lib.pvs_radius_graph_fill(
         _lib.ptr(bp8), _lib.ptr(gp), n_graphs, n, max_graph_nodes, n_edges, _lib.ptr(rowptr),
         _lib.ptr(inter_ptr), _lib.ptr(intra_ptr), _lib.ptr(t['row']), _lib.ptr(t['col']), _lib.ptr(t['etype']),
-        _lib.ptr(t['perm']), _lib.ptr(t['colptr']), _lib.ptr(t['cedge']), _lib.ptr(t['inv_deg']),
+        _lib.ptr(t['perm']), _lib.ptr(t.get('colptr')), _lib.ptr(t.get('cedge')), _lib.ptr(t['inv_deg']),
         _lib.ptr(state), st_bytes, _lib.ptr(ws), ws_bytes, _stream(dev)), 'pvs_radius_graph_fill')
     pg = PreparedGraph(n, n_edges, 3, t)
     pg._status_checked = True     # built, not parsed: nothing to validate
