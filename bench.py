@@ -122,9 +122,16 @@ def screening_bench(args, rank, world, dev):
     poses = random_poses(lig, n_steps * args.batch, seed=7 + rank, device=dev).view(n_steps, args.batch, -1, 3)
     scores = []
 
+    from pointvs_amd.screening import ReceptorScreen
+    screen = None
+    if not os.environ.get('PVS_BENCH_NO_REUSE'):   # first-layer receptor-receptor sums computed once
+        screen = ReceptorScreen(model, rec.to(dev), feats, lig.shape[0], args.batch, cfg['graph']['edge_radius'])
+        batcher = screen.batcher
+
     def step(k):
         with torch.no_grad():
-            scores.append(torch.sigmoid(model(batcher.load(poses[k])).reshape(-1)))
+            out = screen(poses[k]) if screen is not None else model(batcher.load(poses[k]))
+            scores.append(torch.sigmoid(out.reshape(-1)))
 
     for k in range(args.warmup):
         step(k)
@@ -138,6 +145,8 @@ def screening_bench(args, rank, world, dev):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if screen is not None:
+        screen.check()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -151,7 +160,8 @@ def screening_bench(args, rank, world, dev):
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'cfg5: {args.batch} poses/GPU per step, 30-atom ligand + 1970-atom receptor, '
-                                   f'E={e} edges in the last batch, radius graph from coordinates every step',
+                                   f'E={e} edges in the last batch, radius graph from coordinates every step, first-layer '
+                                   f'receptor-receptor sums reused: {screen is not None and screen.reuse}',
                        'graphs_per_gpu': args.batch, 'global_batch': world * args.batch, 'parallelism': f'dp{world}',
                        'mean_score': round(float(torch.cat(scores[-args.steps:]).mean()), 6)}}))
     if world > 1:

@@ -77,6 +77,10 @@ typedef struct PvsGraph {
     int32_t n_segments;
     const int32_t* seg_node_ptr;  /* HOST [n_segments+1] */
     const int32_t* seg_edge_ptr;  /* HOST [n_segments+1] */
+    /* Optional DEVICE int32: the true edge count when it is only known on the device (a graph made
+     * by pvs_graph_filter_ligand_edges); n_edges is then the capacity of the edge arrays. Only
+     * pvs_egnn_layer_edge_sums / _fwd_partial accept such a graph. */
+    const int32_t* n_edges_dev;
 } PvsGraph;
 
 /* Parameters of one EGNNLayer, torch nn.Linear layout W[out][in] (state_dict keys in comments). */
@@ -157,6 +161,7 @@ size_t pvs_radius_graph_state_bytes(int32_t n_nodes, int32_t n_graphs, int32_t m
 size_t pvs_radius_graph_workspace_bytes(int32_t n_nodes, int32_t n_graphs, int32_t n_edges);
 int pvs_radius_graph_count(const float* pos, const uint8_t* bp, const int32_t* graph_ptr, int32_t n_graphs,
                            int32_t n_nodes, int32_t max_graph_nodes, double inter_radius, double intra_radius,
+                           int32_t pair_filter /* 0: every pair; 1: only pairs that touch a ligand atom (bp == 0) */,
                            int32_t* rowptr, int32_t* inter_ptr, int32_t* intra_ptr,
                            void* state, size_t state_bytes, pvs_stream_t stream);
 int pvs_radius_graph_fill(const uint8_t* bp, const int32_t* graph_ptr, int32_t n_graphs, int32_t n_nodes,
@@ -199,6 +204,34 @@ int pvs_egnn_layer_fwd(const PvsLayerDesc* desc, const PvsGraph* graph, const Pv
                        float* h_out, float* x_out, float* m_out, float* att_out,
                        float* node_att_out, float* saved,
                        void* workspace, size_t workspace_bytes, pvs_stream_t stream);
+
+/* Forward-only pieces for virtual screening (`val`/inference.py loop of the
+ * reference, point_neural_network_base.py:208-360): when many ligand poses are scored against one
+ * receptor, the receptor-receptor messages of the FIRST layer (inputs: receptor features and
+ * coordinates only) are the same for every pose.
+ *   pvs_egnn_layer_edge_sums: the row-side sums of one layer's edge work over the edges of `graph`
+ *     only: magg[i] = sum_j att_ij m_ij [N,H], xsum[i] = sum_j (x_i - x_j) s_ij [N,3] (no 1/deg).
+ *   pvs_egnn_layer_fwd_partial: EGNNLayer.forward where `graph` holds only part of every row's edges
+ *     and the rest enters as base_magg [N,H], base_xsum [N,3], base_deg [N] (edge counts as floats):
+ *     M = base_magg + sums over graph, x' = x + (base_xsum + sums) / max(base_deg + deg_graph, 1).
+ * No edge_residual, no softmax attention, H = 32 or 64; no backward. Workspace:
+ * pvs_egnn_layer_workspace_bytes(desc, N, E, 2). */
+int pvs_egnn_layer_edge_sums(const PvsLayerDesc* desc, const PvsGraph* graph, const PvsLayerParams* params,
+                             const float* h, const float* x, float* magg, float* xsum,
+                             void* workspace, size_t workspace_bytes, pvs_stream_t stream);
+int pvs_egnn_layer_fwd_partial(const PvsLayerDesc* desc, const PvsGraph* graph, const PvsLayerParams* params,
+                               const float* h, const float* x, const float* base_magg, const float* base_xsum,
+                               const float* base_deg, float* h_out, float* x_out, float* node_att_out,
+                               float* saved, void* workspace, size_t workspace_bytes, pvs_stream_t stream);
+
+/* The edges of `full` that touch a ligand atom (bp == 0), as a CSR over the same nodes, without a
+ * host round trip: rowptr_out [N+1] (its last entry = the edge count, pass it as
+ * PvsGraph.n_edges_dev), row/col/etype_out with room for `capacity` edges (the call fails through
+ * *status bit 2 if they do not fit). For pvs_egnn_layer_fwd_partial. */
+size_t pvs_graph_filter_workspace_bytes(int32_t n_nodes);
+int pvs_graph_filter_ligand_edges(const PvsGraph* full, const uint8_t* bp, int32_t capacity,
+                                  int32_t* rowptr_out, int32_t* row_out, int32_t* col_out, uint8_t* etype_out,
+                                  int32_t* status, void* workspace, size_t workspace_bytes, pvs_stream_t stream);
 
 /* Backward of the above (what autograd replays for the reference, SURVEY.md §8a "Backward spec").
  *   g_h_out [N,H]; g_x_out [N,3] or NULL (=0: the last layer's x is unused);

@@ -28,7 +28,8 @@ class PvsGraph(C.Structure):
                 ('row', C.c_void_p), ('col', C.c_void_p), ('etype', C.c_void_p),
                 ('perm', C.c_void_p), ('colptr', C.c_void_p), ('cedge', C.c_void_p),
                 ('inv_deg', C.c_void_p), ('n_segments', C.c_int32),
-                ('seg_node_ptr', C.POINTER(C.c_int32)), ('seg_edge_ptr', C.POINTER(C.c_int32))]
+                ('seg_node_ptr', C.POINTER(C.c_int32)), ('seg_edge_ptr', C.POINTER(C.c_int32)),
+                ('n_edges_dev', C.c_void_p)]
 
 
 class PvsLayerParams(C.Structure):
@@ -48,7 +49,7 @@ _PROTOTYPES = {
     'pvs_radius_graph_state_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     'pvs_radius_graph_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     'pvs_radius_graph_count': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
-                                         C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_size_t, C.c_void_p]),
     'pvs_radius_graph_fill': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32] +
                               [C.c_void_p] * 10 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -64,6 +65,15 @@ _PROTOTYPES = {
     'pvs_egnn_layer_fwd': (C.c_int, [C.POINTER(PvsLayerDesc), C.POINTER(PvsGraph),
                                      C.POINTER(PvsLayerParams)] + [C.c_void_p] * 9 +
                            [C.c_void_p, C.c_size_t, C.c_void_p]),
+    'pvs_graph_filter_workspace_bytes': (C.c_size_t, [C.c_int32]),
+    'pvs_graph_filter_ligand_edges': (C.c_int, [C.POINTER(PvsGraph), C.c_void_p, C.c_int32] + [C.c_void_p] * 5 +
+                                      [C.c_void_p, C.c_size_t, C.c_void_p]),
+    'pvs_egnn_layer_edge_sums': (C.c_int, [C.POINTER(PvsLayerDesc), C.POINTER(PvsGraph),
+                                           C.POINTER(PvsLayerParams)] + [C.c_void_p] * 4 +
+                                 [C.c_void_p, C.c_size_t, C.c_void_p]),
+    'pvs_egnn_layer_fwd_partial': (C.c_int, [C.POINTER(PvsLayerDesc), C.POINTER(PvsGraph),
+                                             C.POINTER(PvsLayerParams)] + [C.c_void_p] * 9 +
+                                   [C.c_void_p, C.c_size_t, C.c_void_p]),
     'pvs_egnn_layer_bwd': (C.c_int, [C.POINTER(PvsLayerDesc), C.POINTER(PvsGraph),
                                      C.POINTER(PvsLayerParams)] + [C.c_void_p] * 11 +
                            [C.POINTER(PvsLayerGrads), C.c_void_p, C.c_size_t, C.c_void_p]),

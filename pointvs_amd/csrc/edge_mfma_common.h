@@ -19,6 +19,8 @@ constexpr int kTile = 32;
 #endif
 
 // Timing-only ablation switches (PVS_ABLATE env, tools/ablate.py): results are wrong when set.
+// internal: the forward writes the raw coordinate sums (no x, no 1/deg) into x_out (edge_sums)
+constexpr uint32_t kFwdRawXsum = 1u << 23;
 constexpr uint32_t kAblNoMfma = 1u << 24, kAblNoSilu = 1u << 25, kAblNoReduce = 1u << 26,
                    kAblNoGather = 1u << 27;
 

@@ -24,6 +24,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                 int e_lo, int e_hi) {
     constexpr int H = 32 * HB;
     constexpr int TS = H + 4;   // tile row stride (floats): conflict-free b128 writes / b32 reads
+    if (g.n_edges_dev) e_hi = min(e_hi, *g.n_edges_dev);   // edge count only known on the device
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int kWeightWords = BF16X3 ? 2 * 6 * 64 * 4 : 2 * H * H;
     float* W2s = smem;
@@ -91,10 +92,16 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                 if (upd) {
                     const float4 tx4 = sum_row_slots<HB>(accx);
                     if (lane == 0) {
-                        const float inv = g.inv_deg[row_id];
-                        io.x_out[3 * row_id] = io.x[3 * row_id] + tx4.x * inv;
-                        io.x_out[3 * row_id + 1] = io.x[3 * row_id + 1] + tx4.y * inv;
-                        io.x_out[3 * row_id + 2] = io.x[3 * row_id + 2] + tx4.z * inv;
+                        if (flags & kFwdRawXsum) {
+                            io.x_out[3 * row_id] = tx4.x;
+                            io.x_out[3 * row_id + 1] = tx4.y;
+                            io.x_out[3 * row_id + 2] = tx4.z;
+                        } else {
+                            const float inv = g.inv_deg[row_id];
+                            io.x_out[3 * row_id] = io.x[3 * row_id] + tx4.x * inv;
+                            io.x_out[3 * row_id + 1] = io.x[3 * row_id + 1] + tx4.y * inv;
+                            io.x_out[3 * row_id + 2] = io.x[3 * row_id + 2] + tx4.z * inv;
+                        }
                     }
                 }
             }
@@ -229,13 +236,14 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
 
 namespace {
 __global__ void k_init_fwd(float* __restrict__ Magg, const float* __restrict__ x, float* __restrict__ x_out,
-                           int N, int H) {
+                           int N, int H, int raw_xsum) {
     const int qpr = H / 4;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = t / qpr, q = t - n * qpr;
     if (n >= N) return;
     *reinterpret_cast<float4*>(Magg + (size_t)n * H + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q == 0 && x) { x_out[3 * n] = x[3 * n]; x_out[3 * n + 1] = x[3 * n + 1]; x_out[3 * n + 2] = x[3 * n + 2]; }
+    if (q == 0 && raw_xsum) { x_out[3 * n] = 0.f; x_out[3 * n + 1] = 0.f; x_out[3 * n + 2] = 0.f; }
+    else if (q == 0 && x) { x_out[3 * n] = x[3 * n]; x_out[3 * n + 1] = x[3 * n + 1]; x_out[3 * n + 2] = x[3 * n + 2]; }
 }
 }  // namespace
 
@@ -253,7 +261,7 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     {
         const long long threads = (long long)g.n_nodes * (H / 4);
         k_init_fwd<<<(int)((threads + 255) / 256), 256, 0, s>>>(io.Magg, (flags & PVS_UPDATE_COORDS) ? io.x : nullptr,
-                                                                io.x_out, g.n_nodes, H);
+                                                                io.x_out, g.n_nodes, H, (flags & kFwdRawXsum) ? 1 : 0);
         PVS_CHECK_LAUNCH();
     }
     if (g.n_edges == 0) return 0;

@@ -184,6 +184,80 @@ int pvs_build_csc(hipStream_t stream, const int32_t* col, int E, int N, int32_t*
     return 0;
 }
 
+// ---- the ligand-touching edges of a CSR (screening, see pvs_graph_filter_ligand_edges) ----
+namespace {
+// wave per row: count (FILL = false) or copy (FILL = true) the edges whose row or column is a ligand atom
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+k_filter_ligand(PvsGraph g, const uint8_t* __restrict__ bp, int capacity, int32_t* __restrict__ cnt,
+                const int32_t* __restrict__ rowptr_out, int32_t* __restrict__ row_out,
+                int32_t* __restrict__ col_out, uint8_t* __restrict__ etype_out, int32_t* __restrict__ status) {
+    const int lane = threadIdx.x & 63;
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (i >= g.n_nodes) return;
+    const bool lig_row = bp[i] == 0;
+    const int p0 = g.rowptr[i], p1 = g.rowptr[i + 1];
+    int done = 0;
+    const int base = FILL ? rowptr_out[i] : 0;
+    if (FILL && rowptr_out[g.n_nodes] > capacity) {
+        if (i == 0 && lane == 0) atomicOr(status, 4);
+        return;
+    }
+    for (int pb = p0; pb < p1; pb += 64) {
+        const int p = pb + lane;
+        int c = 0;
+        bool keep = false;
+        if (p < p1) {
+            c = g.col[p];
+            keep = lig_row || bp[c] == 0;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (FILL && keep) {
+            const int q = base + done + __popcll(m & ((1ull << lane) - 1ull));
+            row_out[q] = i;
+            col_out[q] = c;
+            if (etype_out) etype_out[q] = g.etype[p];
+        }
+        done += __popcll(m);
+    }
+    if (!FILL && lane == 0) cnt[i] = done;
+}
+}  // namespace
+
+extern "C" size_t pvs_graph_filter_workspace_bytes(int32_t N) {
+    size_t sb = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, sb, (const int32_t*)nullptr, (int32_t*)nullptr, N + 1);
+    return pvs_align_up(((size_t)N + 1) * sizeof(int32_t), 256) + pvs_align_up(sb, 256) + 512;
+}
+
+extern "C" int pvs_graph_filter_ligand_edges(const PvsGraph* full, const uint8_t* bp, int32_t capacity,
+                                             int32_t* rowptr_out, int32_t* row_out, int32_t* col_out,
+                                             uint8_t* etype_out, int32_t* status, void* workspace,
+                                             size_t workspace_bytes, pvs_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    PVS_REQUIRE(full && bp && rowptr_out && row_out && col_out && status && full->rowptr && full->col,
+                "pvs_graph_filter_ligand_edges: NULL");
+    PVS_REQUIRE(!full->n_edges_dev, "pvs_graph_filter_ligand_edges: needs a graph with a host-side edge count");
+    PVS_REQUIRE(etype_out == nullptr || full->etype, "pvs_graph_filter_ligand_edges: graph has no edge classes");
+    const int N = full->n_nodes;
+    PVS_REQUIRE(workspace_bytes >= pvs_graph_filter_workspace_bytes(N) - 512, "filter workspace too small");
+    PvsArena a(workspace, workspace_bytes);
+    int32_t* cnt = a.take<int32_t>((size_t)N + 1);
+    size_t sb = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, sb, (const int32_t*)nullptr, (int32_t*)nullptr, N + 1);
+    void* tmp = a.take<char>(sb);
+    PVS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), s));
+    PVS_CHECK_HIP(hipMemsetAsync(cnt + N, 0, sizeof(int32_t), s));
+    const int blocks = (N + 3) / 4;
+    k_filter_ligand<false><<<blocks, 256, 0, s>>>(*full, bp, capacity, cnt, nullptr, nullptr, nullptr, nullptr, status);
+    PVS_CHECK_LAUNCH();
+    PVS_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, sb, cnt, rowptr_out, N + 1, s));
+    k_filter_ligand<true><<<blocks, 256, 0, s>>>(*full, bp, capacity, nullptr, rowptr_out, row_out, col_out,
+                                                 etype_out, status);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
 namespace {
 template <bool TO_INPUT>
 __global__ void k_permute_rows(const float* __restrict__ src, float* __restrict__ dst,

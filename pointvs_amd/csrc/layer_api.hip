@@ -7,6 +7,8 @@
 
 #include <stdlib.h>
 
+static constexpr uint32_t kFwdRawXsumFlag = 1u << 23;   // == kFwdRawXsum of edge_mfma_common.h
+
 // PVS_EGNN_KERNELS=generic forces the generic (VALU/LDS) edge kernels everywhere: used by the
 // tests to cross-check the MFMA path against the generic one on the same inputs.
 static bool pvs_use_mfma() {
@@ -96,7 +98,7 @@ PvsNodeW make_node_w(const PvsLayerDesc* d, const PvsLayerParams* p) {
     return w;
 }
 
-int check_desc(const PvsLayerDesc* d, const PvsGraph* g, const PvsLayerParams* p) {
+int check_desc(const PvsLayerDesc* d, const PvsGraph* g, const PvsLayerParams* p, bool allow_dev_count = false) {
     PVS_REQUIRE(d && g && p, "NULL descriptor/graph/params");
     PVS_REQUIRE(pvs_edge_v0_supported(d->hidden),
                 "hidden size %d unsupported by this build (16, 32, 64)", d->hidden);
@@ -105,6 +107,8 @@ int check_desc(const PvsLayerDesc* d, const PvsGraph* g, const PvsLayerParams* p
     PVS_REQUIRE(!((d->flags & PVS_GATED_RESIDUAL) && (d->flags & PVS_REZERO)),
                 "gated_residual and rezero are incompatible");
     PVS_REQUIRE(g->n_nodes > 0 && g->n_edges >= 0, "bad graph sizes");
+    PVS_REQUIRE(allow_dev_count || !g->n_edges_dev, "a graph with a device-side edge count is only accepted by "
+                "pvs_egnn_layer_edge_sums / pvs_egnn_layer_fwd_partial");
     PVS_REQUIRE(d->n_edge_attr == 0 || g->etype, "graph has no edge types but layer expects %d",
                 d->n_edge_attr);
     PVS_REQUIRE(p->edge_w1 && p->edge_b1 && p->edge_w2 && p->edge_b2 && p->node_w1 && p->node_b1 &&
@@ -253,6 +257,8 @@ extern "C" size_t pvs_egnn_layer_workspace_bytes(const PvsLayerDesc* d, int32_t 
     g.n_nodes = N; g.n_edges = E;
     Dims m = make_dims(d, &g);
     PvsArena a(nullptr, 0);
+    if (backward == 2)   // pvs_egnn_layer_edge_sums / _fwd_partial: forward + a per-edge attention scratch
+        return carve_fwd(a, m, nullptr) + pvs_align_up((size_t)(E > 0 ? E : 1) * sizeof(float), 256) + 512;
     return (backward ? carve_bwd(a, m, nullptr) : carve_fwd(a, m, nullptr)) + 256;
 }
 
@@ -293,6 +299,109 @@ extern "C" int pvs_egnn_layer_fwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     if (!(d->flags & PVS_UPDATE_COORDS))
         PVS_CHECK_HIP(hipMemcpyAsync(x_out, x, sizeof(float) * 3 * (size_t)m.N,
                                      hipMemcpyDeviceToDevice, s));
+    PVS_TRY(node_mlp_forward(s, m, d, p, nw, h, Magg, sy1, w.u, so, stats, true, w.shift, w.slabs));
+    PVS_TRY(pvs_node_out_fwd(s, H, so, h, nw, d->flags, d->att_act, m.N, h_out, node_att_out));
+    return 0;
+}
+
+// ---- forward with part of every row's edges given as precomputed sums (screening: the
+// receptor-receptor messages of the first layer do not depend on the ligand pose) ----
+namespace {
+
+__global__ void k_combine_partial(float* __restrict__ Magg, float* __restrict__ x_out, const float* __restrict__ x,
+                                  const float* __restrict__ base_magg, const float* __restrict__ base_xsum,
+                                  const float* __restrict__ base_deg, const int32_t* __restrict__ rowptr,
+                                  int N, int H, int upd) {
+    const int qpr = H / 4;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = t / qpr, q = t - n * qpr;
+    if (n >= N) return;
+    float4* mp = reinterpret_cast<float4*>(Magg + (size_t)n * H + 4 * q);
+    const float4 b = *reinterpret_cast<const float4*>(base_magg + (size_t)n * H + 4 * q);
+    float4 m = *mp;
+    m.x += b.x; m.y += b.y; m.z += b.z; m.w += b.w;
+    *mp = m;
+    if (q == 0) {
+        if (upd) {
+            const float deg = base_deg[n] + (float)(rowptr[n + 1] - rowptr[n]);
+            const float inv = 1.0f / (deg > 1.f ? deg : 1.f);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                x_out[3 * n + c] = x[3 * n + c] + (base_xsum[3 * n + c] + x_out[3 * n + c]) * inv;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x_out[3 * n + c] = x[3 * n + c];
+        }
+    }
+}
+
+int partial_checks(const PvsLayerDesc* d, const PvsGraph* g, const PvsLayerParams* p) {
+    PVS_TRY(check_desc(d, g, p, true));
+    PVS_REQUIRE(pvs_use_mfma() && pvs_edge_mfma_supported(d->hidden, d->flags),
+                "partial-sum forward needs the MFMA edge kernel (H = 32 or 64, no softmax attention)");
+    PVS_REQUIRE(!(d->flags & PVS_EDGE_RESIDUAL), "partial-sum forward: edge_residual layers are not supported");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pvs_egnn_layer_edge_sums(const PvsLayerDesc* d, const PvsGraph* g, const PvsLayerParams* p,
+                                        const float* h, const float* x, float* magg, float* xsum,
+                                        void* workspace, size_t workspace_bytes, pvs_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    PVS_TRY(partial_checks(d, g, p));
+    PVS_REQUIRE(h && x && magg && xsum, "pvs_egnn_layer_edge_sums: NULL tensor");
+    const Dims m = make_dims(d, g);
+    PvsArena arena(workspace, workspace_bytes);
+    FwdWs w;
+    carve_fwd(arena, m, &w);
+    float* att = arena.take<float>((size_t)(m.E > 0 ? m.E : 1));
+    PVS_REQUIRE(arena.ok(), "pvs_egnn_layer_edge_sums: workspace too small (%zu < %zu)", workspace_bytes, arena.off);
+    const PvsEdgeW ew = make_edge_w(m, p);
+    PVS_TRY(node_pre_forward(s, m, p, h, w.PQ));
+    PvsEdgeFwdIO io;
+    io.PQ = w.PQ; io.x = x; io.m_prev = nullptr; io.Magg = magg; io.x_out = xsum; io.m_out = nullptr;
+    io.att_out = att; io.smax = w.smax; io.ssum = w.ssum;
+    PVS_TRY(pvs_launch_edge_fwd_mfma(s, m.H, *g, ew, d->flags | kFwdRawXsumFlag, d->att_act, io));
+    if (!(d->flags & PVS_UPDATE_COORDS))
+        PVS_CHECK_HIP(hipMemsetAsync(xsum, 0, sizeof(float) * 3 * (size_t)m.N, s));
+    return 0;
+}
+
+extern "C" int pvs_egnn_layer_fwd_partial(const PvsLayerDesc* d, const PvsGraph* g, const PvsLayerParams* p,
+                                          const float* h, const float* x, const float* base_magg,
+                                          const float* base_xsum, const float* base_deg, float* h_out,
+                                          float* x_out, float* node_att_out, float* saved, void* workspace,
+                                          size_t workspace_bytes, pvs_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    PVS_TRY(partial_checks(d, g, p));
+    PVS_REQUIRE(h && x && base_magg && base_xsum && base_deg && h_out && x_out && saved,
+                "pvs_egnn_layer_fwd_partial: NULL tensor");
+    PVS_REQUIRE(x_out != x, "pvs_egnn_layer_fwd_partial: x_out must not alias x");
+    const Dims m = make_dims(d, g);
+    PvsArena arena(workspace, workspace_bytes);
+    FwdWs w;
+    carve_fwd(arena, m, &w);
+    float* att = arena.take<float>((size_t)(m.E > 0 ? m.E : 1));
+    PVS_REQUIRE(arena.ok(), "pvs_egnn_layer_fwd_partial: workspace too small (%zu < %zu)", workspace_bytes, arena.off);
+    const int H = m.H;
+    float* Magg = saved;
+    float* stats = saved + (size_t)m.N * H;
+    float* sPQ = stats + 2 * H;
+    float* sy1 = sPQ + 2 * (size_t)m.N * H;
+    float* so = sy1 + (size_t)m.N * H;
+    const PvsEdgeW ew = make_edge_w(m, p);
+    const PvsNodeW nw = make_node_w(d, p);
+    PVS_TRY(node_pre_forward(s, m, p, h, sPQ));
+    PvsEdgeFwdIO io;
+    io.PQ = sPQ; io.x = x; io.m_prev = nullptr; io.Magg = Magg; io.x_out = x_out; io.m_out = nullptr;
+    io.att_out = att; io.smax = w.smax; io.ssum = w.ssum;
+    PVS_TRY(pvs_launch_edge_fwd_mfma(s, H, *g, ew, d->flags | kFwdRawXsumFlag, d->att_act, io));
+    const long long threads = (long long)m.N * (H / 4);
+    k_combine_partial<<<(int)((threads + 255) / 256), 256, 0, s>>>(Magg, x_out, x, base_magg, base_xsum, base_deg,
+                                                                   g->rowptr, m.N, H,
+                                                                   (d->flags & PVS_UPDATE_COORDS) ? 1 : 0);
+    PVS_CHECK_LAUNCH();
     PVS_TRY(node_mlp_forward(s, m, d, p, nw, h, Magg, sy1, w.u, so, stats, true, w.shift, w.slabs));
     PVS_TRY(pvs_node_out_fwd(s, H, so, h, nw, d->flags, d->att_act, m.N, h_out, node_att_out));
     return 0;

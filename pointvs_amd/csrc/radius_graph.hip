@@ -99,7 +99,7 @@ k_radius_masks(const float* __restrict__ pos, const uint8_t* __restrict__ bp,
                const int32_t* __restrict__ gptr, const int32_t* __restrict__ blk_graph,
                const int32_t* __restrict__ blk_row0, const int32_t* __restrict__ n_blocks,
                const long long* __restrict__ mask_off, Radius r_inter, Radius r_intra, Radius r_zero,
-               unsigned long long* __restrict__ masks, int32_t* __restrict__ cnt_inter,
+               int pair_filter, unsigned long long* __restrict__ masks, int32_t* __restrict__ cnt_inter,
                int32_t* __restrict__ cnt_intra) {
     if ((int)blockIdx.x >= *n_blocks) return;
     __shared__ double rx[kRowsPerBlock], ry[kRowsPerBlock], rz[kRowsPerBlock];
@@ -134,7 +134,9 @@ k_radius_masks(const float* __restrict__ pos, const uint8_t* __restrict__ bp,
             s = __dadd_rn(s, __dmul_rn(d1, d1));
             s = __dadd_rn(s, __dmul_rn(d2, d2));
             bool e_inter = false, e_intra = false;
-            if (jok && s <= far && above(s, r_zero)) {       // 1e-7 < d, d < radius
+            // pair_filter 1: only pairs that touch a ligand atom (bp == 0)
+            const bool wanted = pair_filter == 0 || rbp[li] == 0 || bpj == 0;
+            if (jok && wanted && s <= far && above(s, r_zero)) {       // 1e-7 < d, d < radius
                 e_inter = rbp[li] != bpj && below(s, r_inter);
                 e_intra = below(s, r_intra);
             }
@@ -286,7 +288,7 @@ extern "C" size_t pvs_radius_graph_workspace_bytes(int32_t N, int32_t n_graphs, 
 // = E: the caller reads that one int32 back to size the arrays of step 2.
 extern "C" int pvs_radius_graph_count(const float* pos, const uint8_t* bp, const int32_t* graph_ptr,
                                       int32_t n_graphs, int32_t N, int32_t max_graph_nodes,
-                                      double inter_radius, double intra_radius,
+                                      double inter_radius, double intra_radius, int32_t pair_filter,
                                       int32_t* rowptr, int32_t* inter_ptr, int32_t* intra_ptr,
                                       void* state, size_t state_bytes, pvs_stream_t stream_) {
     hipStream_t s = (hipStream_t)stream_;
@@ -302,7 +304,7 @@ extern "C" int pvs_radius_graph_count(const float* pos, const uint8_t* bp, const
     PVS_CHECK_LAUNCH();
     k_radius_masks<<<mb, kThreads, 0, s>>>(pos, bp, graph_ptr, w.blk_graph, w.blk_row0, w.n_blocks, w.mask_off,
                                            make_radius(inter_radius), make_radius(intra_radius),
-                                           make_radius(1e-7), w.masks, w.cnt_inter, w.cnt_intra);
+                                           make_radius(1e-7), pair_filter, w.masks, w.cnt_inter, w.cnt_intra);
     PVS_CHECK_LAUNCH();
     PVS_CHECK_HIP(hipMemsetAsync(w.cnt_inter + N, 0, sizeof(int32_t), s));
     PVS_CHECK_HIP(hipMemsetAsync(w.cnt_intra + N, 0, sizeof(int32_t), s));

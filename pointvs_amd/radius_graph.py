@@ -19,7 +19,7 @@ def _stream(dev):
 
 
 def radius_graph(pos, bp, graph_ptr=None, inter_radius=4.0, intra_radius=None, max_graph_nodes=None,
-                 need_backward=None):
+                 need_backward=None, ligand_pairs_only=False):
     """pos [N,3] fp32, bp [N] (0 ligand / 1 receptor), graph_ptr [B+1] node offsets of the batch's
     graphs (None: one graph). Returns a PreparedGraph identical, array for array, to
     prepare_graph(edge_index, one_hot(edge_attr, 3)) of the reference's generate_edges output for
@@ -27,7 +27,8 @@ def radius_graph(pos, bp, graph_ptr=None, inter_radius=4.0, intra_radius=None, m
     estimate_bonds": intra_radius = inter_radius (data_loaders.py:359-360). max_graph_nodes: size
     of the largest graph if the caller knows it (Batch.graph_node_counts), else read from graph_ptr.
     need_backward=False (default: `torch.is_grad_enabled()`) skips the by-column lists that only the
-    backward reads (one radix sort less)."""
+    backward reads (one radix sort less). ligand_pairs_only keeps only the pairs that touch a ligand
+    atom (the pose-dependent part of a screening graph, pointvs_amd/screening.py)."""
     if need_backward is None:
         need_backward = torch.is_grad_enabled()
     _lib.require_hip(pos, bp)
@@ -53,7 +54,8 @@ def radius_graph(pos, bp, graph_ptr=None, inter_radius=4.0, intra_radius=None, m
     state = torch.empty(st_bytes, dtype=torch.uint8, device=dev)
     _lib.check(lib.pvs_radius_graph_count(
         _lib.ptr(pos), _lib.ptr(bp8), _lib.ptr(gp), n_graphs, n, max_graph_nodes, float(inter_radius),
-        float(intra_radius), _lib.ptr(rowptr), _lib.ptr(inter_ptr), _lib.ptr(intra_ptr), _lib.ptr(state),
+        float(intra_radius), 1 if ligand_pairs_only else 0, _lib.ptr(rowptr), _lib.ptr(inter_ptr),
+        _lib.ptr(intra_ptr), _lib.ptr(state),
         st_bytes, _stream(dev)), 'pvs_radius_graph_count')
     n_edges = int(rowptr[n].item())        # E is data dependent: the one host sync of the builder
     e_alloc = max(n_edges, 1)

@@ -1,0 +1,160 @@
+"""Virtual-screening forward (BASELINE config 5): many rigid poses of one
+ligand against one receptor. Reference loop: `val` / inference.py
+(/root/reference/point_vs/models/point_neural_network_base.py:208-360, point_vs/inference.py:35-146).
+
+What is reused across poses: the receptor-receptor messages of the FIRST EGNN layer depend only on
+receptor features and coordinates, so their per-node sums are computed once
+(`pvs_egnn_layer_edge_sums` on the receptor-only graph); per batch the first layer only runs over
+the edges that touch a ligand atom (`pvs_egnn_layer_fwd_partial`), the other layers over the full
+graph. Graphs are built on the GPU from the coordinates (radius_graph.py). Scores equal the plain
+`model(batch)` forward up to fp32 summation order.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from . import functional as PF
+from .radius_graph import PoseBatcher, radius_graph
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class ReceptorScreen:
+    """scores = ReceptorScreen(model, rec_pos, feats, n_lig, batch_size, edge_radius)(lig_poses)
+
+    feats [n_lig + n_rec, F]: ligand rows first, last column = bp (preprocessing.make_bit_vector);
+    lig_poses [batch_size, n_lig, 3] on the device. Returns the model's raw outputs [batch_size, ...]."""
+
+    def __init__(self, model, rec_pos, feats, n_lig, batch_size, edge_radius, intra_radius=None):
+        layers = list(model.layers)
+        self.model, self.embed, self.egnn = model, layers[0], layers[1:]
+        first = self.egnn[0]
+        self.reuse = (first.hidden_nf in (32, 64) and not first.softmax_attention
+                      and not first.edge_residual and len(self.egnn) > 0)
+        dev = rec_pos.device
+        self.batcher = PoseBatcher(rec_pos, feats, n_lig, batch_size, edge_radius, intra_radius)
+        self.n_lig, self.b = n_lig, batch_size
+        self.r_inter = edge_radius
+        self.r_intra = edge_radius if intra_radius is None else intra_radius
+        self._lig_buf, self._pending, self._l1_ws = None, None, None
+        if not self.reuse:
+            return
+        lib = _lib.lib()
+        n_rec = rec_pos.shape[0]
+        with torch.no_grad():
+            feats_rec = feats[n_lig:].to(dev).float()
+            h_rec = self.embed.embed(feats_rec, rec_pos)
+            pg = radius_graph(rec_pos, torch.ones(n_rec, dtype=torch.uint8, device=dev), None,
+                              self.r_inter, self.r_intra, need_backward=False)
+            desc = _lib.PvsLayerDesc(*first._desc())
+            params = [None if p is None else p.detach().float().contiguous() for p in first._params()]
+            pstruct = _lib.PvsLayerParams(*[_lib.ptr(p) for p in params])
+            magg = torch.empty((n_rec, first.hidden_nf), dtype=torch.float32, device=dev)
+            xsum = torch.empty((n_rec, 3), dtype=torch.float32, device=dev)
+            ws_bytes = lib.pvs_egnn_layer_workspace_bytes(C.byref(desc), n_rec, pg.n_edges, 2)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.pvs_egnn_layer_edge_sums(
+                C.byref(desc), C.byref(pg.c), C.byref(pstruct), _lib.ptr(h_rec.contiguous()),
+                _lib.ptr(rec_pos.contiguous()), _lib.ptr(magg), _lib.ptr(xsum), _lib.ptr(ws), ws_bytes,
+                _stream(dev)), 'pvs_egnn_layer_edge_sums')
+            deg = (pg.t['rowptr'][1:] - pg.t['rowptr'][:-1]).float()
+            n = n_lig + n_rec
+            # batch layout: [ligand rows (no base) | receptor rows] per pose
+            self.base_magg = torch.zeros((batch_size, n, first.hidden_nf), dtype=torch.float32, device=dev)
+            self.base_xsum = torch.zeros((batch_size, n, 3), dtype=torch.float32, device=dev)
+            self.base_deg = torch.zeros((batch_size, n), dtype=torch.float32, device=dev)
+            self.base_magg[:, n_lig:] = magg
+            self.base_xsum[:, n_lig:] = xsum
+            self.base_deg[:, n_lig:] = deg
+            torch.cuda.current_stream(dev).synchronize()    # ws / pg go out of scope
+
+    def _ligand_graph(self, batch):
+        """CSR of the full graph's ligand-touching edges, filtered on the device (no host round trip);
+        the edge count stays on the device (PvsGraph.n_edges_dev)."""
+        lib = _lib.lib()
+        full = batch.prepared
+        dev = batch.pos.device
+        n = full.n_nodes
+        if self._lig_buf is None:
+            # one synchronous probe sizes the buffers; later batches are checked asynchronously
+            probe = radius_graph(batch.pos, batch.x[:, -1], batch.ptr, self.r_inter, self.r_intra,
+                                 max_graph_nodes=self.batcher.n, need_backward=False, ligand_pairs_only=True)
+            cap = min(4 * self.n_lig * self.batcher.n * self.b, 2 * probe.n_edges + 4096)
+            i32 = dict(dtype=torch.int32, device=dev)
+            self._lig_buf = dict(
+                cap=cap, rowptr=torch.empty(n + 1, **i32), row=torch.empty(cap, **i32), col=torch.empty(cap, **i32),
+                etype=torch.empty(cap, dtype=torch.uint8, device=dev), status=torch.zeros(1, **i32),
+                ones=torch.ones(n, dtype=torch.float32, device=dev),
+                ws=torch.empty(lib.pvs_graph_filter_workspace_bytes(n), dtype=torch.uint8, device=dev),
+                bp=batch.x[:, -1].to(torch.uint8).contiguous(),
+                host=torch.zeros(1, dtype=torch.int32).pin_memory())
+        b = self._lig_buf
+        self.check()      # the previous batch's overflow flag has landed by now
+        _lib.check(lib.pvs_graph_filter_ligand_edges(
+            C.byref(full.c), _lib.ptr(b['bp']), b['cap'], _lib.ptr(b['rowptr']), _lib.ptr(b['row']),
+            _lib.ptr(b['col']), _lib.ptr(b['etype']), _lib.ptr(b['status']), _lib.ptr(b['ws']), b['ws'].numel(),
+            _stream(dev)), 'pvs_graph_filter_ligand_edges')
+        b['host'].copy_(b['status'], non_blocking=True)
+        self._pending = torch.cuda.Event()
+        self._pending.record(torch.cuda.current_stream(dev))
+        g = _lib.PvsGraph()
+        g.n_nodes, g.n_edges = n, b['cap']
+        g.rowptr, g.row, g.col, g.etype = (_lib.ptr(b[k]) for k in ('rowptr', 'row', 'col', 'etype'))
+        g.inv_deg = _lib.ptr(b['ones'])
+        g.n_edges_dev = b['rowptr'][n:].data_ptr()
+        return g
+
+    def check(self):
+        """Raises if the ligand-edge buffers of an earlier batch were too small (checked one batch
+        late so that the loop never waits for the device; call once more after the last batch)."""
+        if self._pending is not None:
+            self._pending.synchronize()
+            self._pending = None
+            if int(self._lig_buf['host'].item()) & 4:
+                raise RuntimeError('ReceptorScreen: ligand-edge buffer overflow (more ligand contacts than '
+                                   'twice the first batch); rebuild the screen with a larger probe')
+
+    def _first_layer(self, batch, h, x):
+        lib = _lib.lib()
+        first = self.egnn[0]
+        dev = h.device
+        g = self._ligand_graph(batch)
+        desc = _lib.PvsLayerDesc(*first._desc())
+        params = [None if p is None else p.detach().float().contiguous() for p in first._params()]
+        pstruct = _lib.PvsLayerParams(*[_lib.ptr(p) for p in params])
+        n = h.shape[0]
+        h_out, x_out = torch.empty_like(h), torch.empty_like(x)
+        natt = torch.empty(n, dtype=torch.float32, device=dev) if first.node_attention else None
+        if self._l1_ws is None:
+            self._l1_ws = (
+                torch.empty(lib.pvs_egnn_layer_saved_floats(C.byref(desc), n, g.n_edges), dtype=torch.float32,
+                            device=dev),
+                torch.empty(lib.pvs_egnn_layer_workspace_bytes(C.byref(desc), n, g.n_edges, 2), dtype=torch.uint8,
+                            device=dev))
+        saved, ws = self._l1_ws
+        _lib.check(lib.pvs_egnn_layer_fwd_partial(
+            C.byref(desc), C.byref(g), C.byref(pstruct), _lib.ptr(h), _lib.ptr(x),
+            _lib.ptr(self.base_magg), _lib.ptr(self.base_xsum), _lib.ptr(self.base_deg), _lib.ptr(h_out),
+            _lib.ptr(x_out), _lib.ptr(natt), _lib.ptr(saved), _lib.ptr(ws), ws.numel(), _stream(dev)),
+            'pvs_egnn_layer_fwd_partial')
+        return h_out, x_out
+
+    @torch.no_grad()
+    def __call__(self, lig_poses):
+        batch = self.batcher.load(lig_poses)
+        model = self.model
+        if not self.reuse:
+            return model(batch)
+        h = self.embed.embed(batch.x.float(), batch.pos).contiguous()
+        x = batch.pos.contiguous()
+        h, x = self._first_layer(batch, h, x)
+        m_sorted = None
+        for layer in self.egnn[1:]:
+            h, x, m_sorted = layer.forward_prepared(batch.prepared, h, x, m_sorted, need_m=layer.edge_residual)
+        graph_ptr = batch.ptr.to(device=h.device, dtype=torch.int32)
+        if model.feats_linear_layers is None:
+            return h
+        return model._run_head(model.feats_linear_layers, model._pool(h, graph_ptr, self.b))

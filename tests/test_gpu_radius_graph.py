@@ -123,3 +123,33 @@ def test_pose_batcher_matches_a_collated_batch_of_the_same_poses():
     with torch.no_grad():
         slow = model(Batch.from_data_list(items).to('cuda')).reshape(-1).cpu()
     assert torch.equal(fast, slow)
+
+
+@pytest.mark.parametrize('flags', [dict(), dict(edge_attention=True, node_attention=True, tanh=True, residual=True),
+                                   dict(k=64, normalize=True, graphnorm=True)])
+def test_receptor_screen_matches_the_plain_forward(flags):
+    """First-layer receptor-receptor sums reused across poses (pointvs_amd/screening.py) == plain
+    forward of the same poses, to fp32 summation order (rel 1e-5 per tensor)."""
+    import tempfile
+    from pointvs_amd.egnn_satorras import SartorrasEGNN
+    from pointvs_amd.radius_graph import PoseBatcher
+    from pointvs_amd.screening import ReceptorScreen
+    from pointvs_amd.synthetic import random_poses, screening_set
+    lig, rec, feats = screening_set(seed=5002, n_nodes=500, n_lig=14)
+    poses = random_poses(lig, 8, seed=4, max_shift=5.0).cuda()
+    kw = dict(dim_input=12, k=32, dim_output=1, num_layers=3, residual=False, edge_residual=False,
+              edge_attention=False, normalize=False, tanh=False, dropout=0.0, graphnorm=False, update_coords=True,
+              permutation_invariance=False, node_attention=False, gated_residual=False, rezero=False,
+              softmax_attention=False, model_task='classification')
+    kw.update(flags)
+    torch.manual_seed(1)
+    model = SartorrasEGNN(tempfile.mkdtemp(), 2e-3, 1e-4, silent=True, **kw).eval()
+    screen = ReceptorScreen(model, rec.cuda(), feats, 14, 4, edge_radius=7.0)
+    assert screen.reuse
+    plain = PoseBatcher(rec.cuda(), feats, 14, 4, edge_radius=7.0)
+    for k in range(2):
+        fast = screen(poses[4 * k:4 * k + 4]).reshape(-1)
+        with torch.no_grad():
+            slow = model(plain.load(poses[4 * k:4 * k + 4])).reshape(-1)
+        err = float((fast - slow).abs().max() / slow.abs().max().clamp_min(1e-30))
+        assert err < 1e-5, err
