@@ -301,15 +301,18 @@ __device__ __forceinline__ void split_bf16x3(const float (&v)[16], Bf16Parts& ou
 
 // Stage W[32][32] (row-major, W[out][in]) as bf16x3 A operands: dst[((part*2 + s)*64 + l)*4 .. +3]
 // (uint words) = 8 bf16 of W[l&31][ch(8s + j', l>>5)], j' = 0..7, part in {hi, mid, lo}.
+// ld / row0 / col0: the 32x32 block W[row0 + .][col0 + .] of a matrix with row stride ld.
 __device__ __forceinline__ void stage_weights_bf16x3(unsigned* dst, const float* __restrict__ W,
-                                                     bool transpose = false) {
+                                                     bool transpose = false, int ld = 32, int row0 = 0,
+                                                     int col0 = 0) {
     // transpose: operand rows are the columns of W (Z = W^T V)
+    W += (size_t)row0 * ld + col0;
     for (int i = threadIdx.x; i < 2 * 64 * 4; i += blockDim.x) {
         const int q = i & 3, l = (i >> 2) & 63, s = i >> 8;
         const int o = l & 31, hh = l >> 5;
         const int k0 = xch(8 * s + 2 * q, hh), k1 = xch(8 * s + 2 * q + 1, hh);
-        const float x0 = transpose ? W[k0 * 32 + o] : W[o * 32 + k0];
-        const float x1 = transpose ? W[k1 * 32 + o] : W[o * 32 + k1];
+        const float x0 = transpose ? W[k0 * ld + o] : W[o * ld + k0];
+        const float x1 = transpose ? W[k1 * ld + o] : W[o * ld + k1];
         const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
         const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
         const float t0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
@@ -339,6 +342,43 @@ __device__ __forceinline__ void mfma_chain_bf16x3(const unsigned* __restrict__ W
     }
 }
 
+
+// H = 32*HB: all HB x HB blocks of W (row-major [H][H]) staged block after block ((bo*HB + bi) * 6 KB),
+// and the product acc[bo] += sum_bi W[bo][bi] v[bi] with each input block split once.
+template <int HB>
+__device__ __forceinline__ void stage_weights_bf16x3_blocks(unsigned* dst, const float* __restrict__ W) {
+#pragma unroll
+    for (int bo = 0; bo < HB; ++bo)
+#pragma unroll
+        for (int bi = 0; bi < HB; ++bi)
+            stage_weights_bf16x3(dst + (bo * HB + bi) * (6 * 64 * 4), W, false, 32 * HB, 32 * bo, 32 * bi);
+}
+
+template <int HB>
+__device__ __forceinline__ void mfma_chain_bf16x3_blocks(const unsigned* __restrict__ Wb, int lane,
+                                                         const float (&v)[HB][16], f32x16 (&acc)[HB]) {
+#pragma unroll
+    for (int bi = 0; bi < HB; ++bi) {
+        Bf16Parts b;
+        split_bf16x3(v[bi], b);
+#pragma unroll
+        for (int bo = 0; bo < HB; ++bo) {
+            const unsigned* Wblk = Wb + (bo * HB + bi) * (6 * 64 * 4);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wblk + ((0 * 2 + s) * 64 + lane) * 4));
+                const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wblk + ((1 * 2 + s) * 64 + lane) * 4));
+                const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wblk + ((2 * 2 + s) * 64 + lane) * 4));
+                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.hi[s], acc[bo], 0, 0, 0);
+                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.lo[s], acc[bo], 0, 0, 0);
+                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.mid[s], acc[bo], 0, 0, 0);
+                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.hi[s], acc[bo], 0, 0, 0);
+                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.mid[s], acc[bo], 0, 0, 0);
+                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.hi[s], acc[bo], 0, 0, 0);
+            }
+        }
+    }
+}
 
 template <typename K>
 int set_lds(K kernel, size_t lds) {

@@ -18,15 +18,17 @@
 
 namespace {
 
-template <int HB, bool BF16X3>
-__global__ void __launch_bounds__(kThreads)
+template <int HB, bool BF16X3, int NT = kThreads>
+__global__ void __launch_bounds__(NT)
 k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdIO io, int n_chunks,
                 int e_lo, int e_hi) {
     constexpr int H = 32 * HB;
     constexpr int TS = H + 4;   // tile row stride (floats): conflict-free b128 writes / b32 reads
     if (g.n_edges_dev) e_hi = min(e_hi, *g.n_edges_dev);   // edge count only known on the device
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int kWeightWords = BF16X3 ? 2 * 6 * 64 * 4 : 2 * H * H;
+    constexpr int NW = NT / 64;
+    constexpr int kBlkWords = 6 * 64 * 4;                 // one 32x32 block as bf16x3: 6 KB
+    constexpr int kWeightWords = BF16X3 ? 2 * HB * HB * kBlkWords : 2 * H * H;
     float* W2s = smem;
     float* Wc1s = W2s + H * H;
     float* b2t = smem + kWeightWords;
@@ -42,18 +44,17 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
     const bool eatt = flags & PVS_EDGE_ATTENTION;
     const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
 
-    // BF16X3 (H = 32 only): each matrix takes 3 parts x 2 k-steps x 64 lanes x 16 B = 6 KB
-    static_assert(!BF16X3 || HB == 1, "bf16x3 variant is built for H = 32");
+    // BF16X3: each 32x32 block takes 3 parts x 2 k-steps x 64 lanes x 16 B = 6 KB
     unsigned* W2b = reinterpret_cast<unsigned*>(W2s);
-    unsigned* Wc1b = W2b + 6 * 64 * 4;
+    unsigned* Wc1b = W2b + HB * HB * kBlkWords;
     if constexpr (BF16X3) {
-        stage_weights_bf16x3(W2b, w.w2);
-        if (upd) stage_weights_bf16x3(Wc1b, w.wc1);
+        stage_weights_bf16x3_blocks<HB>(W2b, w.w2);
+        if (upd) stage_weights_bf16x3_blocks<HB>(Wc1b, w.wc1);
     } else {
         stage_weights<HB>(W2s, w.w2, false);
         if (upd) stage_weights<HB>(Wc1s, w.wc1, false);
     }
-    for (int c = threadIdx.x; c < H; c += kThreads) {
+    for (int c = threadIdx.x; c < H; c += NT) {
         b2t[c] = w.b2[c];
         bc1t[c] = upd ? w.bc1[c] : 0.f;
         wc2t[c] = upd ? w.wc2[c] : 0.f;
@@ -76,8 +77,8 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
         if (flags & PVS_GATED_RESIDUAL) gate = fmaxf(gate, 0.f);
     }
 
-    const int total_waves = gridDim.x * kWaves;
-    for (int chunk = pvs_xcd_block(blockIdx.x, gridDim.x) * kWaves + wv; chunk < n_chunks; chunk += total_waves) {
+    const int total_waves = gridDim.x * NW;
+    for (int chunk = pvs_xcd_block(blockIdx.x, gridDim.x) * NW + wv; chunk < n_chunks; chunk += total_waves) {
         const int e_begin = chunk_begin(g, chunk, n_chunks, e_lo, e_hi);
         const int e_end = chunk_begin(g, chunk + 1, n_chunks, e_lo, e_hi);
         int cur_row = -1;
@@ -143,7 +144,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[b][r] = bias[b][r];
-                if constexpr (BF16X3) mfma_chain_bf16x3(W2b, lane, a1[0], acc2[0]);
+                if constexpr (BF16X3) mfma_chain_bf16x3_blocks<HB>(W2b, lane, a1, acc2);
                 else mfma_chain<HB>(W2s, lane, a1, acc2, flags & kAblNoMfma);
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
@@ -185,7 +186,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) accc[b][r] = bias[b][r];
-                if constexpr (BF16X3) mfma_chain_bf16x3(Wc1b, lane, m[0], accc[0]);
+                if constexpr (BF16X3) mfma_chain_bf16x3_blocks<HB>(Wc1b, lane, m, accc);
                 else mfma_chain<HB>(Wc1s, lane, m, accc, flags & kAblNoMfma);
                 float q[HB][16];
 #pragma unroll
@@ -270,12 +271,27 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     PvsProfScope prof(s, PVS_PROF_EDGE_FWD);
     const int HB = H / 32;
     const char* bf = getenv("PVS_EGNN_BF16X3");
-    const bool bf16x3 = !(bf && bf[0] == '0') && H == 32;   // default for H = 32 (PVS_EGNN_BF16X3=0: fp32 MFMA)
-    const size_t words = (bf16x3 ? (size_t)2 * 6 * 64 * 4 : (size_t)2 * H * H) +
+    const char* bf64 = getenv("PVS_EGNN_BF16X3_H64");
+    // default: fp32 products as bf16x3 (PVS_EGNN_BF16X3=0: fp32 MFMAs; PVS_EGNN_BF16X3_H64=0: only for H = 64)
+    const bool bf16x3 = !(bf && bf[0] == '0') && (H == 32 || !(bf64 && bf64[0] == '0'));
+    // H = 64 bf16x3: 48 KB of weight operands, so one 512-thread workgroup per CU (8 waves, as before)
+    const int nw = (HB == 2 && bf16x3) ? 8 : kWaves;
+    if (nw != kWaves) {
+        blocks = (blocks + 1) / 2;
+        if (blocks > 256) blocks = 256;
+        const long long waves = (long long)blocks * nw;
+        long long per_wave = ((long long)g.n_edges + waves * 4096 - 1) / (waves * 4096);
+        if (per_wave < 1) per_wave = 1;
+        n_chunks = (int)(waves * per_wave);
+    }
+    const size_t words = (bf16x3 ? (size_t)2 * HB * HB * 6 * 64 * 4 : (size_t)2 * H * H) +
                          (5 + PVS_MAX_EDGE_ATTR) * H +
-                         (size_t)kWaves * (kTile * (H + 4) + kTile * 4 + kTile);
+                         (size_t)nw * (kTile * (H + 4) + kTile * 4 + kTile);
     const size_t lds = words * sizeof(float);
-    if (HB == 1 && bf16x3) {
+    if (HB == 2 && bf16x3) {
+        if (set_lds(k_edge_fwd_mfma<2, true, 512>, lds)) return -2;
+        k_edge_fwd_mfma<2, true, 512><<<blocks, 512, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
+    } else if (HB == 1 && bf16x3) {
         if (set_lds(k_edge_fwd_mfma<1, true>, lds)) return -2;
         k_edge_fwd_mfma<1, true><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
     } else if (HB == 1) {
