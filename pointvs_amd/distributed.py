@@ -40,18 +40,17 @@ class GradAllReducer:
             total = sum(self.params[i].numel() for i in live)
             self._flat = torch.empty(total, dtype=torch.float32, device=self.params[0].device)
         grads = [self.params[i].grad for i in live]
-        offset = 0
-        for g in grads:
-            n = g.numel()
-            self._flat[offset:offset + n].copy_(g.reshape(-1))
-            offset += n
+        # pack / unpack with one multi-tensor kernel each (34 tensors at cfg2: a per-tensor copy loop
+        # would cost more launches than the whole all-reduce)
+        torch.cat([g.reshape(-1) for g in grads], out=self._flat)
         dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
         self._flat.mul_(1.0 / world)
-        offset = 0
+        views, offset = [], 0
         for g in grads:
             n = g.numel()
-            g.copy_(self._flat[offset:offset + n].view_as(g))
+            views.append(self._flat[offset:offset + n].view_as(g))
             offset += n
+        torch._foreach_copy_(grads, views)
 
 
 def shard_range(n_items, rank, world):
