@@ -154,3 +154,50 @@ def test_grad_allreduce_gloo_world2():
         assert g1 is None
         assert torch.allclose(g0, expect0, atol=1e-6)
     assert torch.equal(out[0][2], out[1][2])
+
+
+def _overlap_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, str(ROOT))
+        from pointvs_amd.distributed import GradAllReducer, OverlappedGradAllReducer
+        res = {}
+        for name, cls in (('flat', GradAllReducer), ('overlap', OverlappedGradAllReducer)):
+            torch.manual_seed(0)
+            net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.SiLU(), torch.nn.Linear(8, 8),
+                                      torch.nn.SiLU(), torch.nn.Linear(8, 1))
+            unused = torch.nn.Parameter(torch.zeros(3))        # never receives a gradient
+            params = list(net.parameters()) + [unused]
+            red = cls(params)
+            steps = []
+            for step in range(3):
+                x = torch.randn(5, 6, generator=torch.Generator().manual_seed(10 * step + rank))
+                for p in params:
+                    p.grad = None
+                net(x).square().sum().backward()
+                red()
+                steps.append([None if p.grad is None else p.grad.clone() for p in params])
+            res[name] = steps
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_allreduce_matches_flat_gloo_world2():
+    """Bucketed exchange started from the backward hooks == the flat exchange, on every step."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_overlap_worker, args=(2, port, out), nprocs=2, join=True)
+    for rank in range(2):
+        for a, b in zip(out[rank]['flat'], out[rank]['overlap']):
+            for ga, gb in zip(a, b):
+                assert (ga is None) == (gb is None)
+                if ga is not None:
+                    assert torch.allclose(ga, gb, atol=1e-6)
+    for ga, gb in zip(out[0]['overlap'][-1], out[1]['overlap'][-1]):
+        assert ga is None or torch.equal(ga, gb)
