@@ -82,7 +82,11 @@ class OverlappedGradAllReducer:
             if b is None:
                 return
             b['ready'] += 1
-            if b['ready'] == len(b['idx']) and b['handle'] is None:
+            # collectives must be issued in the same order on every rank: bucket k only after
+            # buckets 0..k-1 (anything else waits for the end of the backward)
+            k = self._buckets.index(b)
+            if (b['ready'] == len(b['idx']) and b['handle'] is None
+                    and all(prev['handle'] is not None for prev in self._buckets[:k])):
                 self._launch(b)
         return hook
 
