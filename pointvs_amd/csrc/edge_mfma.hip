@@ -506,6 +506,99 @@ __device__ __forceinline__ void xwrite_block(float* __restrict__ T, int j, int h
             make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 }
 
+// ---- bf16x3 weights as ONE swizzled row-major image per part, read row-wise for W v and, through
+// ds_read_b64_tr_b16 (gfx950's transposing LDS read), column-wise for W^T v: half the LDS of two
+// pre-transposed copies. Element (r, c) of W [H][H] sits at 16-bit index
+//   r*H + 4*((c >> 2) ^ swz(r)) + (c & 3),   swz(r) = (r >> 1) & (H/4 - 1):
+// the 8-byte chunks of a row are permuted so that 32 lanes reading the same logical chunk of 32
+// consecutive rows hit 32 different bank pairs (row reads conflict-free, transposed reads 2-way).
+typedef short pvs_v4s __attribute__((ext_vector_type(4)));
+
+template <int HB>
+__device__ __forceinline__ int img_off(int r, int c) {
+    constexpr int H = 32 * HB, NCH = H / 4;
+    return r * H + 4 * ((c >> 2) ^ ((r >> 1) & (NCH - 1))) + (c & 3);
+}
+
+template <int HB>
+__device__ __forceinline__ void stage_weights_img(unsigned short* img, const float* __restrict__ W) {
+    constexpr int H = 32 * HB;
+    unsigned* hi = reinterpret_cast<unsigned*>(img);
+    unsigned* mid = reinterpret_cast<unsigned*>(img + H * H);
+    unsigned* lo = reinterpret_cast<unsigned*>(img + 2 * H * H);
+    for (int i = threadIdx.x; i < H * H / 2; i += blockDim.x) {
+        const int r = (2 * i) / H, c = (2 * i) % H;
+        const float x0 = W[r * H + c], x1 = W[r * H + c + 1];
+        const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
+        const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+        const float t0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+        const float t1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+        const int o = img_off<HB>(r, c) >> 1;
+        hi[o] = pvs_pack_hi16(x0, x1);
+        mid[o] = pvs_pack_hi16(r0, r1);
+        lo[o] = pvs_pack_hi16(t0, t1);
+    }
+}
+
+// A-operand fragment (8 bf16 in the k order of the X layout) of block (bo, bi), k-step s, of one part
+// image: TRANSPOSE = false: rows of W (W v); true: columns of W (W^T v) through the transposing read.
+template <int HB, bool TRANSPOSE>
+__device__ __forceinline__ bf16x8 img_fragment(const unsigned short* __restrict__ part, int lane, int bo,
+                                               int bi, int s) {
+    const int hh = lane >> 5;
+    uint2 a, b;
+    if constexpr (!TRANSPOSE) {
+        const int r = 32 * bo + (lane & 31), c0 = 32 * bi + 16 * s + 4 * hh;
+        a = *reinterpret_cast<const uint2*>(part + img_off<HB>(r, c0));
+        b = *reinterpret_cast<const uint2*>(part + img_off<HB>(r, c0 + 8));
+    } else {
+        // 16-lane group: lane 4q+p supplies row q, columns 4p..4p+3 of a 4x16 block and receives
+        // column (lane & 15) of its 4 rows
+        const int li = lane & 15, q = li >> 2, p = li & 3;
+        const int r0 = 32 * bi + 16 * s + 4 * hh, col = 32 * bo + 16 * ((lane >> 4) & 1) + 4 * p;
+        typedef pvs_v4s __attribute__((address_space(3))) * lds_v4s;
+        const pvs_v4s ta = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(part + img_off<HB>(r0 + q, col)));
+        const pvs_v4s tb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(part + img_off<HB>(r0 + 8 + q, col)));
+        a = __builtin_bit_cast(uint2, ta);
+        b = __builtin_bit_cast(uint2, tb);
+    }
+    return __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
+}
+
+// acc (output block cb) += sum over input blocks bi of W(cb,bi) v_bi as six bf16 MFMA terms per
+// k-step; v_cb from registers, the other blocks from the tile T.
+template <int HB, bool TRANSPOSE>
+__device__ __forceinline__ void chain_team_b3(const unsigned short* __restrict__ img, int lane, int cb,
+                                              const float (&own)[16], const float* __restrict__ T,
+                                              f32x16& acc) {
+    constexpr int H = 32 * HB;
+    const int j = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int bi = 0; bi < HB; ++bi) {
+        float v[16];
+        if (bi == cb) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[t] = own[t];
+        } else {
+            xread_block<HB>(T, j, hh, bi, v);
+        }
+        Bf16Parts b;
+        split_bf16x3(v, b);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 ah = img_fragment<HB, TRANSPOSE>(img, lane, cb, bi, s);
+            const bf16x8 am = img_fragment<HB, TRANSPOSE>(img + H * H, lane, cb, bi, s);
+            const bf16x8 al = img_fragment<HB, TRANSPOSE>(img + 2 * H * H, lane, cb, bi, s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.hi[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.lo[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.mid[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.hi[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.mid[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.hi[s], acc, 0, 0, 0);
+        }
+    }
+}
+
 // acc (output block cb) += sum over input blocks bi of W(cb,bi) v_bi ; v_cb from registers, the
 // other blocks from the tile T. Wn natural padded [H][H+1]; TRANSPOSE: W^T.
 template <int HB, bool TRANSPOSE>
@@ -551,15 +644,20 @@ __device__ __forceinline__ void load16_tab(const float* __restrict__ tab, int hh
     }
 }
 
-template <int HB, bool ERES, bool EATT>
+template <int HB, bool ERES, bool EATT, bool BF16X3 = false>
 __global__ void __launch_bounds__(512, 2)
 k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks,
                 int e_lo, int e_hi) {
     constexpr int H = 32 * HB, TS = H + 4, NT = 512, NW = NT / 64, TEAMS = NW / HB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // fp32: natural padded weights [H][H+1] serving W and W^T; BF16X3: one swizzled bf16 image per
+    // part (3 x H*H x 2 B per matrix), also serving both
+    constexpr int kWeightFloats = BF16X3 ? 2 * 3 * H * H / 2 : 2 * H * (H + 1);
     float* W2n = smem;
     float* Wc1n = W2n + H * (H + 1);
-    float* b2t = Wc1n + H * (H + 1);
+    unsigned short* W2i = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* Wc1i = W2i + 3 * H * H;
+    float* b2t = smem + kWeightFloats;
     float* bc1t = b2t + H;
     float* wc2t = bc1t + H;
     float* wat = wc2t + H;
@@ -573,8 +671,13 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
 
     const bool upd = (flags & PVS_UPDATE_COORDS) && io.gxagg != nullptr;
 
-    stage_weights_nat<HB>(W2n, w.w2);
-    if (upd) stage_weights_nat<HB>(Wc1n, w.wc1);
+    if constexpr (BF16X3) {
+        stage_weights_img<HB>(W2i, w.w2);
+        if (upd) stage_weights_img<HB>(Wc1i, w.wc1);
+    } else {
+        stage_weights_nat<HB>(W2n, w.w2);
+        if (upd) stage_weights_nat<HB>(Wc1n, w.wc1);
+    }
     for (int c = threadIdx.x; c < H; c += NT) {
         b2t[c] = w.b2[c];
         bc1t[c] = upd ? w.bc1[c] : 0.f;
@@ -696,7 +799,8 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 load16_tab(b2t + co, hh, bias);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[r] = bias[r];
-                chain_team<HB, false>(W2n, lane, cb, a1, T0, acc2);
+                if constexpr (BF16X3) chain_team_b3<HB, false>(W2i, lane, cb, a1, T0, acc2);
+                else chain_team<HB, false>(W2n, lane, cb, a1, T0, acc2);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float z2 = acc2[r];
@@ -758,7 +862,8 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 load16_tab(bc1t + co, hh, bias2);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accc[r] = bias2[r];
-                chain_team<HB, false>(Wc1n, lane, cb, m, T1, accc);
+                if constexpr (BF16X3) chain_team_b3<HB, false>(Wc1i, lane, cb, m, T1, accc);
+                else chain_team<HB, false>(Wc1n, lane, cb, m, T1, accc);
                 float q[16], dq[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -786,7 +891,8 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 }
                 xwrite_block<HB>(T2, j, hh, cb, g_zc);
                 __syncthreads();                                                 // (4) T2 = g_zc complete
-                chain_team<HB, true>(Wc1n, lane, cb, g_zc, T2, gm);              // g_m += Wc1^T g_zc
+                if constexpr (BF16X3) chain_team_b3<HB, true>(Wc1i, lane, cb, g_zc, T2, gm);   // g_m += Wc1^T g_zc
+                else chain_team<HB, true>(Wc1n, lane, cb, g_zc, T2, gm);
             } else if (EATT) {
                 __syncthreads();                                                 // glb visible
             }
@@ -844,7 +950,8 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
             f32x16 ga1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ga1[r] = 0.f;
-            chain_team<HB, true>(W2n, lane, cb, g_z2, T2, ga1);
+            if constexpr (BF16X3) chain_team_b3<HB, true>(W2i, lane, cb, g_z2, T2, ga1);
+            else chain_team<HB, true>(W2n, lane, cb, g_z2, T2, ga1);
             float g_z1[16];
             z1_own(g_z1);
 #pragma unroll
@@ -1031,19 +1138,27 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
         blocks = (int)b;
         n_chunks = (int)(teams * per_team);
         *n_slabs = blocks;
-        size_t tw = (size_t)2 * H * (H + 1) + (5 + PVS_MAX_EDGE_ATTR) * H + 16 +
+        const char* bf64 = getenv("PVS_EGNN_BF16X3_H64");
+        const bool team_b3 = !(bf && bf[0] == '0') && !(bf64 && bf64[0] == '0');   // bf16x3 chain products
+        size_t tw = (team_b3 ? (size_t)3 * H * H : (size_t)2 * H * (H + 1)) + (5 + PVS_MAX_EDGE_ATTR) * H + 16 +
                     (size_t)kTeams * (3 * kTile * (H + 4) + kTile * 4 + 2 * kTile + 2 * 2 * kTile);
         if (tw < (size_t)L.total) tw = L.total;
         const size_t tlds = tw * sizeof(float);
-#define PVS_TEAM_LAUNCH(ER, EA)                                                                    \
+#define PVS_TEAM_LAUNCH(ER, EA, B3)                                                                \
     do {                                                                                          \
-        if (set_lds(k_edge_bwd_team<2, ER, EA>, tlds)) return -2;                                 \
-        k_edge_bwd_team<2, ER, EA><<<blocks, 512, tlds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi); \
+        if (set_lds(k_edge_bwd_team<2, ER, EA, B3>, tlds)) return -2;                             \
+        k_edge_bwd_team<2, ER, EA, B3><<<blocks, 512, tlds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi); \
     } while (0)
-        if (eres && eatt) PVS_TEAM_LAUNCH(true, true);
-        else if (eres) PVS_TEAM_LAUNCH(true, false);
-        else if (eatt) PVS_TEAM_LAUNCH(false, true);
-        else PVS_TEAM_LAUNCH(false, false);
+#define PVS_TEAM_PICK(B3)                                     \
+    do {                                                      \
+        if (eres && eatt) PVS_TEAM_LAUNCH(true, true, B3);    \
+        else if (eres) PVS_TEAM_LAUNCH(true, false, B3);      \
+        else if (eatt) PVS_TEAM_LAUNCH(false, true, B3);      \
+        else PVS_TEAM_LAUNCH(false, false, B3);               \
+    } while (0)
+        if (team_b3) PVS_TEAM_PICK(true);
+        else PVS_TEAM_PICK(false);
+#undef PVS_TEAM_PICK
 #undef PVS_TEAM_LAUNCH
     }
 #undef PVS_BWD_PICK
