@@ -21,7 +21,13 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     static_assert(!BF16X3 || HB == 1, "bf16x3 variant is built for H = 32");
     constexpr int NT = BF16X3 ? 512 : kThreads;
     constexpr int NW = NT / 64;
-    constexpr int kWeightWords = BF16X3 ? 4 * 6 * 64 * 4 : 2 * H * (H + 1);
+#ifndef PVS_BWD_IMG
+#define PVS_BWD_IMG 1   // bf16x3: one weight image per matrix (W and W^T), SiLU'(z1) kept in LDS
+#endif
+    constexpr bool IMG = BF16X3 && PVS_BWD_IMG;
+    constexpr int kWeightWords = IMG ? 2 * 3 * H * H / 2 : (BF16X3 ? 4 * 6 * 64 * 4 : 2 * H * (H + 1));
+    unsigned short* W2i = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* Wc1i = W2i + 3 * H * H;
     float* W2n = smem;
     float* Wc1n = W2n + H * (H + 1);
     unsigned* W2b = reinterpret_cast<unsigned*>(smem);      // z2 = W2 a1
@@ -42,7 +48,10 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     constexpr bool eatt = EATT;
     constexpr bool eres = ERES;
 
-    if constexpr (BF16X3) {
+    if constexpr (IMG) {
+        stage_weights_img<HB>(W2i, w.w2);
+        if (upd) stage_weights_img<HB>(Wc1i, w.wc1);
+    } else if constexpr (BF16X3) {
         stage_weights_bf16x3(W2b, w.w2, false);
         stage_weights_bf16x3(W2tb, w.w2, true);
         if (upd) {
@@ -72,6 +81,9 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     float* tx = T2 + kTile * TS;
     float* glb = tx + kTile * 4;
     int* rowbuf = reinterpret_cast<int*>(glb + kTile);
+    // IMG: SiLU'(z1) of the tile, X layout, private to the lane (4 KB per wave) instead of
+    // re-gathering and re-evaluating z1 after the W2^T product
+    float* d1b = wave_base + NW * kWaveFloats + wv * (16 * 64);
     const float bac = eatt ? w.ba[0] : 0.f;
     float gate_raw = 0.f, gate = 1.f;
     if (eres && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
@@ -142,10 +154,25 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
             {
                 float a1[HB][16];
                 assemble_z1<HB>(G, attrt, wrhot, ty, hh, rho, a1);
+                if constexpr (IMG) {
 #pragma unroll
-                for (int b = 0; b < HB; ++b)
+                    for (int gq = 0; gq < 4; ++gq) {
+                        float dd[4];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) a1[b][r] = pvs_silu(a1[b][r]);
+                        for (int q = 0; q < 4; ++q) {
+                            const float z = a1[0][4 * gq + q];
+                            const float sg = pvs_sigmoid(z);
+                            dd[q] = pvs_silu_grad(z, sg);
+                            a1[0][4 * gq + q] = z * sg;
+                        }
+                        *reinterpret_cast<float4*>(d1b + (gq * 64 + lane) * 4) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int b = 0; b < HB; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) a1[b][r] = pvs_silu(a1[b][r]);
+                }
                 // a1 edge-major in T0 for the W2 weight gradient (zero rows for padded slots)
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
@@ -161,7 +188,8 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[b][r] = bias[b][r];
-                if constexpr (BF16X3) mfma_chain_bf16x3(W2b, lane, a1[0], acc2[0]);
+                if constexpr (IMG) mfma_chain_img<false>(W2i, lane, a1[0], acc2[0]);
+                else if constexpr (BF16X3) mfma_chain_bf16x3(W2b, lane, a1[0], acc2[0]);
                 else mfma_chain_nat<HB, false>(W2n, lane, a1, acc2, flags & kAblNoMfma);
                 float dz2[HB][16], m[HB][16];     // SiLU'(z2) and the message
                 float m_new[ERES ? HB : 1][16], mp[ERES ? HB : 1][16];
@@ -241,7 +269,8 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                     for (int b = 0; b < HB; ++b)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) accc[b][r] = bias2[b][r];
-                    if constexpr (BF16X3) mfma_chain_bf16x3(Wc1b, lane, m[0], accc[0]);
+                    if constexpr (IMG) mfma_chain_img<false>(Wc1i, lane, m[0], accc[0]);
+                    else if constexpr (BF16X3) mfma_chain_bf16x3(Wc1b, lane, m[0], accc[0]);
                     else mfma_chain_nat<HB, false>(Wc1n, lane, m, accc, flags & kAblNoMfma);
                     float q[HB][16], dq[HB][16];
 #pragma unroll
@@ -275,7 +304,8 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                             *reinterpret_cast<float4*>(T2 + j * TS + 32 * b + 8 * gq + 4 * hh) =
                                 make_float4(g_zc[b][4 * gq], g_zc[b][4 * gq + 1], g_zc[b][4 * gq + 2],
                                             g_zc[b][4 * gq + 3]);
-                    if constexpr (BF16X3) mfma_chain_bf16x3(Wc1tb, lane, g_zc[0], gm[0]);   // g_m += Wc1^T g_zc
+                    if constexpr (IMG) mfma_chain_img<true>(Wc1i, lane, g_zc[0], gm[0]);   // g_m += Wc1^T g_zc
+                    else if constexpr (BF16X3) mfma_chain_bf16x3(Wc1tb, lane, g_zc[0], gm[0]);
                     else mfma_chain_nat<HB, true>(Wc1n, lane, g_zc, gm, flags & kAblNoMfma);
                 }
                 if (hh == 0) { glb[j] = g_l; rowbuf[j] = i; }
@@ -344,21 +374,33 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 // ---- g_a1 = W2^T g_z2 ; g_z1 = g_a1 * SiLU'(z1) ----
                 // SiLU'(z1): this tile's rows are re-gathered (L2-hot) under the W2^T product
                 // instead of holding z1 in 16 registers across the whole tile
-                gather_tile<HB>(io.PQ, io.x, I, hh, G);
+                if constexpr (!IMG) gather_tile<HB>(io.PQ, io.x, I, hh, G);
                 f32x16 ga1[HB];
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ga1[b][r] = 0.f;
-                if constexpr (BF16X3) mfma_chain_bf16x3(W2tb, lane, g_z2[0], ga1[0]);
+                if constexpr (IMG) mfma_chain_img<true>(W2i, lane, g_z2[0], ga1[0]);
+                else if constexpr (BF16X3) mfma_chain_bf16x3(W2tb, lane, g_z2[0], ga1[0]);
                 else mfma_chain_nat<HB, true>(W2n, lane, g_z2, ga1, flags & kAblNoMfma);
                 float g_z1[HB][16];
-                assemble_z1<HB>(G, attrt, wrhot, ty, hh, rho, g_z1);
+                if constexpr (IMG) {
 #pragma unroll
-                for (int b = 0; b < HB; ++b)
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const float4 dd = *reinterpret_cast<const float4*>(d1b + (gq * 64 + lane) * 4);
+                        g_z1[0][4 * gq] = ga1[0][4 * gq] * dd.x;
+                        g_z1[0][4 * gq + 1] = ga1[0][4 * gq + 1] * dd.y;
+                        g_z1[0][4 * gq + 2] = ga1[0][4 * gq + 2] * dd.z;
+                        g_z1[0][4 * gq + 3] = ga1[0][4 * gq + 3] * dd.w;
+                    }
+                } else {
+                    assemble_z1<HB>(G, attrt, wrhot, ty, hh, rho, g_z1);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        g_z1[b][r] = ga1[b][r] * pvs_silu_grad(g_z1[b][r], pvs_sigmoid(g_z1[b][r]));
+                    for (int b = 0; b < HB; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            g_z1[b][r] = ga1[b][r] * pvs_silu_grad(g_z1[b][r], pvs_sigmoid(g_z1[b][r]));
+                }
 #if PVS_PREFETCH
                 gather_tile<HB>(io.PQ, io.x, In, hh, G);   // next tile, lands during the reductions
 #endif
@@ -504,65 +546,6 @@ __device__ __forceinline__ void xwrite_block(float* __restrict__ T, int j, int h
     for (int g = 0; g < 4; ++g)
         *reinterpret_cast<float4*>(T + j * TS + 32 * cb + 8 * g + 4 * hh) =
             make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-}
-
-// ---- bf16x3 weights as ONE swizzled row-major image per part, read row-wise for W v and, through
-// ds_read_b64_tr_b16 (gfx950's transposing LDS read), column-wise for W^T v: half the LDS of two
-// pre-transposed copies. Element (r, c) of W [H][H] sits at 16-bit index
-//   r*H + 4*((c >> 2) ^ swz(r)) + (c & 3),   swz(r) = (r >> 1) & (H/4 - 1):
-// the 8-byte chunks of a row are permuted so that 32 lanes reading the same logical chunk of 32
-// consecutive rows hit 32 different bank pairs (row reads conflict-free, transposed reads 2-way).
-typedef short pvs_v4s __attribute__((ext_vector_type(4)));
-
-template <int HB>
-__device__ __forceinline__ int img_off(int r, int c) {
-    constexpr int H = 32 * HB, NCH = H / 4;
-    return r * H + 4 * ((c >> 2) ^ ((r >> 1) & (NCH - 1))) + (c & 3);
-}
-
-template <int HB>
-__device__ __forceinline__ void stage_weights_img(unsigned short* img, const float* __restrict__ W) {
-    constexpr int H = 32 * HB;
-    unsigned* hi = reinterpret_cast<unsigned*>(img);
-    unsigned* mid = reinterpret_cast<unsigned*>(img + H * H);
-    unsigned* lo = reinterpret_cast<unsigned*>(img + 2 * H * H);
-    for (int i = threadIdx.x; i < H * H / 2; i += blockDim.x) {
-        const int r = (2 * i) / H, c = (2 * i) % H;
-        const float x0 = W[r * H + c], x1 = W[r * H + c + 1];
-        const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
-        const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
-        const float t0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
-        const float t1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-        const int o = img_off<HB>(r, c) >> 1;
-        hi[o] = pvs_pack_hi16(x0, x1);
-        mid[o] = pvs_pack_hi16(r0, r1);
-        lo[o] = pvs_pack_hi16(t0, t1);
-    }
-}
-
-// A-operand fragment (8 bf16 in the k order of the X layout) of block (bo, bi), k-step s, of one part
-// image: TRANSPOSE = false: rows of W (W v); true: columns of W (W^T v) through the transposing read.
-template <int HB, bool TRANSPOSE>
-__device__ __forceinline__ bf16x8 img_fragment(const unsigned short* __restrict__ part, int lane, int bo,
-                                               int bi, int s) {
-    const int hh = lane >> 5;
-    uint2 a, b;
-    if constexpr (!TRANSPOSE) {
-        const int r = 32 * bo + (lane & 31), c0 = 32 * bi + 16 * s + 4 * hh;
-        a = *reinterpret_cast<const uint2*>(part + img_off<HB>(r, c0));
-        b = *reinterpret_cast<const uint2*>(part + img_off<HB>(r, c0 + 8));
-    } else {
-        // 16-lane group: lane 4q+p supplies row q, columns 4p..4p+3 of a 4x16 block and receives
-        // column (lane & 15) of its 4 rows
-        const int li = lane & 15, q = li >> 2, p = li & 3;
-        const int r0 = 32 * bi + 16 * s + 4 * hh, col = 32 * bo + 16 * ((lane >> 4) & 1) + 4 * p;
-        typedef pvs_v4s __attribute__((address_space(3))) * lds_v4s;
-        const pvs_v4s ta = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(part + img_off<HB>(r0 + q, col)));
-        const pvs_v4s tb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(part + img_off<HB>(r0 + 8 + q, col)));
-        a = __builtin_bit_cast(uint2, ta);
-        b = __builtin_bit_cast(uint2, tb);
-    }
-    return __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
 }
 
 // acc (output block cb) += sum over input blocks bi of W(cb,bi) v_bi as six bf16 MFMA terms per
@@ -1100,7 +1083,9 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     *n_slabs = blocks;
     PvsProfScope prof(s, PVS_PROF_EDGE_BWD);
     const PvsSlabLayout L = pvs_slab_layout(H);
-    size_t words = (bf16x3 ? (size_t)4 * 6 * 64 * 4 : (size_t)2 * H * (H + 1)) +
+    const bool img = bf16x3 && PVS_BWD_IMG;   // (see the kernel)
+    size_t words = (img ? (size_t)3 * H * H + (size_t)nw * 16 * 64
+                        : bf16x3 ? (size_t)4 * 6 * 64 * 4 : (size_t)2 * H * (H + 1)) +
                    (5 + PVS_MAX_EDGE_ATTR) * H +
                    (size_t)nw * (3 * kTile * (H + 4) + kTile * 4 + 2 * kTile);
     if (words < (size_t)L.total) words = L.total;

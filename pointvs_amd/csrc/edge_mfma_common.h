@@ -343,6 +343,85 @@ __device__ __forceinline__ void mfma_chain_bf16x3(const unsigned* __restrict__ W
 }
 
 
+// ---- bf16x3 weights as ONE swizzled row-major image per part, read row-wise for W v and, through
+// ds_read_b64_tr_b16 (gfx950's transposing LDS read), column-wise for W^T v: half the LDS of two
+// pre-transposed copies. Element (r, c) of W [H][H] sits at 16-bit index
+//   r*H + 4*((c >> 2) ^ swz(r)) + (c & 3),   swz(r) = (r / (128/H)) & (H/4 - 1)   (128/H rows span the 64 banks):
+// the 8-byte chunks of a row are permuted so that 32 lanes reading the same logical chunk of 32
+// consecutive rows hit 32 different bank pairs (row reads conflict-free, transposed reads 2-way).
+typedef short pvs_v4s __attribute__((ext_vector_type(4)));
+
+template <int HB>
+__device__ __forceinline__ int img_off(int r, int c) {
+    constexpr int H = 32 * HB, NCH = H / 4, RPC = 128 / H;
+    return r * H + 4 * ((c >> 2) ^ ((r / RPC) & (NCH - 1))) + (c & 3);
+}
+
+template <int HB>
+__device__ __forceinline__ void stage_weights_img(unsigned short* img, const float* __restrict__ W) {
+    constexpr int H = 32 * HB;
+    unsigned* hi = reinterpret_cast<unsigned*>(img);
+    unsigned* mid = reinterpret_cast<unsigned*>(img + H * H);
+    unsigned* lo = reinterpret_cast<unsigned*>(img + 2 * H * H);
+    for (int i = threadIdx.x; i < H * H / 2; i += blockDim.x) {
+        const int r = (2 * i) / H, c = (2 * i) % H;
+        const float x0 = W[r * H + c], x1 = W[r * H + c + 1];
+        const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
+        const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+        const float t0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+        const float t1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+        const int o = img_off<HB>(r, c) >> 1;
+        hi[o] = pvs_pack_hi16(x0, x1);
+        mid[o] = pvs_pack_hi16(r0, r1);
+        lo[o] = pvs_pack_hi16(t0, t1);
+    }
+}
+
+// A-operand fragment (8 bf16 in the k order of the X layout) of block (bo, bi), k-step s, of one part
+// image: TRANSPOSE = false: rows of W (W v); true: columns of W (W^T v) through the transposing read.
+template <int HB, bool TRANSPOSE>
+__device__ __forceinline__ bf16x8 img_fragment(const unsigned short* __restrict__ part, int lane, int bo,
+                                               int bi, int s) {
+    const int hh = lane >> 5;
+    uint2 a, b;
+    if constexpr (!TRANSPOSE) {
+        const int r = 32 * bo + (lane & 31), c0 = 32 * bi + 16 * s + 4 * hh;
+        a = *reinterpret_cast<const uint2*>(part + img_off<HB>(r, c0));
+        b = *reinterpret_cast<const uint2*>(part + img_off<HB>(r, c0 + 8));
+    } else {
+        // 16-lane group: lane 4q+p supplies row q, columns 4p..4p+3 of a 4x16 block and receives
+        // column (lane & 15) of its 4 rows
+        const int li = lane & 15, q = li >> 2, p = li & 3;
+        const int r0 = 32 * bi + 16 * s + 4 * hh, col = 32 * bo + 16 * ((lane >> 4) & 1) + 4 * p;
+        typedef pvs_v4s __attribute__((address_space(3))) * lds_v4s;
+        const pvs_v4s ta = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(part + img_off<HB>(r0 + q, col)));
+        const pvs_v4s tb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(part + img_off<HB>(r0 + 8 + q, col)));
+        a = __builtin_bit_cast(uint2, ta);
+        b = __builtin_bit_cast(uint2, tb);
+    }
+    return __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
+}
+
+// acc += W v (TRANSPOSE: W^T v) for H = 32 with the weights as one image per part
+template <bool TRANSPOSE>
+__device__ __forceinline__ void mfma_chain_img(const unsigned short* __restrict__ img, int lane,
+                                               const float (&v)[16], f32x16& acc) {
+    Bf16Parts b;
+    split_bf16x3(v, b);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const bf16x8 ah = img_fragment<1, TRANSPOSE>(img, lane, 0, 0, s);
+        const bf16x8 am = img_fragment<1, TRANSPOSE>(img + 32 * 32, lane, 0, 0, s);
+        const bf16x8 al = img_fragment<1, TRANSPOSE>(img + 2 * 32 * 32, lane, 0, 0, s);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.hi[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.lo[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.mid[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.hi[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.mid[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.hi[s], acc, 0, 0, 0);
+    }
+}
+
 // H = 32*HB: all HB x HB blocks of W (row-major [H][H]) staged block after block ((bo*HB + bi) * 6 KB),
 // and the product acc[bo] += sum_bi W[bo][bi] v[bi] with each input block split once.
 template <int HB>
