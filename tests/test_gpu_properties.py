@@ -405,3 +405,45 @@ def test_train_and_val_entry_points(tmp_path):
     lines = model.val(loader, predictions_file=tmp_path / 'pred.txt')
     assert len(lines) == 6 and (tmp_path / 'pred.txt').read_text().count('\n') == 6
     assert (tmp_path / 'm' / 'checkpoints' / 'pose_ckpt_epoch_2.pt').exists()
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_kernel_families_agree_on_random_configurations(seed):
+    """Fuzz: random layer flags, hidden size, graph shape (isolated nodes, E not a multiple of the
+    tile, several graphs) - the MFMA kernels (bf16x3 and fp32 products) and the generic kernels give
+    the same outputs and gradients."""
+    rng = np.random.default_rng(1000 + seed)
+    flags = dict(
+        k=int(rng.choice([32, 64])), num_layers=int(rng.integers(1, 4)),
+        residual=bool(rng.integers(2)), edge_residual=bool(rng.integers(2)),
+        edge_attention=bool(rng.integers(2)), node_attention=bool(rng.integers(2)),
+        normalize=bool(rng.integers(2)), tanh=bool(rng.integers(2)), graphnorm=bool(rng.integers(2)),
+        update_coords=bool(rng.integers(4) > 0), permutation_invariance=bool(rng.integers(4) == 0),
+        attention_activation_fn=str(rng.choice(['sigmoid', 'tanh', 'relu', 'silu'])))
+    variant = int(rng.integers(3))
+    if variant == 1:
+        flags['gated_residual'] = True
+    elif variant == 2:
+        flags['rezero'] = True
+    model, _ = make_model(seed=seed, **flags)
+    n = int(rng.integers(40, 2500))
+    e = int(rng.integers(1, 40)) * n + int(rng.integers(0, 31))
+    g = random_graph(n, e, seed=seed, n_graphs=int(rng.integers(1, 5)))
+    runs = {}
+    for name, env in (('mfma', {}), ('fp32', {'PVS_EGNN_BF16X3': '0'}), ('generic', {'PVS_EGNN_KERNELS': 'generic'})):
+        for k_ in ('PVS_EGNN_BF16X3', 'PVS_EGNN_KERNELS'):
+            os.environ.pop(k_, None)
+        os.environ.update(env)
+        try:
+            runs[name] = gpu_run(model, g)
+        finally:
+            for k_ in env:
+                os.environ.pop(k_, None)
+    y_ref, g_ref = runs['generic']
+    for name in ('mfma', 'fp32'):
+        y, grads = runs[name]
+        assert rel_err(y, y_ref) < TOL, (name, flags)
+        for pname in g_ref:
+            assert (g_ref[pname] is None) == (grads[pname] is None), (name, pname)
+            if g_ref[pname] is not None:
+                assert rel_err(grads[pname], g_ref[pname]) < 3 * TOL, (name, pname, flags)

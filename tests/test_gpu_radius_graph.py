@@ -153,3 +153,25 @@ def test_receptor_screen_matches_the_plain_forward(flags):
             slow = model(plain.load(poses[4 * k:4 * k + 4])).reshape(-1)
         err = float((fast - slow).abs().max() / slow.abs().max().clamp_min(1e-30))
         assert err < 1e-5, err
+
+
+def test_radius_graph_with_bond_radius_equals_prepare_graph_of_oracle_edges():
+    """estimate_bonds shape (intra 2 A, inter 6 A, data_loaders.py:359-360) on a ragged batch: the
+    built graph == pvs_graph_prepare of the oracle's per-graph edge lists, array for array."""
+    from oracle.generate_edges_oracle import generate_edges as oracle_edges
+    from pointvs_amd.graph import Batch, Data, prepare_graph
+    from pointvs_amd.radius_graph import radius_graph
+    from pointvs_amd.synthetic import synthetic_graph
+    items = []
+    for k, n in enumerate((150, 333, 64, 257)):
+        g = synthetic_graph(900 + k, n_nodes=n, n_lig=9, edge_radius=1.0, density=0.08)
+        _, (rows, cols), attrs = oracle_edges(g.pos.numpy(), g.x[:, -1].numpy(), 6.0, 2.0, prune=False)
+        items.append(Data(x=g.x, pos=g.pos, edge_index=torch.from_numpy(np.vstack([rows, cols])).long(),
+                          edge_attr=torch.nn.functional.one_hot(torch.from_numpy(attrs).long(), 3),
+                          y=torch.tensor(0), lig_fname='l', rec_fname='r'))
+    b = Batch.from_data_list(items).to('cuda')
+    ref = prepare_graph(b.edge_index, b.edge_attr, b.x.shape[0])
+    pg = radius_graph(b.pos, b.x[:, -1], b.ptr, inter_radius=6.0, intra_radius=2.0)
+    assert pg.n_edges == ref.n_edges
+    for k in ('rowptr', 'row', 'col', 'etype', 'colptr', 'cedge', 'inv_deg'):
+        assert torch.equal(pg.t[k][:len(ref.t[k])], ref.t[k]), k
