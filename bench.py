@@ -225,6 +225,8 @@ def main():
     if use_graph:   # same Adam, step counter kept on the device so the step can be captured
         model.optimiser = torch.optim.Adam(params, lr=2e-3, weight_decay=1e-4, capturable=True)
     # exchange of the late layers' gradients starts from backward hooks, the rest after the backward
+    elif os.environ.get('PVS_BENCH_TORCH_ADAM'):   # A/B: torch's multi-tensor Adam + clip_grad_value_
+        model.optimiser = torch.optim.Adam(params, lr=2e-3, weight_decay=1e-4)
     reducer = OverlappedGradAllReducer(params) if world > 1 else None
 
     # measured on MI355X: no gain (8.9 ms with and without; the sorts contend with the edge
@@ -253,8 +255,11 @@ def main():
         loss.backward()
         if reducer is not None:
             reducer()
-        torch.nn.utils.clip_grad_value_(params, 1.0)
-        model.optimiser.step()
+        if hasattr(model.optimiser, '_fusable'):      # pointvs_amd.optim.FusedClipAdam: clip + Adam in one launch
+            model.optimiser.step(clip_value=1.0)
+        else:
+            torch.nn.utils.clip_grad_value_(params, 1.0)
+            model.optimiser.step()
         return loss
 
     # Graph mode keeps every step (warm-up, capture, replays, the profiled eager steps) on ONE

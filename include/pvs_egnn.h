@@ -267,6 +267,25 @@ int pvs_mean_pool_bwd(const float* g_pooled, const int32_t* graph_ptr, float* g_
                       int32_t n_graphs, int32_t n_nodes, int32_t width, pvs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * clip_grad_value_(params, clip) + torch.optim.Adam.step() (point_neural_network_base.py:421-422)
+ * for all parameters in ONE launch. table: DEVICE array of n entries; the
+ * gradients are clamped in place to [-clip, clip] (clip <= 0: no clamp), then
+ *   g += weight_decay * p;  m += (1 - beta1) (g - m);  v = beta2 v + (1 - beta2) g^2;
+ *   p -= (lr / bias_correction1) * m / (sqrt(v) / sqrt(bias_correction2) + eps)
+ * (torch's non-amsgrad, non-maximize Adam, same operation order). bias_correction = 1 - beta^step
+ * is passed by the host, which owns the step counter. */
+typedef struct PvsAdamEntry {
+    float* param;
+    float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+} PvsAdamEntry;
+int pvs_adam_clip_step(const PvsAdamEntry* table, int32_t n_tensors, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, float bias_correction1, float bias_correction2,
+                       float clip, pvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * unsorted_segment_sum / unsorted_segment_mean (egnn_satorras.py:332-337 / :340-347) as standalone
  * operators (inside the layers these sums are fused into the edge kernels).
  *   data [E,C] fp32, ids [E] int64 in [0,N) -> out [N,C]; mean != 0 divides by max(count, 1).

@@ -305,3 +305,43 @@ int pvs_sum_vec(hipStream_t s, const float* v, int n, float* out) {
     PVS_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ---- clip + Adam for every parameter tensor in one launch (include/pvs_egnn.h) ----
+namespace {
+__global__ void __launch_bounds__(256)
+k_adam_clip(const PvsAdamEntry* __restrict__ table, float lr, float beta1, float beta2, float eps, float wd,
+            float bc1, float bc2, float clip) {
+    const PvsAdamEntry e = table[blockIdx.y];
+    const float step_size = lr / bc1;
+    const float bc2_sqrt = sqrtf(bc2);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < e.numel;
+         i += (long long)gridDim.x * blockDim.x) {
+        float g = e.grad[i];
+        if (clip > 0.f) {
+            g = fminf(fmaxf(g, -clip), clip);
+            e.grad[i] = g;                       // clip_grad_value_ is in place
+        }
+        const float p = e.param[i];
+        if (wd != 0.f) g = __fadd_rn(g, __fmul_rn(wd, p));                        // grad.add(param, alpha=wd)
+        float m = e.exp_avg[i];
+        m = __fadd_rn(m, __fmul_rn(1.f - beta1, __fsub_rn(g, m)));               // lerp_(grad, 1 - beta1)
+        float v = __fmul_rn(e.exp_avg_sq[i], beta2);
+        v = __fadd_rn(v, __fmul_rn(__fmul_rn(1.f - beta2, g), g));               // addcmul_(g, g, value = 1 - beta2)
+        const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), bc2_sqrt), eps);
+        e.exp_avg[i] = m;
+        e.exp_avg_sq[i] = v;
+        e.param[i] = __fadd_rn(p, __fmul_rn(-step_size, __fdiv_rn(m, denom)));   // addcdiv_(m, denom, value=-step_size)
+    }
+}
+}  // namespace
+
+extern "C" int pvs_adam_clip_step(const PvsAdamEntry* table, int32_t n, float lr, float beta1, float beta2,
+                                  float eps, float wd, float bc1, float bc2, float clip, pvs_stream_t stream) {
+    PVS_REQUIRE(table && n >= 0, "pvs_adam_clip_step: bad arguments");
+    PVS_REQUIRE(bc1 > 0.f && bc2 > 0.f, "pvs_adam_clip_step: bias corrections must be positive (step >= 1)");
+    if (n == 0) return 0;
+    k_adam_clip<<<dim3(8, n), 256, 0, (hipStream_t)stream>>>(table, lr, beta1, beta2, eps, wd, bc1, bc2, clip);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}

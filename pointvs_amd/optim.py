@@ -1,0 +1,81 @@
+"""`torch.optim.Adam` whose step (and the `clip_grad_value_` the reference runs just before it,
+/root/reference/point_vs/models/point_neural_network_base.py:421-422) is ONE kernel launch for all
+parameters (`pvs_adam_clip_step`) instead of torch's dozen multi-tensor
+launches. Same update rule, same `state_dict` layout (`step`, `exp_avg`, `exp_avg_sq`), so
+checkpoints stay interchangeable with the reference's Adam."""
+import torch
+
+from . import _lib
+
+
+class FusedClipAdam(torch.optim.Adam):
+    """Drop-in `torch.optim.Adam`; `step(clip_value=c)` first clamps every gradient to [-c, c] in
+    place. Falls back to torch's own implementation whenever a feature the kernel does not cover is
+    on (amsgrad, maximize, capturable, differentiable, non-CUDA / non-fp32 parameters)."""
+
+    def __init__(self, params, **kwargs):
+        super().__init__(params, **kwargs)
+        # pointer tables travel through a small ring of pinned buffers: a slot is only rewritten once
+        # the copy that read it has run (the host may be several steps ahead of the device)
+        self._ring, self._slot = [], 0
+
+    def _fusable(self):
+        for group in self.param_groups:
+            if group.get('amsgrad') or group.get('maximize') or group.get('capturable') \
+                    or group.get('differentiable') or isinstance(group['lr'], torch.Tensor):
+                return False
+            for p in group['params']:
+                if p.grad is not None and (not p.is_cuda or p.dtype != torch.float32 or p.grad.is_sparse
+                                           or not p.is_contiguous() or not p.grad.is_contiguous()):
+                    return False
+        return True
+
+    @torch.no_grad()
+    def step(self, closure=None, clip_value=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if not self._fusable():
+            if clip_value is not None:
+                torch.nn.utils.clip_grad_value_([p for g in self.param_groups for p in g['params']], clip_value)
+            super().step()
+            return loss
+        lib = _lib.lib()
+        for group in self.param_groups:
+            beta1, beta2 = group['betas']
+            by_step = {}
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                state = self.state[p]
+                if len(state) == 0:      # torch.optim.Adam._init_group, non-capturable flavour
+                    state['step'] = torch.tensor(0.0, dtype=torch.float32)
+                    state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state['step'] += 1
+                by_step.setdefault(float(state['step']), []).append((p, state))
+            for step, items in by_step.items():
+                n = len(items)
+                dev = items[0][0].device
+                if not self._ring or self._ring[0][0].shape[0] < n:
+                    cap = max(n, 64)
+                    self._ring = [[torch.empty((cap, 5), dtype=torch.int64).pin_memory(),
+                                   torch.empty((cap, 5), dtype=torch.int64, device=dev), None] for _ in range(8)]
+                slot = self._ring[self._slot]
+                self._slot = (self._slot + 1) % len(self._ring)
+                if slot[2] is not None:
+                    slot[2].synchronize()
+                table_host, table_dev = slot[0], slot[1]
+                rows = [[p.data_ptr(), p.grad.data_ptr(), s['exp_avg'].data_ptr(), s['exp_avg_sq'].data_ptr(),
+                         p.numel()] for p, s in items]
+                table_host[:n] = torch.tensor(rows, dtype=torch.int64)
+                table_dev[:n].copy_(table_host[:n], non_blocking=True)
+                slot[2] = torch.cuda.Event()
+                slot[2].record(torch.cuda.current_stream(dev))
+                _lib.check(lib.pvs_adam_clip_step(
+                    _lib.ptr(table_dev), n, float(group['lr']), float(beta1), float(beta2),
+                    float(group['eps']), float(group['weight_decay']), 1.0 - beta1 ** step, 1.0 - beta2 ** step,
+                    float(clip_value) if clip_value is not None else 0.0,
+                    torch.cuda.current_stream(dev).cuda_stream), 'pvs_adam_clip_step')
+        return loss

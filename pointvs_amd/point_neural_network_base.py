@@ -20,6 +20,7 @@ import yaml
 from torch import nn
 
 from .global_objects import DEVICE
+from .optim import FusedClipAdam
 
 
 class PointNeuralNetworkBase(nn.Module):
@@ -48,8 +49,8 @@ class PointNeuralNetworkBase(nn.Module):
         self.n_layers = model_kwargs.get('num_layers', 12)
         self.layers = self.build_net(**model_kwargs)
         if optimiser == 'adam':
-            self.optimiser = torch.optim.Adam(self.parameters(), lr=self.lr,
-                                              weight_decay=weight_decay or 0)
+            # torch.optim.Adam subclass: same rule and state_dict, one launch for clip + step on the GPU
+            self.optimiser = FusedClipAdam(self.parameters(), lr=self.lr, weight_decay=weight_decay or 0)
         elif optimiser == 'sgd':
             self.optimiser = torch.optim.SGD(self.parameters(), lr=self.lr, momentum=0.9,
                                              weight_decay=weight_decay or 0, nesterov=True)
@@ -94,8 +95,11 @@ class PointNeuralNetworkBase(nn.Module):
         loss.backward()
         if self.grad_sync is not None:
             self.grad_sync()
-        torch.nn.utils.clip_grad_value_(self.parameters(), 1.0)
-        self.optimiser.step()
+        if isinstance(self.optimiser, FusedClipAdam):
+            self.optimiser.step(clip_value=1.0)
+        else:
+            torch.nn.utils.clip_grad_value_(self.parameters(), 1.0)
+            self.optimiser.step()
         if not sync:
             return loss.detach()
         loss_ = float(loss.detach().cpu())

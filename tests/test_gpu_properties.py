@@ -447,3 +447,35 @@ def test_kernel_families_agree_on_random_configurations(seed):
             assert (g_ref[pname] is None) == (grads[pname] is None), (name, pname)
             if g_ref[pname] is not None:
                 assert rel_err(grads[pname], g_ref[pname]) < 3 * TOL, (name, pname, flags)
+
+
+def test_fused_clip_adam_matches_torch_adam():
+    """pvs_adam_clip_step (one launch) vs clip_grad_value_ + torch.optim.Adam over several steps,
+    including a parameter that never receives a gradient and one that starts late."""
+    from pointvs_amd.optim import FusedClipAdam
+    torch.manual_seed(0)
+    shapes = [(32, 68), (32,), (1, 32), (64, 64), (3,)]
+    a = [torch.nn.Parameter(torch.randn(s, device='cuda')) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa = FusedClipAdam(a, lr=2e-3, weight_decay=1e-4)
+    ob = torch.optim.Adam(b, lr=2e-3, weight_decay=1e-4)
+    for step in range(5):
+        for k, (pa, pb) in enumerate(zip(a, b)):
+            if k == 4 or (k == 2 and step < 2):      # never / late
+                pa.grad = pb.grad = None
+                continue
+            g = torch.randn(pa.shape, generator=torch.Generator().manual_seed(10 * step + k)).cuda() * 2
+            pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step(clip_value=1.0)
+        torch.nn.utils.clip_grad_value_(b, 1.0)
+        ob.step()
+    for pa, pb in zip(a, b):
+        assert rel_err(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()) < 1e-6
+    for pa, pb in zip(a, b):
+        if pa.grad is not None:
+            assert torch.equal(pa.grad, pb.grad)     # clipped in place, like clip_grad_value_
+    sa, sb = oa.state_dict()['state'], ob.state_dict()['state']
+    assert set(sa) == set(sb)
+    for k in sa:
+        assert float(sa[k]['step']) == float(sb[k]['step'])
+        assert rel_err(sa[k]['exp_avg_sq'].cpu().numpy(), sb[k]['exp_avg_sq'].cpu().numpy()) < 1e-6

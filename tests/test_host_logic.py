@@ -201,3 +201,23 @@ def test_overlapped_allreduce_matches_flat_gloo_world2():
                     assert torch.allclose(ga, gb, atol=1e-6)
     for ga, gb in zip(out[0]['overlap'][-1], out[1]['overlap'][-1]):
         assert ga is None or torch.equal(ga, gb)
+
+
+def test_fused_clip_adam_falls_back_to_torch_on_cpu_tensors():
+    """No GPU here: FusedClipAdam must behave exactly like clip_grad_value_ + torch.optim.Adam."""
+    from pointvs_amd.optim import FusedClipAdam
+    torch.manual_seed(0)
+    a = [torch.nn.Parameter(torch.randn(7, 3)), torch.nn.Parameter(torch.randn(5))]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa = FusedClipAdam(a, lr=2e-3, weight_decay=1e-4)
+    ob = torch.optim.Adam(b, lr=2e-3, weight_decay=1e-4)
+    for step in range(3):
+        for pa, pb in zip(a, b):
+            g = torch.randn(pa.shape, generator=torch.Generator().manual_seed(step)) * 3
+            pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step(clip_value=1.0)
+        torch.nn.utils.clip_grad_value_(b, 1.0)
+        ob.step()
+    for pa, pb in zip(a, b):
+        assert torch.equal(pa, pb)
+    assert set(oa.state_dict()['state'][0]) == set(ob.state_dict()['state'][0])
