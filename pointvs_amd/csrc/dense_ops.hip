@@ -129,7 +129,7 @@ k_colreduce(int mode, float* __restrict__ slabs, const float* __restrict__ A, in
 // added in lane order: a fixed summation tree, so the result is reproducible.
 __global__ void __launch_bounds__(kThreads)
 k_reduce_slabs(float* __restrict__ out, int ldo, int inner, const float* __restrict__ slabs,
-               int n_slabs, int width, float scale, int accumulate) {
+               int n_slabs, int width, float scale, int accumulate, int inner_valid = 1 << 30) {
     __shared__ float part[8][33];
     const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int o = blockIdx.x * 32 + ol;
@@ -138,7 +138,7 @@ k_reduce_slabs(float* __restrict__ out, int ldo, int inner, const float* __restr
         for (int gidx = sl; gidx < n_slabs; gidx += 8) s += slabs[(size_t)gidx * width + o];
     part[sl][ol] = s;
     __syncthreads();
-    if (sl == 0 && o < width) {
+    if (sl == 0 && o < width && (o % inner) < inner_valid) {
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += part[k][ol];
@@ -273,7 +273,8 @@ typedef f32x16 f32x16_t;
 template <int CB, int KB>
 __global__ void __launch_bounds__(kThreads)
 k_tsgemm_mfma(float* __restrict__ slabs, const float* __restrict__ A, int lda,
-              const float* __restrict__ B, int ldb, int N, int rows_per_block) {
+              const float* __restrict__ B, int ldb, int N, int rows_per_block, int kvalid) {
+    // kvalid: number of real columns of B (< 32*KB: the rest of the block is zero; slab stays padded)
     __shared__ float red[CB * KB * 1024];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 31, hh = lane >> 5;
@@ -296,7 +297,7 @@ k_tsgemm_mfma(float* __restrict__ slabs, const float* __restrict__ A, int lda,
 #pragma unroll
             for (int a = 0; a < CB; ++a) av[u][a] = ok ? A[(size_t)n * lda + 32 * a + j] : 0.f;
 #pragma unroll
-            for (int b = 0; b < KB; ++b) bv[u][b] = ok ? B[(size_t)n * ldb + 32 * b + j] : 0.f;
+            for (int b = 0; b < KB; ++b) bv[u][b] = (ok && 32 * b + j < kvalid) ? B[(size_t)n * ldb + 32 * b + j] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u)
@@ -512,12 +513,23 @@ int pvs_launch_tsgemm_tn(hipStream_t s, float* out, int ldo, const float* A, int
     const int rpb = rows_per_block_for(N, blocks);
     if (C % 32 == 0 && K % 32 == 0 && C <= 64 && K <= 64) {
         const int cb = C / 32, kb = K / 32;
-        if (cb == 1 && kb == 1) k_tsgemm_mfma<1, 1><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb);
-        else if (cb == 1 && kb == 2) k_tsgemm_mfma<1, 2><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb);
-        else if (cb == 2 && kb == 1) k_tsgemm_mfma<2, 1><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb);
-        else k_tsgemm_mfma<2, 2><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb);
+        if (cb == 1 && kb == 1) k_tsgemm_mfma<1, 1><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb, K);
+        else if (cb == 1 && kb == 2) k_tsgemm_mfma<1, 2><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb, K);
+        else if (cb == 2 && kb == 1) k_tsgemm_mfma<2, 1><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb, K);
+        else k_tsgemm_mfma<2, 2><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb, K);
         PVS_CHECK_LAUNCH();
         return pvs_launch_reduce_slabs(s, out, ldo, K, slabs, blocks, CK, accumulate);
+    }
+    if (C % 32 == 0 && C <= 64 && K < 32 && N >= 1024) {
+        // narrow right operand (the input embedding: K = 12 atom features): zero-padded to one
+        // 32-column MFMA block; the slabs keep the padded [C][32] layout, the reduction skips the pad
+        if (C == 32) k_tsgemm_mfma<1, 1><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb, K);
+        else k_tsgemm_mfma<2, 1><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb, K);
+        PVS_CHECK_LAUNCH();
+        k_reduce_slabs<<<(C * 32 + 31) / 32, kThreads, 0, s>>>(out, ldo, 32, slabs, blocks, C * 32, 1.0f,
+                                                              accumulate ? 1 : 0, K);
+        PVS_CHECK_LAUNCH();
+        return 0;
     }
     size_t lds = (size_t)16 * (C + K) * sizeof(float);
     if (CK <= 8 * kThreads)
@@ -578,7 +590,8 @@ extern "C" int pvs_linear_fwd(const float* x, const float* w, const float* b, fl
 }
 
 extern "C" size_t pvs_linear_bwd_workspace_bytes(int32_t N, int32_t K, int32_t C) {
-    return (size_t)pvs_reduce_blocks(N) * (size_t)C * (size_t)(K > 1 ? K : 1) * sizeof(float) + 256;
+    const size_t kpad = K < 32 ? 32 : K;     // narrow K runs zero-padded to one MFMA block
+    return (size_t)pvs_reduce_blocks(N) * (size_t)C * kpad * sizeof(float) + 256;
 }
 
 extern "C" int pvs_linear_bwd(const float* x, const float* w, const float* g_y, float* g_x,
