@@ -327,7 +327,7 @@ def main():
         achieved = dom_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
         step_bytes = layers * algorithmic_bytes_per_layer(n_nodes, n_edges, h)
         step_flops = algorithmic_flops_per_step(
-            n_nodes, n_edges, h, 3, layers, cfg['model']['edge_attention'],
+            n_nodes, n_edges, h, 1 if args.infer else 3, layers, cfg['model']['edge_attention'],
             cfg['model']['node_attention'])
         traffic = None
         tfile = ROOT / 'profiles' / f'r01_{args.config}_traffic.json'
