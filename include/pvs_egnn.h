@@ -233,6 +233,22 @@ int pvs_graph_filter_ligand_edges(const PvsGraph* full, const uint8_t* bp, int32
                                   int32_t* rowptr_out, int32_t* row_out, int32_t* col_out, uint8_t* etype_out,
                                   int32_t* status, void* workspace, size_t workspace_bytes, pvs_stream_t stream);
 
+/* The radius graphs of B rigid poses of one ligand against one receptor without re-testing the
+ * receptor-receptor pairs (they are pose independent: rr_rowptr [n_rec+1] / rr_col, receptor-local
+ * ids, from pvs_radius_graph_* on the receptor alone). Node layout per pose: n_lig (<= 64) ligand
+ * atoms first, then the n_rec receptor atoms; lig_pos [B,n_lig,3], rec_pos [n_rec,3]. Same edges,
+ * classes and in-row order as generate_edges per pose. Outputs: the full CSR (rowptr [N+1], row,
+ * col, etype with room for `capacity` edges, inv_deg [N]) and the CSR of its ligand-touching edges
+ * (`_lig`), both with the edge count only on the device (rowptr[N]; pass it as PvsGraph.n_edges_dev:
+ * forward-only use). *status bit 2 = a capacity was too small (nothing is written then). */
+size_t pvs_screen_graph_state_bytes(int32_t n_poses, int32_t n_lig, int32_t n_rec);
+int pvs_screen_graph_build(const float* lig_pos, const float* rec_pos, const int32_t* rr_rowptr,
+                           const int32_t* rr_col, int32_t n_poses, int32_t n_lig, int32_t n_rec,
+                           double inter_radius, double intra_radius, int32_t capacity, int32_t capacity_lig,
+                           int32_t* rowptr, int32_t* row, int32_t* col, uint8_t* etype, float* inv_deg,
+                           int32_t* rowptr_lig, int32_t* row_lig, int32_t* col_lig, uint8_t* etype_lig,
+                           int32_t* status, void* state, size_t state_bytes, pvs_stream_t stream);
+
 /* Backward of the above (what autograd replays for the reference, SURVEY.md §8a "Backward spec").
  *   g_h_out [N,H]; g_x_out [N,3] or NULL (=0: the last layer's x is unused);
  *   g_m_out [E,H] sorted or NULL (=0); att [E] sorted as written by the forward.

@@ -65,6 +65,10 @@ _PROTOTYPES = {
     'pvs_egnn_layer_fwd': (C.c_int, [C.POINTER(PvsLayerDesc), C.POINTER(PvsGraph),
                                      C.POINTER(PvsLayerParams)] + [C.c_void_p] * 9 +
                            [C.c_void_p, C.c_size_t, C.c_void_p]),
+    'pvs_screen_graph_state_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    'pvs_screen_graph_build': (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_double, C.c_double, C.c_int32,
+                                                                              C.c_int32] + [C.c_void_p] * 10 +
+                               [C.c_void_p, C.c_size_t, C.c_void_p]),
     'pvs_graph_filter_workspace_bytes': (C.c_size_t, [C.c_int32]),
     'pvs_graph_filter_ligand_edges': (C.c_int, [C.POINTER(PvsGraph), C.c_void_p, C.c_int32] + [C.c_void_p] * 5 +
                                       [C.c_void_p, C.c_size_t, C.c_void_p]),

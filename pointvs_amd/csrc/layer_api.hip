@@ -268,7 +268,9 @@ extern "C" int pvs_egnn_layer_fwd(const PvsLayerDesc* d, const PvsGraph* g, cons
                                   float* saved, void* workspace, size_t workspace_bytes,
                                   pvs_stream_t stream_) {
     hipStream_t s = (hipStream_t)stream_;
-    PVS_TRY(check_desc(d, g, p));
+    PVS_TRY(check_desc(d, g, p, /*allow_dev_count=*/true));
+    PVS_REQUIRE(!g->n_edges_dev || (pvs_use_mfma() && pvs_edge_mfma_supported(d->hidden, d->flags) && !m_out),
+                "pvs_egnn_layer_fwd: a graph with a device-side edge count needs the MFMA edge kernel and m_out = NULL");
     PVS_REQUIRE(h && x && h_out && x_out && saved, "pvs_egnn_layer_fwd: NULL tensor");
     PVS_REQUIRE(x_out != x, "pvs_egnn_layer_fwd: x_out must not alias x");
     const bool eatt = d->flags & PVS_EDGE_ATTENTION;

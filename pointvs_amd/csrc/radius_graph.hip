@@ -18,6 +18,7 @@
 // FMA contraction, so the `<` decisions match the reference bit for bit.
 #include "common.h"
 #include "profile.h"
+#include "radius_common.h"
 #include <hipcub/hipcub.hpp>
 
 int pvs_build_csc(hipStream_t stream, const int32_t* col, int E, int N, int32_t* colptr, int32_t* cedge,
@@ -30,31 +31,6 @@ constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 constexpr int kRowsPerWave = 16;
 constexpr int kRowsPerBlock = kWaves * kRowsPerWave;
-
-// Distances: scipy euclidean_distance_double: s = 0; s += d*d for k = 0,1,2; d = sqrt(s)  (fp64, no FMA).
-// `sqrt(s) < r` and `sqrt(s) > 1e-7` exactly as the reference decides them, with the correctly
-// rounded square root only evaluated in the (practically never taken) band where comparing s with
-// r*r could disagree with it.
-struct Radius {
-    double r, lo, hi;   // s < lo => sqrt(s) < r for sure; s > hi => sqrt(s) >= r for sure
-};
-__host__ __device__ inline Radius make_radius(double r) {
-    Radius q;
-    q.r = r;
-    q.lo = r * r * (1.0 - 0x1p-48);
-    q.hi = r * r * (1.0 + 0x1p-48);
-    return q;
-}
-__device__ __forceinline__ bool below(double s, const Radius& q) {
-    if (s < q.lo) return true;
-    if (s > q.hi) return false;
-    return __dsqrt_rn(s) < q.r;
-}
-__device__ __forceinline__ bool above(double s, const Radius& q) {
-    if (s > q.hi) return true;
-    if (s < q.lo) return false;
-    return __dsqrt_rn(s) > q.r;
-}
 
 // block -> (graph, first row) and the per-graph offset of its neighbour bit masks
 __global__ void k_block_table(const int32_t* __restrict__ gptr, int B, int32_t* __restrict__ blk_graph,

@@ -40,6 +40,10 @@ class ReceptorScreen:
         self.r_inter = edge_radius
         self.r_intra = edge_radius if intra_radius is None else intra_radius
         self._lig_buf, self._pending, self._l1_ws = None, None, None
+        self._fast = None
+        # the specialised pose-batch builder (pvs_screen_graph_build) leaves the edge counts on the
+        # device; layers that return edge messages (edge_residual) need them on the host
+        self.fast_graph = self.reuse and n_lig <= 64 and not any(l.edge_residual for l in self.egnn)
         if not self.reuse:
             return
         lib = _lib.lib()
@@ -61,6 +65,7 @@ class ReceptorScreen:
                 _lib.ptr(rec_pos.contiguous()), _lib.ptr(magg), _lib.ptr(xsum), _lib.ptr(ws), ws_bytes,
                 _stream(dev)), 'pvs_egnn_layer_edge_sums')
             deg = (pg.t['rowptr'][1:] - pg.t['rowptr'][:-1]).float()
+            self._rr = pg          # receptor-receptor template (rowptr / col, receptor-local ids)
             n = n_lig + n_rec
             # batch layout: [ligand rows (no base) | receptor rows] per pose
             self.base_magg = torch.zeros((batch_size, n, first.hidden_nf), dtype=torch.float32, device=dev)
@@ -117,11 +122,12 @@ class ReceptorScreen:
                 raise RuntimeError('ReceptorScreen: ligand-edge buffer overflow (more ligand contacts than '
                                    'twice the first batch); rebuild the screen with a larger probe')
 
-    def _first_layer(self, batch, h, x):
+    def _first_layer(self, batch, h, x, g=None):
         lib = _lib.lib()
         first = self.egnn[0]
         dev = h.device
-        g = self._ligand_graph(batch)
+        if g is None:
+            g = self._ligand_graph(batch)
         desc = _lib.PvsLayerDesc(*first._desc())
         params = [None if p is None else p.detach().float().contiguous() for p in first._params()]
         pstruct = _lib.PvsLayerParams(*[_lib.ptr(p) for p in params])
@@ -142,18 +148,77 @@ class ReceptorScreen:
             'pvs_egnn_layer_fwd_partial')
         return h_out, x_out
 
+    def _build_fast(self, lig_poses):
+        """Full graph + ligand-touching subgraph of the pose batch from the receptor template
+        (pvs_screen_graph_build): no receptor-receptor distance tests, no host round trip."""
+        from .graph import PreparedGraph
+        lib = _lib.lib()
+        dev = lig_poses.device
+        n, b_, n_rec = self.batcher.n, self.b, self.batcher.n - self.n_lig
+        big_n = n * b_
+        if self._fast is None:
+            batch = self.batcher.load(lig_poses)       # one synchronous probe sizes the buffers
+            probe = radius_graph(batch.pos, batch.x[:, -1], batch.ptr, self.r_inter, self.r_intra,
+                                 max_graph_nodes=n, need_backward=False, ligand_pairs_only=True)
+            cap_l = min(4 * self.n_lig * n * b_, 2 * probe.n_edges + 4096)
+            cap = b_ * self._rr.n_edges + cap_l
+            i32 = dict(dtype=torch.int32, device=dev)
+            f = dict(cap=cap, cap_l=cap_l, status=torch.zeros(1, **i32),
+                     host=torch.zeros(1, dtype=torch.int32).pin_memory(),
+                     state=torch.empty(lib.pvs_screen_graph_state_bytes(b_, self.n_lig, n_rec), dtype=torch.uint8,
+                                       device=dev))
+            for tag, c in (('', cap), ('_l', cap_l)):
+                f['rowptr' + tag] = torch.empty(big_n + 1, **i32)
+                f['row' + tag] = torch.empty(c, **i32)
+                f['col' + tag] = torch.empty(c, **i32)
+                f['etype' + tag] = torch.empty(c, dtype=torch.uint8, device=dev)
+            f['inv_deg'] = torch.empty(big_n, dtype=torch.float32, device=dev)
+            f['ones'] = torch.ones(big_n, dtype=torch.float32, device=dev)
+            pg = PreparedGraph(big_n, cap, 3, dict(rowptr=f['rowptr'], row=f['row'], col=f['col'],
+                                                    etype=f['etype'], inv_deg=f['inv_deg'], status=f['status']))
+            pg._status_checked = True
+            pg.c.n_edges_dev = f['rowptr'][big_n:].data_ptr()
+            gl = _lib.PvsGraph()
+            gl.n_nodes, gl.n_edges = big_n, cap_l
+            gl.rowptr, gl.row, gl.col, gl.etype = (_lib.ptr(f[k + '_l']) for k in ('rowptr', 'row', 'col', 'etype'))
+            gl.inv_deg = _lib.ptr(f['ones'])
+            gl.n_edges_dev = f['rowptr_l'][big_n:].data_ptr()
+            f['pg'], f['gl'] = pg, gl
+            self._fast = f
+        f = self._fast
+        self.check()
+        self.batcher._pos[:, :self.n_lig] = lig_poses
+        _lib.check(lib.pvs_screen_graph_build(
+            _lib.ptr(lig_poses.contiguous()), _lib.ptr(self.batcher._pos[0, self.n_lig:].contiguous()),
+            _lib.ptr(self._rr.t['rowptr']), _lib.ptr(self._rr.t['col']), b_, self.n_lig, n_rec,
+            float(self.r_inter), float(self.r_intra), f['cap'], f['cap_l'],
+            _lib.ptr(f['rowptr']), _lib.ptr(f['row']), _lib.ptr(f['col']), _lib.ptr(f['etype']),
+            _lib.ptr(f['inv_deg']), _lib.ptr(f['rowptr_l']), _lib.ptr(f['row_l']), _lib.ptr(f['col_l']),
+            _lib.ptr(f['etype_l']), _lib.ptr(f['status']), _lib.ptr(f['state']), f['state'].numel(),
+            _stream(dev)), 'pvs_screen_graph_build')
+        f['host'].copy_(f['status'], non_blocking=True)
+        self._pending = torch.cuda.Event()
+        self._pending.record(torch.cuda.current_stream(dev))
+        self._lig_buf = dict(host=f['host'])       # check() reads the overflow flag from here
+        return f['pg'], f['gl']
+
     @torch.no_grad()
     def __call__(self, lig_poses):
-        batch = self.batcher.load(lig_poses)
         model = self.model
         if not self.reuse:
-            return model(batch)
+            return model(self.batcher.load(lig_poses))
+        if self.fast_graph:
+            pg_full, g_lig = self._build_fast(lig_poses)
+            batch = self.batcher.batch
+        else:
+            batch = self.batcher.load(lig_poses)
+            pg_full, g_lig = batch.prepared, None
         h = self.embed.embed(batch.x.float(), batch.pos).contiguous()
         x = batch.pos.contiguous()
-        h, x = self._first_layer(batch, h, x)
+        h, x = self._first_layer(batch, h, x, g_lig)
         m_sorted = None
         for layer in self.egnn[1:]:
-            h, x, m_sorted = layer.forward_prepared(batch.prepared, h, x, m_sorted, need_m=layer.edge_residual)
+            h, x, m_sorted = layer.forward_prepared(pg_full, h, x, m_sorted, need_m=layer.edge_residual)
         graph_ptr = batch.ptr.to(device=h.device, dtype=torch.int32)
         if model.feats_linear_layers is None:
             return h

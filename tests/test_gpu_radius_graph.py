@@ -175,3 +175,43 @@ def test_radius_graph_with_bond_radius_equals_prepare_graph_of_oracle_edges():
     assert pg.n_edges == ref.n_edges
     for k in ('rowptr', 'row', 'col', 'etype', 'colptr', 'cedge', 'inv_deg'):
         assert torch.equal(pg.t[k][:len(ref.t[k])], ref.t[k]), k
+
+
+def test_pose_batch_builder_equals_the_generic_builder():
+    """pvs_screen_graph_build (receptor-receptor pairs from a template, only ligand contacts tested)
+    == pvs_radius_graph_* on the same pose batch, array for array; its ligand-touching CSR == the
+    ligand-only build."""
+    import tempfile
+    from pointvs_amd.egnn_satorras import SartorrasEGNN
+    from pointvs_amd.radius_graph import PoseBatcher, radius_graph
+    from pointvs_amd.screening import ReceptorScreen
+    from pointvs_amd.synthetic import random_poses, screening_set
+    lig, rec, feats = screening_set(seed=5003, n_nodes=700, n_lig=17)
+    poses = random_poses(lig, 5, seed=9, max_shift=6.0).cuda()
+    kw = dict(dim_input=12, k=32, dim_output=1, num_layers=2, residual=False, edge_residual=False,
+              edge_attention=False, normalize=False, tanh=False, dropout=0.0, graphnorm=False, update_coords=True,
+              permutation_invariance=False, node_attention=False, gated_residual=False, rezero=False,
+              softmax_attention=False, model_task='classification')
+    torch.manual_seed(0)
+    model = SartorrasEGNN(tempfile.mkdtemp(), 2e-3, 1e-4, silent=True, **kw).eval()
+    for r_inter, r_intra in ((7.0, None), (6.0, 2.5)):
+        screen = ReceptorScreen(model, rec.cuda(), feats, 17, 5, edge_radius=r_inter, intra_radius=r_intra)
+        assert screen.fast_graph
+        pg, gl = screen._build_fast(poses)
+        screen.check()
+        ref_b = PoseBatcher(rec.cuda(), feats, 17, 5, r_inter, r_intra).load(poses)
+        ref = ref_b.prepared
+        n = ref.n_nodes
+        e = int(screen._fast['rowptr'][n].item())
+        assert e == ref.n_edges
+        assert torch.equal(screen._fast['rowptr'], ref.t['rowptr'])
+        for k in ('row', 'col', 'etype'):
+            assert torch.equal(screen._fast[k][:e], ref.t[k][:e]), k
+        assert torch.equal(screen._fast['inv_deg'], ref.t['inv_deg'])
+        lig_ref = radius_graph(ref_b.pos, ref_b.x[:, -1], ref_b.ptr, r_inter, r_intra, max_graph_nodes=717,
+                               need_backward=False, ligand_pairs_only=True)
+        el = int(screen._fast['rowptr_l'][n].item())
+        assert el == lig_ref.n_edges
+        assert torch.equal(screen._fast['rowptr_l'], lig_ref.t['rowptr'])
+        for k in ('row', 'col', 'etype'):
+            assert torch.equal(screen._fast[k + '_l'][:el], lig_ref.t[k][:el]), k
