@@ -215,3 +215,28 @@ def test_pose_batch_builder_equals_the_generic_builder():
         assert torch.equal(screen._fast['rowptr_l'], lig_ref.t['rowptr'])
         for k in ('row', 'col', 'etype'):
             assert torch.equal(screen._fast[k + '_l'][:el], lig_ref.t[k][:el]), k
+
+
+def test_captured_screening_step_replays_on_new_poses():
+    """hipGraph capture of the whole screening step (graph build + layer stack + head): replays on
+    other pose batches give the eager results."""
+    import tempfile
+    from pointvs_amd.egnn_satorras import SartorrasEGNN
+    from pointvs_amd.screening import ReceptorScreen
+    from pointvs_amd.synthetic import random_poses, screening_set
+    lig, rec, feats = screening_set(seed=5004, n_nodes=600, n_lig=20)
+    poses = random_poses(lig, 12, seed=2, max_shift=5.0).cuda()
+    kw = dict(dim_input=12, k=32, dim_output=1, num_layers=3, residual=True, edge_residual=False,
+              edge_attention=True, normalize=False, tanh=True, dropout=0.0, graphnorm=False, update_coords=True,
+              permutation_invariance=False, node_attention=False, gated_residual=False, rezero=False,
+              softmax_attention=False, model_task='classification')
+    torch.manual_seed(2)
+    model = SartorrasEGNN(tempfile.mkdtemp(), 2e-3, 1e-4, silent=True, **kw).eval()
+    eager = ReceptorScreen(model, rec.cuda(), feats, 20, 4, edge_radius=7.0)
+    want = [eager(poses[4 * k:4 * k + 4]).reshape(-1).clone() for k in range(3)]
+    eager.check()
+    graph = ReceptorScreen(model, rec.cuda(), feats, 20, 4, edge_radius=7.0).capture(poses[:4])
+    for k in (2, 0, 1):
+        got = graph.replay(poses[4 * k:4 * k + 4]).reshape(-1).clone()
+        assert torch.equal(got, want[k])
+    graph.check()
