@@ -246,9 +246,10 @@ int node_pre_forward(hipStream_t s, const Dims& m, const PvsLayerParams* p, cons
 
 extern "C" size_t pvs_egnn_layer_saved_floats(const PvsLayerDesc* d, int32_t N, int32_t E) {
     (void)E;
-    // Magg [N,H] | graphnorm stats [2H] | PQ [N,2H] | y1 [N,H] | o [N,H]: the node-level forward is
+    // Magg [N,H] | graphnorm stats [2H] | PQ [N,2H] | y1 [N,H] | o [N,H] | u [N,H]: the node-level forward is
     // kept for the backward (N rows: small) instead of being recomputed
-    return 5 * (size_t)N * d->hidden + 2 * (size_t)d->hidden;
+    // (+ u = SiLU(GN(y1)) [N,H]: one small launch less in the backward)
+    return 6 * (size_t)N * d->hidden + 2 * (size_t)d->hidden;
 }
 
 extern "C" size_t pvs_egnn_layer_workspace_bytes(const PvsLayerDesc* d, int32_t N, int32_t E,
@@ -301,7 +302,7 @@ extern "C" int pvs_egnn_layer_fwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     if (!(d->flags & PVS_UPDATE_COORDS))
         PVS_CHECK_HIP(hipMemcpyAsync(x_out, x, sizeof(float) * 3 * (size_t)m.N,
                                      hipMemcpyDeviceToDevice, s));
-    PVS_TRY(node_mlp_forward(s, m, d, p, nw, h, Magg, sy1, w.u, so, stats, true, w.shift, w.slabs));
+    PVS_TRY(node_mlp_forward(s, m, d, p, nw, h, Magg, sy1, so + (size_t)m.N * H, so, stats, true, w.shift, w.slabs));
     PVS_TRY(pvs_node_out_fwd(s, H, so, h, nw, d->flags, d->att_act, m.N, h_out, node_att_out));
     return 0;
 }
@@ -404,7 +405,7 @@ extern "C" int pvs_egnn_layer_fwd_partial(const PvsLayerDesc* d, const PvsGraph*
                                                                    g->rowptr, m.N, H,
                                                                    (d->flags & PVS_UPDATE_COORDS) ? 1 : 0);
     PVS_CHECK_LAUNCH();
-    PVS_TRY(node_mlp_forward(s, m, d, p, nw, h, Magg, sy1, w.u, so, stats, true, w.shift, w.slabs));
+    PVS_TRY(node_mlp_forward(s, m, d, p, nw, h, Magg, sy1, so + (size_t)m.N * H, so, stats, true, w.shift, w.slabs));
     PVS_TRY(pvs_node_out_fwd(s, H, so, h, nw, d->flags, d->att_act, m.N, h_out, node_att_out));
     return 0;
 }
@@ -448,7 +449,7 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
                               !getenv("PVS_EGNN_SPLIT_WGRADS");
 
     // ---- node-level forward: PQ, y1, o were kept by the forward; u = SiLU(GN(y1)) is elementwise ----
-    PVS_TRY(pvs_node_tail_fwd(s, sy1, stats, nw, N, H, w.u));
+    const float* su = so + (size_t)N * H;      // u = SiLU(GN(y1)) kept by the forward
 
     // ---- node_model backward ----
     PVS_TRY(pvs_node_out_bwd(s, H, g_h_out, so, h, nw, F, d->att_act, N, w.g_o, g_h, w.gl, w.t1,
@@ -470,7 +471,7 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     PVS_TRY(pvs_launch_linear(s, w.g_u, H, w.g_o, H, p->node_w2, 1, H, nullptr, nullptr, 0, nullptr, 0,
                               0, N, H, 0, H, false));
     if (gr.node_w2 && !fused_wgrads)
-        PVS_TRY(pvs_launch_tsgemm_tn(s, gr.node_w2, H, w.g_o, H, w.u, H, N, H, H, w.dslabs, false));
+        PVS_TRY(pvs_launch_tsgemm_tn(s, gr.node_w2, H, w.g_o, H, su, H, N, H, H, w.dslabs, false));
     if (gr.node_b2 && !fused_wgrads)
         PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.node_b2, w.g_o, H, nullptr, 0, nullptr, N, H,
                                      1.f, w.dslabs, false));
@@ -575,13 +576,12 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     }
 
     // ---- first edge-MLP layer at node level: P = W1a h + b1, Q = W1b h ----
-    PVS_TRY(pvs_launch_linear(s, g_h, H, w.gPQ, 2 * H, p->edge_w1, 1, m.ld1, nullptr, nullptr, 0,
-                              nullptr, 0, 0, N, H, 0, H, true));
-    PVS_TRY(pvs_launch_linear(s, g_h, H, w.gPQ + H, 2 * H, p->edge_w1 + m.off_q, 1, m.ld1, nullptr,
-                              nullptr, 0, nullptr, 0, 0, N, H, 0, H, true));
+    // g_h += g_P W1a + g_Q W1b: one launch with the two (input, weight) pairs
+    PVS_TRY(pvs_launch_linear(s, g_h, H, w.gPQ, 2 * H, p->edge_w1, 1, m.ld1, nullptr, w.gPQ + H, 2 * H,
+                              p->edge_w1 + m.off_q, 1, m.ld1, N, H, H, H, true));
     if (fused_wgrads) {
         PvsNodeWgradIn wi;
-        wi.g_o = w.g_o; wi.g_y1 = g_y1; wi.gPQ = w.gPQ; wi.u = w.u; wi.h = h; wi.Magg = Magg;
+        wi.g_o = w.g_o; wi.g_y1 = g_y1; wi.gPQ = w.gPQ; wi.u = su; wi.h = h; wi.Magg = Magg;
         PvsNodeWgradOut wo;
         wo.node_w2 = gr.node_w2; wo.node_w1 = gr.node_w1; wo.edge_w1 = gr.edge_w1;
         wo.node_b2 = gr.node_b2; wo.node_b1 = gr.node_b1; wo.edge_b1 = gr.edge_b1;
