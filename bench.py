@@ -185,6 +185,8 @@ def main():
                     help='cfg5: virtual-screening sweep (BASELINE config 5): forward only, random poses '
                          'of one ligand against one receptor, graphs built on the GPU per batch')
     ap.add_argument('--batch', type=int, default=32, help='graphs per GPU')
+    ap.add_argument('--global-batch', type=int, default=0,
+                    help='strong scaling (BASELINE config 4): fixed global batch, --batch becomes global/gpus')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--infer', action='store_true',
                     help='forward-only (torch.no_grad) throughput: the virtual-screening shape of '
@@ -196,6 +198,11 @@ def main():
     ap.add_argument('--graph', type=int, default=int(os.environ.get('PVS_BENCH_GRAPH', '0')),
                     help='1: capture the whole training step in a hipGraph and time replays')
     args = ap.parse_args()
+    strong = args.global_batch > 0
+    if strong:
+        if args.global_batch % args.gpus:
+            raise SystemExit(f'--global-batch {args.global_batch} is not divisible by --gpus {args.gpus}')
+        args.batch = args.global_batch // args.gpus
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -351,8 +358,8 @@ def main():
                       'edge+node attention, ~2k nodes r=6A',
             'value': round(graphs_per_s, 2), 'unit': 'graphs/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
-            'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{args.config}: {layers}-layer EGNN, channels={h}, '
                                    f'edge_radius={cfg["graph"]["edge_radius"]}A, '
                                    f'{args.batch} graphs/GPU x {cfg["graph"]["n_nodes"]} atoms, '

@@ -479,3 +479,25 @@ def test_fused_clip_adam_matches_torch_adam():
     for k in sa:
         assert float(sa[k]['step']) == float(sb[k]['step'])
         assert rel_err(sa[k]['exp_avg_sq'].cpu().numpy(), sb[k]['exp_avg_sq'].cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize('config', ['cfg2', 'cfg3'])
+def test_kernel_families_agree_at_baseline_batch_size(config):
+    """BASELINE configs at their full per-GPU batch (8 graphs for cfg3 to bound the generic kernels'
+    time): MFMA kernels vs generic kernels, outputs and every gradient."""
+    from pointvs_amd.synthetic import CONFIGS, synthetic_batch
+    cfg = CONFIGS[config]
+    model, _ = make_model(seed=5, **{k: v for k, v in cfg['model'].items() if k in BASE_KW})
+    g = synthetic_batch(cfg['cfg_id'], 32 if config == 'cfg2' else 8, **cfg['graph'])
+    os.environ.pop('PVS_EGNN_KERNELS', None)
+    y_a, g_a = gpu_run(model, g)
+    os.environ['PVS_EGNN_KERNELS'] = 'generic'
+    try:
+        y_b, g_b = gpu_run(model, g)
+    finally:
+        os.environ.pop('PVS_EGNN_KERNELS', None)
+    assert rel_err(y_a, y_b) < TOL
+    for pname in g_a:
+        assert (g_a[pname] is None) == (g_b[pname] is None)
+        if g_a[pname] is not None:
+            assert rel_err(g_a[pname], g_b[pname]) < 2 * TOL, pname
