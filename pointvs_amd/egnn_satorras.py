@@ -8,6 +8,8 @@ The nn.Sequential members only hold parameters under the reference's names (so r
 checkpoints load and seeds give the same init); they are never called. The arithmetic of
 forward/backward is `pvs_egnn_layer_fwd/bwd` in libpvs_egnn.so (include/pvs_egnn.h).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -165,7 +167,7 @@ class EGNNLayer(nn.Module):
 
     _KERNEL_WIDTHS = (16, 32, 64)
 
-    def _padded_call(self, pg, h, coord, m_prev_sorted, need_m):
+    def _padded_call(self, pg, h, coord, m_prev_sorted, need_m, flags=None):
         """Hidden sizes the kernels are not built for run zero-padded to the next built width.
         Exact: a zero channel stays zero through SiLU, the products, GraphNorm (weight 0, bias 0)
         and the gates, so the extra channels contribute nothing; padding/slicing are autograd ops."""
@@ -192,27 +194,44 @@ class EGNNLayer(nn.Module):
                   cols(p[6]), cols(p[7]), p[8], rows(wn1p), rows(p[10]), rows(cols(p[11])), rows(p[12]),
                   rows(p[13]), rows(p[14]), rows(p[15]), cols(p[16]), p[17], p[18], p[19]]
         desc = (wide, a) + self._desc()[2:]
+        if flags is not None:
+            desc = (wide, a, flags, desc[3])
         mp = None if m_prev_sorted is None else F.pad(m_prev_sorted, (0, pad))
         h_out, x_out, m_sorted, att, natt = PF.egnn_layer(
             F.pad(h, (0, pad)), coord, mp, pg, desc, need_m, tuple(padded))
         return (h_out[:, :hid], x_out, None if m_sorted is None else m_sorted[:, :hid], att, natt)
 
-    def forward_prepared(self, pg, h, coord, m_prev_sorted=None, need_m=False):
-        """Layer on a PreparedGraph; edge tensors stay in CSR-sorted order (internal fast path)."""
+    def forward_prepared(self, pg, h, coord, m_prev_sorted=None, need_m=False, need_coords=True):
+        """Layer on a PreparedGraph; edge tensors stay in CSR-sorted order (internal fast path).
+        need_coords=False: the caller discards the returned coordinates (the last layer of a model:
+        `x_L` feeds nothing), so the coordinate branch of the edge kernel is skipped and
+        the input coordinates are returned; `intermediate_coords` is then evaluated on demand."""
         if not self.edge_residual:
             m_prev_sorted = None
+        # PVS_EGNN_KEEP_DEAD_COORDS=1 evaluates the unused coordinate update anyway (like the reference)
+        skip_coords = self.use_coords and not need_coords and not os.environ.get('PVS_EGNN_KEEP_DEAD_COORDS')
+        desc = self._desc()
+        if skip_coords:
+            desc = (desc[0], desc[1], desc[2] & ~_lib.UPDATE_COORDS, desc[3])
         if self.hidden_nf > max(self._KERNEL_WIDTHS):
             raise NotImplementedError(f'hidden size {self.hidden_nf} > {max(self._KERNEL_WIDTHS)} is '
                                       f'not built in libpvs_egnn.so')
         if self.hidden_nf not in self._KERNEL_WIDTHS:
-            h_out, x_out, m_sorted, att, natt = self._padded_call(pg, h, coord, m_prev_sorted, need_m)
+            h_out, x_out, m_sorted, att, natt = self._padded_call(pg, h, coord, m_prev_sorted, need_m, desc[2])
         else:
             h_out, x_out, m_sorted, att, natt = PF.egnn_layer(
-                h, coord, m_prev_sorted, pg, self._desc(), need_m, self._params())
+                h, coord, m_prev_sorted, pg, desc, need_m, self._params())
         self._att_src = None if att is None else (
             lambda: PF.rows_to_input_order(att.detach()[:pg.n_edges].reshape(-1, 1), pg))
         self._natt_src = None if natt is None else (lambda: natt.detach().reshape(-1, 1))
-        self._coords_src = (lambda: x_out.detach()) if self.use_coords else self._coords_src
+        if skip_coords:
+            def coords_on_demand(h=h.detach(), coord=coord.detach(),
+                                 mp=None if m_prev_sorted is None else m_prev_sorted.detach()):
+                with torch.no_grad():
+                    return self.forward_prepared(pg, h, coord, mp, need_m=False)[1]
+            self._coords_src = coords_on_demand
+        else:
+            self._coords_src = (lambda: x_out.detach()) if self.use_coords else self._coords_src
         return h_out, x_out, m_sorted
 
     def forward(self, h, edge_index, coord, edge_attr=None, edge_messages=None):
@@ -306,9 +325,11 @@ class SartorrasEGNN(PNNGeometricBase):
         self.feats_linear_layers = nn.Sequential(*head)
         return nn.Sequential(*layers)
 
-    def embed_prepared(self, pg, feats, coords, need_messages=False, trace=None):
+    def embed_prepared(self, pg, feats, coords, need_messages=False, trace=None, need_coords=True):
         """Layer stack on a PreparedGraph. Edge messages stay in sorted order between layers and
-        are only materialised where a consumer exists (edge_residual, or need_messages)."""
+        are only materialised where a consumer exists (edge_residual, or need_messages).
+        need_coords=False: the caller ignores the returned coordinates, so the last layer skips its
+        coordinate branch (nothing downstream reads x_L)."""
         embed = self.layers[0]
         feats = embed.embed(feats, coords)
         if trace is not None:
@@ -319,7 +340,8 @@ class SartorrasEGNN(PNNGeometricBase):
             last = idx == len(egnn_layers) - 1
             need_m = (need_messages and last) or (self.edge_residual and not last)
             feats, coords, m_sorted = layer.forward_prepared(
-                pg, feats, coords, m_sorted, need_m=need_m)
+                pg, feats, coords, m_sorted, need_m=need_m,
+                need_coords=need_coords or not last or trace is not None)
             if trace is not None:
                 trace[f'h{idx + 1}'], trace[f'x{idx + 1}'] = feats, coords
         return feats, coords, m_sorted
@@ -328,7 +350,7 @@ class SartorrasEGNN(PNNGeometricBase):
         """Reference signature (egnn_satorras.py:319-329): returns (feats, edge_messages) with
         edge_messages in the caller's edge order."""
         pg = prepared_for(edges, edge_attributes, feats.size(0))
-        feats, _, m_sorted = self.embed_prepared(pg, feats, coords, need_messages=True)
+        feats, _, m_sorted = self.embed_prepared(pg, feats, coords, need_messages=True, need_coords=False)
         edge_messages = None if m_sorted is None else PF.rows_to_input_order(m_sorted, pg)
         return feats, edge_messages
 

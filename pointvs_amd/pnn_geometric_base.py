@@ -49,7 +49,7 @@ class PNNGeometricBase(PointNeuralNetworkBase):
         if pg is None:
             pg = prepared_for(edges, edge_attributes, n_nodes, segments)
         pg.poll_status()
-        feats, _, _ = self.embed_prepared(pg, feats, coords)
+        feats, _, _ = self.embed_prepared(pg, feats, coords, need_coords=False)
         return feats, pg, graph_ptr, n_graphs
 
     @staticmethod

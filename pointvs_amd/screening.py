@@ -255,7 +255,8 @@ class ReceptorScreen:
         h, x = self._first_layer(batch, h, x, g_lig)
         m_sorted = None
         for layer in self.egnn[1:]:
-            h, x, m_sorted = layer.forward_prepared(pg_full, h, x, m_sorted, need_m=layer.edge_residual)
+            h, x, m_sorted = layer.forward_prepared(pg_full, h, x, m_sorted, need_m=layer.edge_residual,
+                                                    need_coords=layer is not self.egnn[-1])
         if model.feats_linear_layers is None:
             return h
         return model._run_head(model.feats_linear_layers, model._pool(h, self._graph_ptr, self.b))

@@ -501,3 +501,26 @@ def test_kernel_families_agree_at_baseline_batch_size(config):
         assert (g_a[pname] is None) == (g_b[pname] is None)
         if g_a[pname] is not None:
             assert rel_err(g_a[pname], g_b[pname]) < 2 * TOL, pname
+
+
+def test_last_layer_coordinates_are_available_on_demand():
+    """The model forward skips the last layer's coordinate branch (nothing reads x_L); the layer's
+    `intermediate_coords` side attribute (egnn_satorras.py:175) must still give the reference value."""
+    from pointvs_amd.graph import prepared_for
+    model, _ = make_model(seed=7, num_layers=3, tanh=True, residual=True)
+    g = random_graph(300, 6000, seed=3, n_graphs=2).to('cuda')
+    with torch.no_grad():
+        y_skip = model(g).reshape(-1).clone()
+        lazy = model.layers[-1].intermediate_coords
+        feats, edges, coords, eattr, _ = model.unpack_graph(g)
+        pg = prepared_for(edges, eattr, feats.size(0))
+        trace = {}
+        model.embed_prepared(pg, feats, coords, trace=trace)          # full evaluation
+        os.environ['PVS_EGNN_KEEP_DEAD_COORDS'] = '1'
+        try:
+            y_full = model(g).reshape(-1).clone()
+        finally:
+            os.environ.pop('PVS_EGNN_KEEP_DEAD_COORDS')
+    assert torch.equal(y_skip, y_full)
+    assert np.array_equal(lazy, trace['x3'].cpu().numpy())
+    assert not np.array_equal(lazy, trace['x2'].cpu().numpy())
