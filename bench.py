@@ -187,6 +187,9 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='graphs per GPU')
     ap.add_argument('--global-batch', type=int, default=0,
                     help='strong scaling (BASELINE config 4): fixed global batch, --batch becomes global/gpus')
+    ap.add_argument('--skip-dead-coords', action='store_true',
+                    help='let the model skip the last layer\'s coordinate update, whose result nothing reads '
+                         '(the library default); the bench evaluates it by default, like the reference does')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--infer', action='store_true',
                     help='forward-only (torch.no_grad) throughput: the virtual-screening shape of '
@@ -199,6 +202,8 @@ def main():
                     help='1: capture the whole training step in a hipGraph and time replays')
     args = ap.parse_args()
     strong = args.global_batch > 0
+    if not args.skip_dead_coords:      # same per-step work as the reference: every layer updates x
+        os.environ['PVS_EGNN_KEEP_DEAD_COORDS'] = '1'
     if strong:
         if args.global_batch % args.gpus:
             raise SystemExit(f'--global-batch {args.global_batch} is not divisible by --gpus {args.gpus}')
@@ -367,6 +372,7 @@ def main():
                                    f'layer flags, Adam lr 2e-3 wd 1e-4 clip 1.0, random init',
                        'graphs_per_gpu': args.batch, 'global_batch': world * args.batch,
                        'parallelism': f'dp{world}', 'final_loss': round(final_loss, 6),
+                       'last_layer_coord_update': 'skipped (dead)' if args.skip_dead_coords else 'evaluated',
                        'launch': 'hipGraph replay of the whole step' if use_graph else 'eager'},
             'roofline': {
                 'bound': 'hbm', 'kernel': ('k_edge_bwd_mfma<1> (edge backward, one launch per layer)' if h == 32
