@@ -24,6 +24,10 @@ int pvs_launch_colreduce(hipStream_t s, int mode, float* out, const float* A, in
 int pvs_launch_reduce_slabs(hipStream_t s, float* out, int ldo, int inner, const float* slabs,
                             int n_slabs, int width, bool accumulate);
 
+// out_a[o] = sum_g slabs_a[g*width_a + o] except o in [skip_lo, skip_hi); out_b[o] = sum_g slabs_b[g*width_b + o]
+int pvs_launch_reduce_slabs2(hipStream_t s, float* out_a, const float* slabs_a, int n_a, int width_a, int skip_lo,
+                             int skip_hi, float* out_b, const float* slabs_b, int n_b, int width_b);
+
 // All node-level weight gradients of one EGNNLayer backward in one pass over the N rows (H = 32, 64):
 //   node_w2 = g_o^T u, node_w1 = g_y1^T [h | Magg], edge_w1[:, P/Q columns] = [gP | gQ]^T h and the
 //   bias gradients node_b2 / node_b1 / edge_b1 = column sums of g_o / g_y1 / gP.

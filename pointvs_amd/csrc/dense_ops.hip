@@ -148,6 +148,32 @@ k_reduce_slabs(float* __restrict__ out, int ldo, int inner, const float* __restr
     }
 }
 
+// Two slab reductions in one launch (the edge kernel's slabs and the column gather's slabs of one
+// layer backward): blocks [0, blocks_a) do A, the rest B; A leaves [skip_lo, skip_hi) to B.
+__global__ void __launch_bounds__(kThreads)
+k_reduce_slabs2(float* __restrict__ out_a, const float* __restrict__ slabs_a, int n_a, int width_a, int blocks_a,
+                int skip_lo, int skip_hi, float* __restrict__ out_b, const float* __restrict__ slabs_b, int n_b,
+                int width_b) {
+    __shared__ float part[8][33];
+    const bool is_a = (int)blockIdx.x < blocks_a;
+    const float* slabs = is_a ? slabs_a : slabs_b;
+    float* out = is_a ? out_a : out_b;
+    const int n_slabs = is_a ? n_a : n_b, width = is_a ? width_a : width_b;
+    const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int o = ((int)blockIdx.x - (is_a ? 0 : blocks_a)) * 32 + ol;
+    float s = 0.f;
+    if (o < width)
+        for (int gidx = sl; gidx < n_slabs; gidx += 8) s += slabs[(size_t)gidx * width + o];
+    part[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && o < width && !(is_a && o >= skip_lo && o < skip_hi)) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += part[k][ol];
+        out[o] = t;
+    }
+}
+
 constexpr int kPoolThreads = 1024;
 // One workgroup per graph; thread = (row slot, channel), 4 independent partial sums per thread so
 // that 4 * (1024 / width) rows are in flight; fixed summation order.
@@ -501,6 +527,15 @@ int pvs_launch_reduce_slabs(hipStream_t s, float* out, int ldo, int inner, const
                             int n_slabs, int width, bool accumulate) {
     k_reduce_slabs<<<(width + 31) / 32, kThreads, 0, s>>>(out, ldo, inner, slabs, n_slabs, width, 1.0f,
                                                           accumulate ? 1 : 0);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+int pvs_launch_reduce_slabs2(hipStream_t s, float* out_a, const float* slabs_a, int n_a, int width_a, int skip_lo,
+                             int skip_hi, float* out_b, const float* slabs_b, int n_b, int width_b) {
+    const int ba = (width_a + 31) / 32, bb = (width_b + 31) / 32;
+    k_reduce_slabs2<<<ba + bb, kThreads, 0, s>>>(out_a, slabs_a, n_a, width_a, ba, skip_lo, skip_hi, out_b, slabs_b,
+                                                 n_b, width_b);
     PVS_CHECK_LAUNCH();
     return 0;
 }

@@ -568,11 +568,13 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
         PVS_TRY(pvs_launch_node_gather(s, H, *g, false, w.gz1, w.gd, w.gx_row, g_x_out, w.gPQ, g_x,
                                        w.nslabs, 0, N, &n_nslabs));
     }
-    PVS_TRY(pvs_launch_reduce_slabs(s, w.gsum, L.total, L.total, w.eslabs, n_slabs, L.total, false));
-    if (mfma_bwd) {   // g_wrho / g_wattr come from the node gather: overwrite those slab regions
-        // slab layout [wrho | wattr0 | wattr1 | wattr2] == gsum[L.wrho .. L.wrho + 4H)
-        PVS_TRY(pvs_launch_reduce_slabs(s, w.gsum + L.wrho, 4 * H, 4 * H, w.nslabs, n_nslabs, 4 * H,
-                                        false));
+    if (mfma_bwd) {
+        // g_wrho / g_wattr come from the node gather: its slab layout [wrho | wattr0 | wattr1 | wattr2]
+        // == gsum[L.wrho .. L.wrho + 4H), which the edge slabs leave alone (one launch for both)
+        PVS_TRY(pvs_launch_reduce_slabs2(s, w.gsum, w.eslabs, n_slabs, L.total, L.wrho, L.wrho + 4 * H,
+                                         w.gsum + L.wrho, w.nslabs, n_nslabs, 4 * H));
+    } else {
+        PVS_TRY(pvs_launch_reduce_slabs(s, w.gsum, L.total, L.total, w.eslabs, n_slabs, L.total, false));
     }
 
     // ---- first edge-MLP layer at node level: P = W1a h + b1, Q = W1b h ----
