@@ -42,7 +42,41 @@ struct PvsNodeWgradOut {
     float *node_b2, *node_b1, *edge_b1;     // NULL to skip
     int ld1, off_q, perm;                   // edge_w1 row stride, column of the Q block, P/Q share columns
 };
+// reduced sums layout (per 32x32 sub-block (bo, bi) of the H x H products): 5 products x [32][32],
+// then 3 bias vectors x [32] (valid for bi == 0)
+#define PVS_WG_PRODUCTS 5
+#define PVS_WG_BIAS 3
+#define PVS_WG_SLAB (PVS_WG_PRODUCTS * 1024 + PVS_WG_BIAS * 32)
+// scatter of the reduced sums into the gradient tensors (device side, for fusing into another small kernel)
+__device__ __forceinline__ void pvs_node_wgrads_scatter(const float* __restrict__ gsum, const PvsNodeWgradOut& out,
+                                                        int H, int tid, int stride);
 int pvs_node_wgrads_supported(int H);
 size_t pvs_node_wgrads_slab_floats(int N, int H);
+// scatter = false: stop after the slab reduction; *gsum_out then points at the reduced sums for a later
+// pvs_node_wgrads_scatter
 int pvs_launch_node_wgrads(hipStream_t s, int H, int N, const PvsNodeWgradIn& in, const PvsNodeWgradOut& out,
-                           float* slabs);
+                           float* slabs, bool scatter = true, const float** gsum_out = nullptr);
+
+__device__ __forceinline__ void pvs_node_wgrads_scatter(const float* __restrict__ gsum, const PvsNodeWgradOut& out,
+                                                        int H, int tid, int stride) {
+    const int HB = H / 32;
+    for (int i = tid; i < H * H; i += stride) {
+        const int c = i / H, k = i % H;
+        const float* b = gsum + (size_t)((c >> 5) * HB + (k >> 5)) * PVS_WG_SLAB + (c & 31) * 32 + (k & 31);
+        out.node_w2[(size_t)c * H + k] = b[0];
+        out.node_w1[(size_t)c * 2 * H + k] = b[1024];
+        out.node_w1[(size_t)c * 2 * H + H + k] = b[2 * 1024];
+        if (out.perm) {
+            out.edge_w1[(size_t)c * out.ld1 + k] = b[3 * 1024] + b[4 * 1024];
+        } else {
+            out.edge_w1[(size_t)c * out.ld1 + k] = b[3 * 1024];
+            out.edge_w1[(size_t)c * out.ld1 + out.off_q + k] = b[4 * 1024];
+        }
+    }
+    for (int c = tid; c < H; c += stride) {
+        const float* b = gsum + (size_t)((c >> 5) * HB) * PVS_WG_SLAB + PVS_WG_PRODUCTS * 1024 + (c & 31);
+        if (out.node_b2) out.node_b2[c] = b[0];
+        if (out.node_b1) out.node_b1[c] = b[32];
+        if (out.edge_b1) out.edge_b1[c] = b[64];
+    }
+}

@@ -364,8 +364,8 @@ k_tsgemm_mfma(float* __restrict__ slabs, const float* __restrict__ A, int lda,
 // Products (A, B): (g_o, u) (g_y1, h) (g_y1, Magg) (gP, h) (gQ, h); column sums of g_o, g_y1, gP.
 // blockIdx.y = 32x32 sub-block (bo, bi) of every product; per wave 5 accumulators; rows as the MFMA
 // k index, operands straight from row-major HBM (as k_tsgemm_mfma).
-constexpr int kWgProducts = 5, kWgBias = 3;
-constexpr int kWgSlab = kWgProducts * 1024 + kWgBias * 32;   // floats per (row block, sub-block)
+constexpr int kWgProducts = PVS_WG_PRODUCTS, kWgBias = PVS_WG_BIAS;
+constexpr int kWgSlab = PVS_WG_SLAB;   // floats per (row block, sub-block)
 constexpr int kWgRowsPerBlock = 256;
 
 template <int HB>
@@ -441,29 +441,8 @@ k_node_wgrads(float* __restrict__ slabs, PvsNodeWgradIn in, int N) {
     for (int i = threadIdx.x; i < kWgSlab; i += kThreads) dst[i] = red[i];
 }
 
-template <int HB>
-__global__ void k_node_wgrads_scatter(const float* __restrict__ gsum, PvsNodeWgradOut out) {
-    constexpr int H = 32 * HB;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    for (int i = tid; i < H * H; i += stride) {
-        const int c = i / H, k = i % H;
-        const float* b = gsum + (size_t)((c >> 5) * HB + (k >> 5)) * kWgSlab + (c & 31) * 32 + (k & 31);
-        out.node_w2[(size_t)c * H + k] = b[0];
-        out.node_w1[(size_t)c * 2 * H + k] = b[1024];
-        out.node_w1[(size_t)c * 2 * H + H + k] = b[2 * 1024];
-        if (out.perm) {
-            out.edge_w1[(size_t)c * out.ld1 + k] = b[3 * 1024] + b[4 * 1024];
-        } else {
-            out.edge_w1[(size_t)c * out.ld1 + k] = b[3 * 1024];
-            out.edge_w1[(size_t)c * out.ld1 + out.off_q + k] = b[4 * 1024];
-        }
-    }
-    for (int c = tid; c < H; c += stride) {
-        const float* b = gsum + (size_t)((c >> 5) * HB) * kWgSlab + kWgProducts * 1024 + (c & 31);
-        if (out.node_b2) out.node_b2[c] = b[0];
-        if (out.node_b1) out.node_b1[c] = b[32];
-        if (out.edge_b1) out.edge_b1[c] = b[64];
-    }
+__global__ void k_node_wgrads_scatter(const float* __restrict__ gsum, PvsNodeWgradOut out, int H) {
+    pvs_node_wgrads_scatter(gsum, out, H, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 int grid_for(long long work_items, int per_block) {
@@ -586,7 +565,7 @@ size_t pvs_node_wgrads_slab_floats(int N, int H) {
 }
 
 int pvs_launch_node_wgrads(hipStream_t s, int H, int N, const PvsNodeWgradIn& in, const PvsNodeWgradOut& out,
-                           float* slabs) {
+                           float* slabs, bool scatter, const float** gsum_out) {
     PVS_REQUIRE(pvs_node_wgrads_supported(H), "node_wgrads: H = %d unsupported", H);
     PVS_REQUIRE(out.node_w2 && out.node_w1 && out.edge_w1, "node_wgrads: NULL weight gradient");
     const int hb = H / 32, rb = wg_row_blocks(N);
@@ -597,8 +576,9 @@ int pvs_launch_node_wgrads(hipStream_t s, int H, int N, const PvsNodeWgradIn& in
     PVS_CHECK_LAUNCH();
     k_reduce_slabs<<<(width + 31) / 32, kThreads, 0, s>>>(gsum, width, width, slabs, rb, width, 1.0f, 0);
     PVS_CHECK_LAUNCH();
-    if (hb == 1) k_node_wgrads_scatter<1><<<4, kThreads, 0, s>>>(gsum, out);
-    else k_node_wgrads_scatter<2><<<16, kThreads, 0, s>>>(gsum, out);
+    if (gsum_out) *gsum_out = gsum;
+    if (!scatter) return 0;
+    k_node_wgrads_scatter<<<hb == 1 ? 4 : 16, kThreads, 0, s>>>(gsum, out, H);
     PVS_CHECK_LAUNCH();
     return 0;
 }

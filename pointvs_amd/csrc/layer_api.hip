@@ -186,9 +186,12 @@ size_t carve_bwd(PvsArena& a, const Dims& m, BwdWs* w) {
 // scatter the reduced edge-kernel slab into the parameter gradients
 __global__ void k_finalize_edge_grads(const float* __restrict__ gsum, PvsSlabLayout L, int H, int A,
                                       int ld1, int off_rho, PvsLayerGrads gr, int has_coord,
-                                      int has_att, int has_gate) {
+                                      int has_att, int has_gate, const float* __restrict__ node_gsum,
+                                      PvsNodeWgradOut node_out) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = gridDim.x * blockDim.x;
+    // (the node-level weight gradients' reduced sums, when they were left for this kernel to scatter)
+    if (node_gsum) pvs_node_wgrads_scatter(node_gsum, node_out, H, tid, stride);
     for (int i = tid; i < H * H; i += stride) {
         if (gr.edge_w2) gr.edge_w2[i] = gsum[L.w2 + i];
         if (has_coord && gr.coord_w1) gr.coord_w1[i] = gsum[L.wc1 + i];
@@ -581,6 +584,8 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     // g_h += g_P W1a + g_Q W1b: one launch with the two (input, weight) pairs
     PVS_TRY(pvs_launch_linear(s, g_h, H, w.gPQ, 2 * H, p->edge_w1, 1, m.ld1, nullptr, w.gPQ + H, 2 * H,
                               p->edge_w1 + m.off_q, 1, m.ld1, N, H, H, H, true));
+    const float* node_gsum = nullptr;
+    PvsNodeWgradOut node_out{};
     if (fused_wgrads) {
         PvsNodeWgradIn wi;
         wi.g_o = w.g_o; wi.g_y1 = g_y1; wi.gPQ = w.gPQ; wi.u = su; wi.h = h; wi.Magg = Magg;
@@ -588,7 +593,8 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
         wo.node_w2 = gr.node_w2; wo.node_w1 = gr.node_w1; wo.edge_w1 = gr.edge_w1;
         wo.node_b2 = gr.node_b2; wo.node_b1 = gr.node_b1; wo.edge_b1 = gr.edge_b1;
         wo.ld1 = m.ld1; wo.off_q = m.off_q; wo.perm = m.perm ? 1 : 0;
-        PVS_TRY(pvs_launch_node_wgrads(s, H, N, wi, wo, w.wslabs));
+        PVS_TRY(pvs_launch_node_wgrads(s, H, N, wi, wo, w.wslabs, /*scatter=*/false, &node_gsum));
+        node_out = wo;
     }
     if (gr.edge_w1 && !fused_wgrads) {
         PVS_TRY(pvs_launch_tsgemm_tn(s, gr.edge_w1, m.ld1, w.gPQ, 2 * H, h, H, N, H, H, w.dslabs,
@@ -599,9 +605,10 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     if (gr.edge_b1 && !fused_wgrads)
         PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.edge_b1, w.gPQ, 2 * H, nullptr, 0, nullptr,
                                      N, H, 1.f, w.dslabs, false));
-    k_finalize_edge_grads<<<4, 256, 0, s>>>(w.gsum, L, H, m.A, m.ld1, m.off_rho, gr,
+    k_finalize_edge_grads<<<H == 64 ? 16 : 4, 256, 0, s>>>(w.gsum, L, H, m.A, m.ld1, m.off_rho, gr,
                                             coord_bwd ? 1 : 0, eatt ? 1 : 0,
-                                            (eres && (F & (PVS_REZERO | PVS_GATED_RESIDUAL))) ? 1 : 0);
+                                            (eres && (F & (PVS_REZERO | PVS_GATED_RESIDUAL))) ? 1 : 0,
+                                            node_gsum, node_out);
     PVS_CHECK_LAUNCH();
     return 0;
 }
