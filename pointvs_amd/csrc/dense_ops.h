@@ -5,7 +5,13 @@
 // y[n*ldy + c] (=|+=) b[c] + sum_k x[n*ldx+k] * W[c*swc + k*swk] + sum_k2 x2[n*ldx2+k2] * W2[c*swc2 + k2*swk2]
 int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx, const float* W,
                       int swc, int swk, const float* b, const float* x2, int ldx2, const float* W2,
-                      int swc2, int swk2, int N, int K, int K2, int C, bool accumulate);
+                      int swc2, int swk2, int N, int K, int K2, int C, bool accumulate, int epi = 0,
+                      const float* aux_in = nullptr, int ld_in = 0, float* aux_out = nullptr, int ld_out = 0);
+// elementwise epilogue on the product (only on the MFMA path: check first):
+//   1: aux_out = SiLU(y)   2: aux_out = aux_in + y   3: y *= SiLU'(aux_in)   4: aux_out = y
+enum { PVS_EPI_NONE = 0, PVS_EPI_SILU_OUT = 1, PVS_EPI_ADD_OUT = 2, PVS_EPI_MUL_SILU_GRAD = 3, PVS_EPI_COPY_OUT = 4 };
+bool pvs_linear_epilogue_supported(int ldy, int ldx, int ldx2, int K, int K2, int C, const void* y,
+                                   const void* x, const void* x2);
 
 // number of float slabs a column reduction / tsgemm over N rows needs: slabs * width floats
 int pvs_reduce_blocks(int N);

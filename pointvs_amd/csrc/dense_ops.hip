@@ -231,7 +231,11 @@ __global__ void __launch_bounds__(kThreads)
 k_linear_mfma(float* __restrict__ y, int ldy, const float* __restrict__ x, int ldx, int kb1,
               const float* __restrict__ x2, int ldx2, const float* __restrict__ W, int swc, int swk,
               const float* __restrict__ W2, int swc2, int swk2, const float* __restrict__ b, int N,
-              int accumulate) {
+              int accumulate, int epi, const float* __restrict__ aux_in, int ld_in, float* __restrict__ aux_out,
+              int ld_out) {
+    // epi (elementwise epilogue on the accumulator, saves a pass over [N,C]):
+    //   1: aux_out = SiLU(y)          2: aux_out = aux_in + y          3: y *= SiLU'(aux_in)
+    //   4: aux_out = y
     constexpr int K = 32 * KB, C = 32 * CB, LD = K + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wn = smem;
@@ -282,9 +286,26 @@ k_linear_mfma(float* __restrict__ y, int ldy, const float* __restrict__ x, int l
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(dst + 32 * cb + 8 * g + 4 * hh) =
-                        make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
+                for (int g = 0; g < 4; ++g) {
+                    const int off = 32 * cb + 8 * g + 4 * hh;
+                    float4 r = make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
+                    if (epi == 3) {
+                        const float4 z = *reinterpret_cast<const float4*>(aux_in + (size_t)nn * ld_in + off);
+                        r.x *= pvs_silu_grad(z.x, pvs_sigmoid(z.x)); r.y *= pvs_silu_grad(z.y, pvs_sigmoid(z.y));
+                        r.z *= pvs_silu_grad(z.z, pvs_sigmoid(z.z)); r.w *= pvs_silu_grad(z.w, pvs_sigmoid(z.w));
+                    }
+                    *reinterpret_cast<float4*>(dst + off) = r;
+                    if (epi == 1) {
+                        *reinterpret_cast<float4*>(aux_out + (size_t)nn * ld_out + off) =
+                            make_float4(pvs_silu(r.x), pvs_silu(r.y), pvs_silu(r.z), pvs_silu(r.w));
+                    } else if (epi == 2) {
+                        const float4 a = *reinterpret_cast<const float4*>(aux_in + (size_t)nn * ld_in + off);
+                        *reinterpret_cast<float4*>(aux_out + (size_t)nn * ld_out + off) =
+                            make_float4(a.x + r.x, a.y + r.y, a.z + r.z, a.w + r.w);
+                    } else if (epi == 4) {
+                        *reinterpret_cast<float4*>(aux_out + (size_t)nn * ld_out + off) = r;
+                    }
+                }
         }
     }
 }
@@ -463,10 +484,20 @@ int pvs_reduce_blocks(int N) {
 
 static int rows_per_block_for(int N, int blocks) { return (N + blocks - 1) / blocks; }
 
+bool pvs_linear_epilogue_supported(int ldy, int ldx, int ldx2, int K, int K2, int C, const void* y,
+                                   const void* x, const void* x2) {
+    const int KK = K + K2;
+    const bool aligned16 = ((ldx | ldy | ldx2) & 3) == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)x2) & 15) == 0;
+    return aligned16 && K % 32 == 0 && K2 % 32 == 0 && C % 32 == 0 && C <= 64 && (KK == 32 || KK == 64 || KK == 128);
+}
+
 int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx, const float* W,
                       int swc, int swk, const float* b, const float* x2, int ldx2, const float* W2,
-                      int swc2, int swk2, int N, int K, int K2, int C, bool accumulate) {
+                      int swc2, int swk2, int N, int K, int K2, int C, bool accumulate, int epi,
+                      const float* aux_in, int ld_in, float* aux_out, int ld_out) {
     PVS_REQUIRE(C >= 1 && C <= kThreads, "linear: n_out %d unsupported (1..256)", C);
+    PVS_REQUIRE(epi == 0 || pvs_linear_epilogue_supported(ldy, ldx, x2 ? ldx2 : 0, K, K2, C, y, x, x2),
+                "linear: the epilogue needs the MFMA path");
     if (N <= 0) return 0;
     const int KK = K + K2;
     const bool aligned16 = ((ldx | ldy | (x2 ? ldx2 : 0)) & 3) == 0 &&
@@ -478,7 +509,8 @@ int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx,
         if (blocks_m > 1024) blocks_m = 1024;
 #define PVS_LIN(KBV, CBV)                                                                          \
     k_linear_mfma<KBV, CBV><<<blocks_m, kThreads, lds_m, s>>>(y, ldy, x, ldx, K / 32, x2, ldx2, W, swc, \
-                                                              swk, W2, swc2, swk2, b, N, accumulate ? 1 : 0)
+                                                              swk, W2, swc2, swk2, b, N, accumulate ? 1 : 0, \
+                                                              epi, aux_in, ld_in, aux_out, ld_out)
         if (kb == 1 && cb == 1) PVS_LIN(1, 1);
         else if (kb == 2 && cb == 1) PVS_LIN(2, 1);
         else if (kb == 4 && cb == 1) PVS_LIN(4, 1);

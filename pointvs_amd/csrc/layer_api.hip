@@ -219,18 +219,32 @@ __global__ void k_finalize_edge_grads(const float* __restrict__ gsum, PvsSlabLay
         if (_rc) return _rc;      \
     } while (0)
 
-// y1 = [h | Magg] Wn1^T + bn1 ; (graphnorm stats) ; u = SiLU(GN(y1)) ; o = u Wn2^T + bn2
+// y1 = [h | Magg] Wn1^T + bn1 ; (graphnorm stats) ; u = SiLU(GN(y1)) ; o = u Wn2^T + bn2 ; h_out
+// = node_out(o, h). Without GraphNorm the SiLU rides on the first product's epilogue, and the plain
+// (un-gated, no node attention) output stage on the second's: two launches instead of four.
 int node_mlp_forward(hipStream_t s, const Dims& m, const PvsLayerDesc* d, const PvsLayerParams* p,
                      const PvsNodeW& nw, const float* h, const float* Magg, float* y1, float* u,
-                     float* o, float* stats, bool compute_stats, float* shift_tmp, float* slabs) {
+                     float* o, float* stats, bool compute_stats, float* shift_tmp, float* slabs,
+                     float* h_out, float* node_att_out) {
     const int H = m.H;
+    const uint32_t F = d->flags;
+    const bool can_epi = pvs_linear_epilogue_supported(H, H, H, H, H, H, y1, h, Magg) &&
+                         pvs_linear_epilogue_supported(H, H, 0, H, 0, H, o, u, nullptr) &&
+                         (((uintptr_t)h_out | (uintptr_t)u) & 15) == 0;
+    const bool fuse_silu = can_epi && !(F & PVS_GRAPHNORM);
+    const bool gated = (F & PVS_RESIDUAL) && (F & (PVS_REZERO | PVS_GATED_RESIDUAL));
+    const bool fuse_out = can_epi && !(F & PVS_NODE_ATTENTION) && !gated;
     PVS_TRY(pvs_launch_linear(s, y1, H, h, H, p->node_w1, 2 * H, 1, p->node_b1, Magg, H,
-                              p->node_w1 + H, 2 * H, 1, m.N, H, H, H, false));
-    if ((d->flags & PVS_GRAPHNORM) && compute_stats)
+                              p->node_w1 + H, 2 * H, 1, m.N, H, H, H, false,
+                              fuse_silu ? PVS_EPI_SILU_OUT : PVS_EPI_NONE, nullptr, 0, u, H));
+    if ((F & PVS_GRAPHNORM) && compute_stats)
         PVS_TRY(pvs_graphnorm_stats(s, y1, p->gn_mean_scale, m.N, H, stats, shift_tmp, slabs));
-    PVS_TRY(pvs_node_tail_fwd(s, y1, stats, nw, m.N, H, u));
+    if (!fuse_silu) PVS_TRY(pvs_node_tail_fwd(s, y1, stats, nw, m.N, H, u));
     PVS_TRY(pvs_launch_linear(s, o, H, u, H, p->node_w2, H, 1, p->node_b2, nullptr, 0, nullptr, 0, 0,
-                              m.N, H, 0, H, false));
+                              m.N, H, 0, H, false,
+                              !fuse_out ? PVS_EPI_NONE : (F & PVS_RESIDUAL) ? PVS_EPI_ADD_OUT : PVS_EPI_COPY_OUT,
+                              h, H, h_out, H));
+    if (!fuse_out) PVS_TRY(pvs_node_out_fwd(s, H, o, h, nw, F, d->att_act, m.N, h_out, node_att_out));
     return 0;
 }
 
@@ -305,8 +319,8 @@ extern "C" int pvs_egnn_layer_fwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     if (!(d->flags & PVS_UPDATE_COORDS))
         PVS_CHECK_HIP(hipMemcpyAsync(x_out, x, sizeof(float) * 3 * (size_t)m.N,
                                      hipMemcpyDeviceToDevice, s));
-    PVS_TRY(node_mlp_forward(s, m, d, p, nw, h, Magg, sy1, so + (size_t)m.N * H, so, stats, true, w.shift, w.slabs));
-    PVS_TRY(pvs_node_out_fwd(s, H, so, h, nw, d->flags, d->att_act, m.N, h_out, node_att_out));
+    PVS_TRY(node_mlp_forward(s, m, d, p, nw, h, Magg, sy1, so + (size_t)m.N * H, so, stats, true, w.shift, w.slabs,
+                             h_out, node_att_out));
     return 0;
 }
 
@@ -408,8 +422,8 @@ extern "C" int pvs_egnn_layer_fwd_partial(const PvsLayerDesc* d, const PvsGraph*
                                                                    g->rowptr, m.N, H,
                                                                    (d->flags & PVS_UPDATE_COORDS) ? 1 : 0);
     PVS_CHECK_LAUNCH();
-    PVS_TRY(node_mlp_forward(s, m, d, p, nw, h, Magg, sy1, so + (size_t)m.N * H, so, stats, true, w.shift, w.slabs));
-    PVS_TRY(pvs_node_out_fwd(s, H, so, h, nw, d->flags, d->att_act, m.N, h_out, node_att_out));
+    PVS_TRY(node_mlp_forward(s, m, d, p, nw, h, Magg, sy1, so + (size_t)m.N * H, so, stats, true, w.shift, w.slabs,
+                             h_out, node_att_out));
     return 0;
 }
 
@@ -471,15 +485,19 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
         PVS_TRY(pvs_sum_vec(s, w.gvec, H, gr.node_gate));
     }
     // o = u Wn2^T + bn2
+    // (without GraphNorm g_y1 = g_u * SiLU'(y1) rides on this product's epilogue)
+    const bool fuse_tail_bwd = !gn && pvs_linear_epilogue_supported(H, H, 0, H, 0, H, w.g_u, w.g_o, nullptr) &&
+                               ((uintptr_t)sy1 & 15) == 0;
     PVS_TRY(pvs_launch_linear(s, w.g_u, H, w.g_o, H, p->node_w2, 1, H, nullptr, nullptr, 0, nullptr, 0,
-                              0, N, H, 0, H, false));
+                              0, N, H, 0, H, false, fuse_tail_bwd ? PVS_EPI_MUL_SILU_GRAD : PVS_EPI_NONE, sy1, H,
+                              nullptr, 0));
     if (gr.node_w2 && !fused_wgrads)
         PVS_TRY(pvs_launch_tsgemm_tn(s, gr.node_w2, H, w.g_o, H, su, H, N, H, H, w.dslabs, false));
     if (gr.node_b2 && !fused_wgrads)
         PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.node_b2, w.g_o, H, nullptr, 0, nullptr, N, H,
                                      1.f, w.dslabs, false));
     // u = SiLU(GN(y1)) ; g_u becomes g_yn then g_y1 in place
-    PVS_TRY(pvs_node_tail_bwd1(s, w.g_u, sy1, stats, nw, N, H, w.g_u));
+    if (!fuse_tail_bwd) PVS_TRY(pvs_node_tail_bwd1(s, w.g_u, sy1, stats, nw, N, H, w.g_u));
     if (gn) {
         PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, w.S1, w.g_u, H, nullptr, 0, nullptr, N, H, 1.f,
                                      w.dslabs, false));
