@@ -252,7 +252,6 @@ def main():
     # measured on MI355X: no gain (8.9 ms with and without; the sorts contend with the edge
     # kernels), so off by default
     prefetch = int(os.environ.get('PVS_BENCH_PREFETCH', '0')) and not use_graph
-    segs = (batch.graph_node_counts, batch.graph_edge_counts)
 
     def infer_step():
         with torch.no_grad():
@@ -269,7 +268,7 @@ def main():
         y_pred = model(batch).reshape(-1)
         if prefetch:   # the next batch's CSR/CSC build (here: the same tensors) runs on a side
             # stream under this batch's backward, as a data loader's look-ahead would arrange it
-            pgraph.prefetch_graph(batch.edge_index, batch.edge_attr, n_nodes, segs)
+            pgraph.prefetch_graph(batch.edge_index, batch.edge_attr, n_nodes)
         loss = model.get_loss(y_true, y_pred)
         model.optimiser.zero_grad()
         loss.backward()

@@ -69,14 +69,6 @@ typedef struct PvsGraph {
     const int32_t* colptr;   /* [N+1] CSC offsets by col                                        */
     const int32_t* cedge;    /* [E]   sorted positions of the edges grouped by col (stable)     */
     const float*   inv_deg;  /* [N]   1 / max(deg_row, 1)  (unsorted_segment_mean's clamp)      */
-    /* Optional HOST arrays (may be NULL / 0): the batch cut into n_segments groups of whole graphs
-     * (no edge crosses a segment: PyG collation). seg_node_ptr[s] = first node, seg_edge_ptr[s] =
-     * first CSR-sorted edge of segment s. Lets the backward pipeline segment s's column gather
-     * (HBM-bound, side stream) under segment s+1's edge kernel (ALU-bound) and keeps the per-edge
-     * gradient buffer of a segment inside the 256 MB Infinity Cache between the two. */
-    int32_t n_segments;
-    const int32_t* seg_node_ptr;  /* HOST [n_segments+1] */
-    const int32_t* seg_edge_ptr;  /* HOST [n_segments+1] */
     /* Optional DEVICE int32: the true edge count when it is only known on the device (a graph made
      * by pvs_graph_filter_ligand_edges); n_edges is then the capacity of the edge arrays. Only
      * pvs_egnn_layer_edge_sums / _fwd_partial accept such a graph. */

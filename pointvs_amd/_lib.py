@@ -27,9 +27,7 @@ class PvsGraph(C.Structure):
     _fields_ = [('n_nodes', C.c_int32), ('n_edges', C.c_int32), ('rowptr', C.c_void_p),
                 ('row', C.c_void_p), ('col', C.c_void_p), ('etype', C.c_void_p),
                 ('perm', C.c_void_p), ('colptr', C.c_void_p), ('cedge', C.c_void_p),
-                ('inv_deg', C.c_void_p), ('n_segments', C.c_int32),
-                ('seg_node_ptr', C.POINTER(C.c_int32)), ('seg_edge_ptr', C.POINTER(C.c_int32)),
-                ('n_edges_dev', C.c_void_p)]
+                ('inv_deg', C.c_void_p), ('n_edges_dev', C.c_void_p)]
 
 
 class PvsLayerParams(C.Structure):

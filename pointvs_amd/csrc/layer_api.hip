@@ -22,44 +22,12 @@ static uint32_t pvs_ablate_bits() {
     return v ? (uint32_t)strtoul(v, nullptr, 16) << 24 : 0u;
 }
 
-// Side stream + events for the segment pipeline of the backward (created once per device, before
-// any graph capture that wants to include it: run one eager step first).
-constexpr int kMaxStages = 16;
-struct PvsPipe {
-    hipStream_t side = nullptr;
-    hipEvent_t stage[kMaxStages] = {};
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-static PvsPipe* pvs_get_pipe() {
-    static PvsPipe pipes[16];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    PvsPipe* p = &pipes[dev];
-    if (!p->side) {
-        if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        for (int i = 0; i < kMaxStages; ++i)
-            if (hipEventCreateWithFlags(&p->stage[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&p->join, hipEventDisableTiming) != hipSuccess) return nullptr;
-    }
-    return p;
-}
-// Off by default: measured on MI355X/ROCm 7.2 the eager event record + cross-stream wait per stage
-// costs ~0.2 ms of host time, more than the overlap wins (cfg2: 9.8 ms/step without, 12.4 with 4
-// stages, 15.2 with 8). PVS_EGNN_PIPELINE=1 enables it (meant for a hipGraph-captured step, where
-// the dependencies are resolved on the device).
-static bool pvs_use_pipeline() {
-    const char* v = getenv("PVS_EGNN_PIPELINE");
-    return v && v[0] == '1';
-}
-
 namespace {
 
 static size_t edge_slab_capacity(int H, int E) {
-    const size_t by_edges = (size_t)E / 4096 + kMaxStages + 1;
-    const size_t by_stages = (size_t)kMaxStages * pvs_edge_bwd_mfma_max_blocks(H);
-    const size_t cap = by_edges < by_stages ? by_edges : by_stages;
-    return cap < 512 ? 512 : cap;
+    (void)E;
+    const size_t cap = (size_t)pvs_edge_bwd_mfma_max_blocks(H);
+    return cap < 512 ? 512 : cap;     // one slab per workgroup of the edge backward
 }
 
 struct Dims {
@@ -176,7 +144,7 @@ size_t carve_bwd(PvsArena& a, const Dims& m, BwdWs* w) {
     t.S2 = a.take<float>(m.H);
     t.coefs = a.take<float>(3 * (size_t)m.H);
     t.gvec = a.take<float>(m.H);
-    t.nslabs = a.take<float>((size_t)kMaxStages * 512 * 4 * m.H);
+    t.nslabs = a.take<float>((size_t)2048 * 4 * m.H);      // one [4H] slab per workgroup of the column gather
     t.nsum = a.take<float>(4 * (size_t)m.H);
     t.wslabs = a.take<float>(pvs_node_wgrads_supported(m.H) ? pvs_node_wgrads_slab_floats(m.N, m.H) : 4);
     if (w) *w = t;
@@ -539,51 +507,9 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     int n_nslabs = 0;
     if (mfma_bwd) {
         const uint32_t Fk = F | pvs_ablate_bits();
-        PvsPipe* pipe = nullptr;
-        int n_stage = 1;
-        if (g->n_segments >= 2 && g->seg_node_ptr && g->seg_edge_ptr && pvs_use_pipeline()) {
-            pipe = pvs_get_pipe();
-            if (pipe) {
-                const char* sv = getenv("PVS_EGNN_STAGES");
-                int want = sv ? atoi(sv) : 8;
-                if (want < 1) want = 1;
-                if (want > kMaxStages) want = kMaxStages;
-                n_stage = g->n_segments < want ? g->n_segments : want;
-            }
-        }
-        if (!pipe) {
-            PVS_TRY(pvs_launch_edge_bwd_mfma(s, H, *g, ew, Fk, d->att_act, io, 0, m.E, &n_slabs));
-            PVS_TRY(pvs_launch_node_gather(s, H, *g, true, w.gz1, w.gd, w.gx_row, g_x_out, w.gPQ, g_x,
-                                           w.nslabs, 0, N, &n_nslabs));
-        } else {
-            // Segment pipeline: segment k's column gather (HBM-bound) runs on the side stream under
-            // segment k+1's edge kernel (ALU-bound); a segment's gz1 stays in the Infinity Cache.
-            const size_t cap = edge_slab_capacity(H, m.E);
-            PVS_CHECK_HIP(hipEventRecord(pipe->fork, s));
-            PVS_CHECK_HIP(hipStreamWaitEvent(pipe->side, pipe->fork, 0));
-            for (int k = 0; k < n_stage; ++k) {
-                // stage k = segments [k*S/n, (k+1)*S/n)
-                const int s0 = (int)((long long)k * g->n_segments / n_stage);
-                const int s1 = (int)((long long)(k + 1) * g->n_segments / n_stage);
-                const int n_lo = g->seg_node_ptr[s0], n_hi = g->seg_node_ptr[s1];
-                const int e_lo = g->seg_edge_ptr[s0], e_hi = g->seg_edge_ptr[s1];
-                PvsEdgeBwdIO iok = io;
-                iok.slabs = w.eslabs + (size_t)n_slabs * L.total;
-                int got = 0;
-                PVS_TRY(pvs_launch_edge_bwd_mfma(s, H, *g, ew, Fk, d->att_act, iok, e_lo, e_hi, &got));
-                n_slabs += got;
-                PVS_REQUIRE((size_t)n_slabs <= cap, "edge slab capacity exceeded (%d > %zu)", n_slabs, cap);
-                PVS_CHECK_HIP(hipEventRecord(pipe->stage[k], s));
-                PVS_CHECK_HIP(hipStreamWaitEvent(pipe->side, pipe->stage[k], 0));
-                int gotn = 0;
-                PVS_TRY(pvs_launch_node_gather(pipe->side, H, *g, true, w.gz1, w.gd, w.gx_row, g_x_out,
-                                               w.gPQ, g_x, w.nslabs + (size_t)n_nslabs * 4 * H, n_lo, n_hi,
-                                               &gotn));
-                n_nslabs += gotn;
-            }
-            PVS_CHECK_HIP(hipEventRecord(pipe->join, pipe->side));
-            PVS_CHECK_HIP(hipStreamWaitEvent(s, pipe->join, 0));
-        }
+        PVS_TRY(pvs_launch_edge_bwd_mfma(s, H, *g, ew, Fk, d->att_act, io, 0, m.E, &n_slabs));
+        PVS_TRY(pvs_launch_node_gather(s, H, *g, true, w.gz1, w.gd, w.gx_row, g_x_out, w.gPQ, g_x,
+                                       w.nslabs, 0, N, &n_nslabs));
     } else {
         PVS_TRY(pvs_launch_edge_bwd_v0(s, H, *g, ew, F, d->att_act, io, &n_slabs));
         PVS_TRY(pvs_launch_node_gather(s, H, *g, false, w.gz1, w.gd, w.gx_row, g_x_out, w.gPQ, g_x,

@@ -56,8 +56,8 @@ class Batch(Data):
         merged['batch'] = torch.cat(batch_vec)
         merged['ptr'] = torch.tensor(ptr, dtype=torch.long)
         merged['num_graphs'] = len(items)
-        # host-side per-graph sizes (plain lists survive .to(device)): let the backward pipeline
-        # whole-graph segments without a device->host sync
+        # host-side per-graph sizes (plain lists survive .to(device)): sizes without a device->host sync
+        # (radius_graph's mask buffers, the screening batcher)
         merged['graph_node_counts'] = [int(item.x.size(0)) for item in items]
         merged['graph_edge_counts'] = [int(item.edge_index.size(1)) for item in items]
         return Batch(**merged)
@@ -66,26 +66,13 @@ class Batch(Data):
 class PreparedGraph:
     """Device-resident CSR (by row = edge_index[0]) + CSC (by col) of one batch."""
 
-    def __init__(self, n_nodes, n_edges, n_edge_attr, tensors, segments=None):
+    def __init__(self, n_nodes, n_edges, n_edge_attr, tensors):
         self.n_nodes, self.n_edges, self.n_edge_attr = n_nodes, n_edges, n_edge_attr
         self.t = tensors  # keeps the storage alive for the struct's raw pointers
         g = _lib.PvsGraph()
         g.n_nodes, g.n_edges = n_nodes, n_edges
         for name in ('rowptr', 'row', 'col', 'etype', 'perm', 'colptr', 'cedge', 'inv_deg'):
             setattr(g, name, _lib.ptr(tensors.get(name)))
-        self._seg_arrays = None
-        if segments is not None:
-            node_counts, edge_counts = segments
-            if (len(node_counts) >= 2 and sum(node_counts) == n_nodes
-                    and sum(edge_counts) == n_edges):
-                n_seg = len(node_counts)
-                node_ptr = (C.c_int32 * (n_seg + 1))()
-                edge_ptr = (C.c_int32 * (n_seg + 1))()
-                for i in range(n_seg):
-                    node_ptr[i + 1] = node_ptr[i] + int(node_counts[i])
-                    edge_ptr[i + 1] = edge_ptr[i] + int(edge_counts[i])
-                self._seg_arrays = (node_ptr, edge_ptr)
-                g.n_segments, g.seg_node_ptr, g.seg_edge_ptr = n_seg, node_ptr, edge_ptr
         self.c = g
         self._status_checked = False
         self._status_host = None
@@ -128,9 +115,8 @@ class PreparedGraph:
 _PENDING = []
 
 
-def prepare_graph(edge_index, edge_attr, n_nodes, segments=None, need_backward=None):
+def prepare_graph(edge_index, edge_attr, n_nodes, need_backward=None):
     """int64 COO `[2,E]` (+ int64 one-hot `[E,A]` or None) -> PreparedGraph on the same device.
-    segments: optional (node_counts, edge_counts) per whole graph, host lists (see PvsGraph).
     need_backward=False (default: torch.is_grad_enabled()) skips the by-column lists that only the
     backward reads."""
     if need_backward is None:
@@ -172,7 +158,7 @@ def prepare_graph(edge_index, edge_attr, n_nodes, segments=None, need_backward=N
         _lib.ptr(t['perm']), _lib.ptr(t.get('colptr')), _lib.ptr(t.get('cedge')), _lib.ptr(t['inv_deg']),
         _lib.ptr(t['status']), _lib.ptr(ws), ws_bytes, stream)
     _lib.check(rc, 'pvs_graph_prepare')
-    return PreparedGraph(n_nodes, n_edges, n_attr, t, segments)
+    return PreparedGraph(n_nodes, n_edges, n_attr, t)
 
 
 _PREFETCH = {}
@@ -184,7 +170,7 @@ def _graph_key(edge_index, edge_attr, n_nodes):
             None if edge_attr is None else (edge_attr.data_ptr(), edge_attr._version), n_nodes)
 
 
-def prefetch_graph(edge_index, edge_attr, n_nodes, segments=None):
+def prefetch_graph(edge_index, edge_attr, n_nodes):
     """Start `prepare_graph` for an upcoming batch on a side stream (e.g. while the current batch
     is in its backward pass: the sorts are memory/latency-bound, the edge kernels ALU-bound). The
     next `prepared_for` call with the same tensors picks the result up and orders the consumer
@@ -195,7 +181,7 @@ def prefetch_graph(edge_index, edge_attr, n_nodes, segments=None):
         side = _PREFETCH_STREAM[dev] = torch.cuda.Stream(dev)
     side.wait_stream(torch.cuda.current_stream(dev))   # inputs may have been produced just now
     with torch.cuda.stream(side):
-        pg = prepare_graph(edge_index, edge_attr, n_nodes, segments, need_backward=True)
+        pg = prepare_graph(edge_index, edge_attr, n_nodes, need_backward=True)
         done = torch.cuda.Event()
         done.record(side)
     _PREFETCH[dev] = (_graph_key(edge_index, edge_attr, n_nodes), pg, done, edge_index, edge_attr)
@@ -219,13 +205,13 @@ _CACHE_SIZE = 4
 CACHE_ENABLED = True   # bench.py turns this off: a training step prepares every batch afresh
 
 
-def prepared_for(edge_index, edge_attr, n_nodes, segments=None):
+def prepared_for(edge_index, edge_attr, n_nodes):
     """Cached `prepare_graph`: the L layers of a forward are called with the same edge tensors."""
     pre = _take_prefetched(edge_index, edge_attr, n_nodes)
     if pre is not None:
         return pre
     if not CACHE_ENABLED:
-        return prepare_graph(edge_index, edge_attr, n_nodes, segments)
+        return prepare_graph(edge_index, edge_attr, n_nodes)
     key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
            None if edge_attr is None else (edge_attr.data_ptr(), edge_attr._version), n_nodes,
            torch.is_grad_enabled())      # a forward-only graph has no by-column lists
@@ -233,7 +219,7 @@ def prepared_for(edge_index, edge_attr, n_nodes, segments=None):
     if hit is not None:
         _CACHE.move_to_end(key)
         return hit[0]
-    pg = prepare_graph(edge_index, edge_attr, n_nodes, segments)
+    pg = prepare_graph(edge_index, edge_attr, n_nodes)
     _CACHE[key] = (pg, edge_index, edge_attr)  # hold the inputs so data_ptr keys stay unique
     while len(_CACHE) > _CACHE_SIZE:
         _CACHE.popitem(last=False)

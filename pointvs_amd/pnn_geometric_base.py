@@ -42,12 +42,9 @@ class PNNGeometricBase(PointNeuralNetworkBase):
             counts = torch.bincount(batch, minlength=n_graphs)
             ptr = torch.cat([counts.new_zeros(1), counts.cumsum(0)])
         graph_ptr = ptr.to(device=feats.device, dtype=torch.int32).contiguous()
-        segments = None
-        if hasattr(graph, 'graph_node_counts') and hasattr(graph, 'graph_edge_counts'):
-            segments = (graph.graph_node_counts, graph.graph_edge_counts)
         pg = getattr(graph, 'prepared', None)     # built on the GPU (radius_graph.attach_radius_graph)
         if pg is None:
-            pg = prepared_for(edges, edge_attributes, n_nodes, segments)
+            pg = prepared_for(edges, edge_attributes, n_nodes)
         pg.poll_status()
         feats, _, _ = self.embed_prepared(pg, feats, coords, need_coords=False)
         return feats, pg, graph_ptr, n_graphs
