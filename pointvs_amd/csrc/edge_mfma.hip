@@ -132,20 +132,17 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
             acc = make_float4(0.f, 0.f, 0.f, 0.f);
             accx = acc;
         };
-        // software pipeline: tile t+1's indices are loaded at the top of tile t, its node rows
-        // are gathered before tile t's weight-gradient / reduction phase
+        // tile t+1's indices are loaded at the top of tile t; its node rows are gathered at its own
+        // start (register prefetch of the rows measured slower: occupancy)
         TileIdx I = load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_begin, e_begin, e_end, j);
         TileGather<HB> G;
-        if (e_begin < e_end) gather_tile<HB>(io.PQ, io.x, I, hh, G);
         for (int e0 = e_begin; e0 < e_end; e0 += kTile) {
             const int e_next = (e0 + kTile < e_end) ? e0 + kTile : e0;
             const TileIdx In = load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_next, e_begin, e_end, j);
             const int e = I.e, ee = I.ee, i = I.i, ty = I.ty;
             const bool valid = I.valid;
             const float vm = valid ? 1.f : 0.f;
-#if !PVS_PREFETCH
             gather_tile<HB>(io.PQ, io.x, I, hh, G);
-#endif
             const unsigned bmask = (unsigned)__ballot(valid && hh == 0 && i != I.prev_row);
             const float d0 = G.d0, d1 = G.d1, d2 = G.d2;
             const float rho = d0 * d0 + d1 * d1 + d2 * d2;
@@ -401,9 +398,6 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                         for (int r = 0; r < 16; ++r)
                             g_z1[b][r] = ga1[b][r] * pvs_silu_grad(g_z1[b][r], pvs_sigmoid(g_z1[b][r]));
                 }
-#if PVS_PREFETCH
-                gather_tile<HB>(io.PQ, io.x, In, hh, G);   // next tile, lands during the reductions
-#endif
                 const float g_rho = dot_tab<HB>(wrhot, hh, g_z1);
                 const float k1 = s_coord * nrm * vm;
                 const float gd0 = fmaf(k1, gT0, 2.f * d0 * g_rho);

@@ -14,10 +14,6 @@ constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 constexpr int kTile = 32;
 
-#ifndef PVS_PREFETCH
-#define PVS_PREFETCH 0   // gather tile t+1's node rows while tile t is reduced (0: gather at tile start)
-#endif
-
 // Timing-only ablation switches (PVS_ABLATE env, tools/ablate.py): results are wrong when set.
 // internal: the forward writes the raw coordinate sums (no x, no 1/deg) into x_out (edge_sums)
 constexpr uint32_t kFwdRawXsum = 1u << 23;

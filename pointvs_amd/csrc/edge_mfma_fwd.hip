@@ -110,10 +110,9 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
             accx = acc;
         };
 
-        // software pipeline: the gathers of tile t+1 are issued while tile t is being reduced
+        // tile t+1's indices are loaded at the top of tile t (its node rows at its own start)
         TileIdx I = load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_begin, e_begin, e_end, j);
         TileGather<HB> G;
-        if (e_begin < e_end) gather_tile<HB>(io.PQ, io.x, I, hh, G);
         for (int e0 = e_begin; e0 < e_end; e0 += kTile) {
             const int e_next = (e0 + kTile < e_end) ? e0 + kTile : e0;
             const TileIdx In = load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_next, e_begin, e_end, j);
@@ -121,9 +120,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
             const bool valid = I.valid;
             const unsigned long long ball = __ballot(valid && hh == 0 && i != I.prev_row);
             const unsigned bmask = (unsigned)ball;
-#if !PVS_PREFETCH
             gather_tile<HB>(io.PQ, io.x, I, hh, G);
-#endif
             const float d0 = G.d0, d1 = G.d1, d2 = G.d2;
             const float rho = d0 * d0 + d1 * d1 + d2 * d2;
 
@@ -217,9 +214,6 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                 *reinterpret_cast<float4*>(tx + j * 4) = make_float4(d0 * sv, d1 * sv, d2 * sv, 0.f);
                 rowbuf[j] = i;
             }
-#if PVS_PREFETCH
-            gather_tile<HB>(io.PQ, io.x, In, hh, G);   // next tile's rows fly during the reduction
-#endif
             I = In;
             pvs_wave_lds_sync();
             if (!(flags & kAblNoReduce))
