@@ -524,3 +524,18 @@ def test_last_layer_coordinates_are_available_on_demand():
     assert torch.equal(y_skip, y_full)
     assert np.array_equal(lazy, trace['x3'].cpu().numpy())
     assert not np.array_equal(lazy, trace['x2'].cpu().numpy())
+
+
+def test_backward_on_a_forward_only_graph_fails_loudly():
+    """A graph prepared without the by-column lists (forward-only) must make the backward raise, not
+    read NULL pointers."""
+    from pointvs_amd.egnn_satorras import EGNNLayer
+    from pointvs_amd.graph import prepare_graph
+    torch.manual_seed(0)
+    layer = EGNNLayer(32, 32, 32, edges_in_d=3).cuda()
+    g = random_graph(60, 700, seed=1).to('cuda')
+    pg = prepare_graph(g.edge_index, g.edge_attr, 60, need_backward=False)
+    h = torch.randn(60, 32, device='cuda', requires_grad=True)
+    h_out, _, _ = layer.forward_prepared(pg, h, g.pos)
+    with pytest.raises(RuntimeError, match='by-column'):
+        h_out.sum().backward()
