@@ -621,11 +621,11 @@ __device__ __forceinline__ void load16_tab(const float* __restrict__ tab, int hh
     }
 }
 
-template <int HB, bool ERES, bool EATT, bool BF16X3 = false>
-__global__ void __launch_bounds__(512, 2)
+template <int HB, bool ERES, bool EATT, bool BF16X3 = false, int NT = 64 * HB>
+__global__ void __launch_bounds__(NT, 1)
 k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks,
                 int e_lo, int e_hi) {
-    constexpr int H = 32 * HB, TS = H + 4, NT = 512, NW = NT / 64, TEAMS = NW / HB;
+    constexpr int H = 32 * HB, TS = H + 4, NW = NT / 64, TEAMS = NW / HB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // fp32: natural padded weights [H][H+1] serving W and W^T; BF16X3: one swizzled bf16 image per
     // part (3 x H*H x 2 B per matrix), also serving both
@@ -732,38 +732,65 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
             accx = acc;
         };
 
+        // software pipeline over the tiles of the chunk: the indices of tile it+2 and the gathered rows
+        // of tile it+1 are in flight while tile it is processed (one wave per SIMD: nothing else hides
+        // the two dependent gather latencies)
+        struct Idx { int ee, i, jn, ty, prev; };
+        auto idx_of = [&](int itx) {
+            Idx o;
+            const int e = e_begin + itx * kTile + j;
+            int ee = e < e_end ? e : e_end - 1;
+            ee = min(max(ee, 0), g.n_edges - 1);
+            o.ee = ee;
+            o.i = g.row[ee];
+            o.jn = g.col[ee];
+            o.ty = w.n_attr ? (int)g.etype[ee] : 0;
+            o.prev = (ee == e_begin || ee == 0) ? -1 : g.row[ee - 1];
+            return o;
+        };
+        float pp[16], qq[16], xi[3], xj[3];
+        auto rows_of = [&](const Idx& t) {
+            load16_tab(io.PQ + (size_t)t.i * 2 * H + co, hh, pp);
+            load16_tab(io.PQ + (size_t)t.jn * 2 * H + H + co, hh, qq);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { xi[c] = io.x[3 * t.i + c]; xj[c] = io.x[3 * t.jn + c]; }
+        };
+        Idx cur = idx_of(0), nxt = cur;
+        if (n_iter > 0) {
+            rows_of(cur);
+            nxt = idx_of(1);
+        }
+
         for (int it = 0; it < n_iter; ++it) {
             const int e0 = e_begin + it * kTile;
             const int e = e0 + j;
             const bool valid = e < e_end;
             const float vm = valid ? 1.f : 0.f;
-            int ee = valid ? e : e_end - 1;
-            ee = min(max(ee, 0), g.n_edges - 1);
-            const int i = g.row[ee], jn = g.col[ee];
-            const int ty = w.n_attr ? (int)g.etype[ee] : 0;
-            const int prev_row = (ee == e_begin || ee == 0) ? -1 : g.row[ee - 1];
-            const unsigned bmask = (unsigned)__ballot(valid && hh == 0 && i != prev_row);
-            const float d0 = io.x[3 * i] - io.x[3 * jn], d1 = io.x[3 * i + 1] - io.x[3 * jn + 1];
-            const float d2 = io.x[3 * i + 2] - io.x[3 * jn + 2];
+            const int ee = cur.ee, i = cur.i, jn = cur.jn, ty = cur.ty;
+            const unsigned bmask = (unsigned)__ballot(valid && hh == 0 && i != cur.prev);
+            const float d0 = xi[0] - xj[0], d1 = xi[1] - xj[1], d2 = xi[2] - xj[2];
             const float rho = d0 * d0 + d1 * d1 + d2 * d2;
-            const float* Pp = io.PQ + (size_t)i * 2 * H + co;
-            const float* Qp = io.PQ + (size_t)jn * 2 * H + H + co;
 
-            auto z1_own = [&](float (&z)[16]) {
-                float pp[16], qq[16], aa[16], rr[16];
-                load16_tab(Pp, hh, pp);
-                load16_tab(Qp, hh, qq);
+            // ---- recompute: a1 (own block) -> T0 ----
+            float a1[16], sd1[16];     // a1 = SiLU(z1), sd1 = SiLU'(z1) (kept in registers)
+            {
+                float aa[16], rr[16];
                 load16_tab(attrt + ty * H + co, hh, aa);
                 load16_tab(wrhot + co, hh, rr);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) z[r] = pp[r] + qq[r] + fmaf(rr[r], rho, aa[r]);
-            };
-
-            // ---- recompute: a1 (own block) -> T0 ----
-            float a1[16];
-            z1_own(a1);
+                for (int r = 0; r < 16; ++r) a1[r] = pp[r] + qq[r] + fmaf(rr[r], rho, aa[r]);
+            }
+            // rows of this tile that are needed later (issued before the prefetch: loads return in order)
+            float gMi[16];
+            load16_tab(io.gM + (size_t)i * H + co, hh, gMi);
+            rows_of(nxt);
+            const Idx nn = idx_of(it + 2);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a1[r] = pvs_silu(a1[r]);
+            for (int r = 0; r < 16; ++r) {
+                const float sg = pvs_sigmoid(a1[r]);
+                sd1[r] = pvs_silu_grad(a1[r], sg);
+                a1[r] *= sg;
+            }
             xwrite_block<HB>(T0, j, hh, cb, a1);
             if (cb == 0 && hh == 0) rowbuf[j] = i;
             __syncthreads();                                                     // (1) T0 complete
@@ -805,8 +832,6 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gm[r] = io.g_m_out ? init[r] * vm : 0.f;
             }
-            float gMi[16];
-            load16_tab(io.gM + (size_t)i * H + co, hh, gMi);
             if constexpr (EATT) {
                 float pl = dot16_tab(wat + co, hh, m);
                 float pdot = 0.f;
@@ -930,10 +955,8 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
             if constexpr (BF16X3) chain_team_b3<HB, true>(W2i, lane, cb, g_z2, T2, ga1);
             else chain_team<HB, true>(W2n, lane, cb, g_z2, T2, ga1);
             float g_z1[16];
-            z1_own(g_z1);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                g_z1[r] = ga1[r] * pvs_silu_grad(g_z1[r], pvs_sigmoid(g_z1[r]));
+            for (int r = 0; r < 16; ++r) g_z1[r] = ga1[r] * sd1[r];
             const float prho = dot16_tab(wrhot + co, hh, g_z1);
             if (hh == 0) pdA[cb * kTile + j] = prho;
             // ---- W2 weight gradient (row block cb) + g_b2 ----
@@ -991,6 +1014,8 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 }
             }
             __syncthreads();                                                     // (9) tile buffers free
+            cur = nxt;
+            nxt = nn;
         }
         flush(cur_row);
     }
@@ -1046,7 +1071,7 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
 
 }  // namespace
 
-int pvs_edge_bwd_mfma_max_blocks(int H) { return H == 32 ? 512 : 256; }
+int pvs_edge_bwd_mfma_max_blocks(int H) { (void)H; return 512; }
 
 // Edge backward over the CSR edge range [e_lo, e_hi) (row-aligned: the whole batch or one segment
 // of whole graphs). gPQ's row part and gx_row must have been zeroed by the caller (rows without
@@ -1105,12 +1130,13 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     else if (H == 32) PVS_BWD_PICK(1, false);
     else if (!use_team) PVS_BWD_PICK(2, false);
     else {
-        // team kernel: 512 threads = 4 teams of 2 waves, one block per CU
-        constexpr int kTeams = 4;
+        // team kernel: one team of 2 waves per 128-thread block, two blocks per CU: one wave per SIMD
+        // with the whole register file (the 4-team 512-thread block spilled at 256 registers)
+        constexpr int kTeams = 1;
         const int E = e_hi - e_lo;
-        long long b = ((long long)E + (long long)kTeams * 2048 - 1) / ((long long)kTeams * 2048);
+        long long b = ((long long)E + 2047) / 2048;
         if (b < 1) b = 1;
-        if (b > 256) b = 256;
+        if (b > 512) b = 512;
         const long long teams = b * kTeams;
         long long per_team = ((long long)E + teams * 4096 - 1) / (teams * 4096);
         if (per_team < 1) per_team = 1;
@@ -1126,7 +1152,7 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
 #define PVS_TEAM_LAUNCH(ER, EA, B3)                                                                \
     do {                                                                                          \
         if (set_lds(k_edge_bwd_team<2, ER, EA, B3>, tlds)) return -2;                             \
-        k_edge_bwd_team<2, ER, EA, B3><<<blocks, 512, tlds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi); \
+        k_edge_bwd_team<2, ER, EA, B3><<<blocks, 128, tlds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi); \
     } while (0)
 #define PVS_TEAM_PICK(B3)                                     \
     do {                                                      \

@@ -1,5 +1,5 @@
 """A/B of library builds in ONE process tree on ONE device (interleaved rounds).
-Usage: python tools/ab.py name1=path1.so name2=path2.so [--rounds 3]"""
+Usage: [AB_ROUNDS=3] [AB_ARGS="--config cfg3"] python tools/ab.py name1=path1.so name2=path2.so"""
 import json
 import os
 import subprocess
@@ -14,7 +14,7 @@ for r in range(rounds):
     for name, path in libs:
         e = dict(os.environ, PVS_EGNN_LIB=str(Path(path).resolve()))
         out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--steps', '4', '--warmup', '2',
-                              '--no-cpu-baseline'], env=e, capture_output=True, text=True)
+                              '--no-cpu-baseline'] + os.environ.get('AB_ARGS', '').split(), env=e, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith('{')]
         if not line:
             print(name, 'FAILED', out.stderr[-400:])
