@@ -1090,7 +1090,7 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     {
         const int E = e_hi - e_lo;
         const int max_blocks = bf16x3 ? 256 : pvs_edge_bwd_mfma_max_blocks(H);
-        long long b = ((long long)E + (long long)nw * 2048 - 1) / ((long long)nw * 2048);
+        long long b = ((long long)E + (long long)nw * 512 - 1) / ((long long)nw * 512);   // fill the chip first
         if (b < 1) b = 1;
         if (b > max_blocks) b = max_blocks;
         const long long waves = b * nw;
@@ -1134,7 +1134,7 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
         // with the whole register file (the 4-team 512-thread block spilled at 256 registers)
         constexpr int kTeams = 1;
         const int E = e_hi - e_lo;
-        long long b = ((long long)E + 2047) / 2048;
+        long long b = ((long long)E + 511) / 512;
         if (b < 1) b = 1;
         if (b > 512) b = 512;
         const long long teams = b * kTeams;

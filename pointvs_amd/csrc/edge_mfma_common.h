@@ -463,13 +463,13 @@ int set_lds(K kernel, size_t lds) {
     return 0;
 }
 
-void pick_grid(int E, int* blocks, int* n_chunks, int max_blocks = 1024) {
-    // a wave gets >= ~2048 edges where the range allows; chunks of <= ~4096 edges; every wave gets
-    // the same number of chunks
-    long long b = ((long long)E + 4 * 2048 - 1) / (4 * 2048);
+void pick_grid(int E, int* blocks, int* n_chunks, int nw = kWaves, int max_blocks = 1024) {
+    // fill the chip first: a wave gets >= ~512 edges (16 tiles amortise the weight staging of its
+    // block) where the range allows; chunks of <= ~4096 edges; every wave gets the same number of chunks
+    long long b = ((long long)E + (long long)nw * 512 - 1) / ((long long)nw * 512);
     if (b < 1) b = 1;
     if (b > max_blocks) b = max_blocks;
-    const long long waves = b * kWaves;
+    const long long waves = b * nw;
     long long per_wave = ((long long)E + waves * 4096 - 1) / (waves * 4096);
     if (per_wave < 1) per_wave = 1;
     *blocks = (int)b;

@@ -260,24 +260,16 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
         PVS_CHECK_LAUNCH();
     }
     if (g.n_edges == 0) return 0;
-    int blocks, n_chunks;
-    pick_grid(g.n_edges, &blocks, &n_chunks);
     PvsProfScope prof(s, PVS_PROF_EDGE_FWD);
     const int HB = H / 32;
     const char* bf = getenv("PVS_EGNN_BF16X3");
     const char* bf64 = getenv("PVS_EGNN_BF16X3_H64");
     // default: fp32 products as bf16x3 (PVS_EGNN_BF16X3=0: fp32 MFMAs; PVS_EGNN_BF16X3_H64=0: only for H = 64)
     const bool bf16x3 = !(bf && bf[0] == '0') && (H == 32 || !(bf64 && bf64[0] == '0'));
-    // H = 64 bf16x3: 48 KB of weight operands, so one 512-thread workgroup per CU (8 waves, as before)
+    // H = 64 bf16x3: 48 KB of weight operands, so one 512-thread workgroup per CU (8 waves)
     const int nw = (HB == 2 && bf16x3) ? 8 : kWaves;
-    if (nw != kWaves) {
-        blocks = (blocks + 1) / 2;
-        if (blocks > 256) blocks = 256;
-        const long long waves = (long long)blocks * nw;
-        long long per_wave = ((long long)g.n_edges + waves * 4096 - 1) / (waves * 4096);
-        if (per_wave < 1) per_wave = 1;
-        n_chunks = (int)(waves * per_wave);
-    }
+    int blocks, n_chunks;
+    pick_grid(g.n_edges, &blocks, &n_chunks, nw, nw == 8 ? 256 : 1024);
     const size_t words = (bf16x3 ? (size_t)2 * HB * HB * 6 * 64 * 4 : (size_t)2 * H * H) +
                          (5 + PVS_MAX_EDGE_ATTR) * H +
                          (size_t)nw * (kTile * (H + 4) + kTile * 4 + kTile);
