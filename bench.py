@@ -375,7 +375,7 @@ def main():
                        'launch': 'hipGraph replay of the whole step' if use_graph else 'eager'},
             'roofline': {
                 'bound': 'hbm', 'kernel': ('k_edge_bwd_mfma<1> (edge backward, one launch per layer)' if h == 32
-                                          else 'k_edge_bwd_team<2> (edge backward, one launch per layer)'),
+                                          else 'k_edge_bwd_team_parts (H=64 edge backward, one launch per layer)'),
                 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                 'algorithmic_bytes_per_launch': dom_bytes,
