@@ -198,6 +198,10 @@ def main():
                     help='build the radius graph on the GPU from the coordinates every step '
                          '(pvs_radius_graph_*, SURVEY §8f row 1) instead of parsing the resident int64 '
                          'COO + one-hot; not the headline configuration (one host sync per step)')
+    ap.add_argument('--host-inputs', choices=['pinned', 'pageable'], default=None,
+                    help='hand every step a HOST batch (as the reference\'s DataLoader does) and count the '
+                         'host-to-device copy in the step: the PCIe-inclusive rate noted in DESIGN.md, never '
+                         'the headline value (inputs resident in HBM)')
     ap.add_argument('--graph', type=int, default=int(os.environ.get('PVS_BENCH_GRAPH', '0')),
                     help='1: capture the whole training step in a hipGraph and time replays')
     args = ap.parse_args()
@@ -235,13 +239,25 @@ def main():
     # ---- inputs: this rank's graphs, built on the host, then resident in HBM ----
     batch = synthetic_batch(cfg['cfg_id'], args.batch, first_graph=rank * args.batch, **cfg['graph'])
     n_nodes, n_edges = int(batch.x.shape[0]), int(batch.edge_index.shape[1])
+    host_batch = None
+    if args.host_inputs:
+        import copy
+        host_batch = copy.copy(batch)       # Data.to() moves in place: keep a separate attribute bag on the host
+        if args.build_graph:      # only coordinates and features cross PCIe; the edges are built on the GPU
+            for name in ('edge_index', 'edge_attr'):
+                delattr(host_batch, name)
+        if args.host_inputs == 'pinned':
+            for name in host_batch.keys():
+                v = getattr(host_batch, name)
+                if torch.is_tensor(v):
+                    setattr(host_batch, name, v.pin_memory())
     batch = batch.to(dev)
     y_true = batch.y.float()
 
     torch.manual_seed(0)
     model = SartorrasEGNN(Path('/tmp/pvs_bench'), 2e-3, 1e-4, silent=True, **cfg['model']).train()
     params = list(model.parameters())
-    use_graph = bool(args.graph) and world == 1 and not args.build_graph
+    use_graph = bool(args.graph) and world == 1 and not args.build_graph and not args.host_inputs
     if use_graph:   # same Adam, step counter kept on the device so the step can be captured
         model.optimiser = torch.optim.Adam(params, lr=2e-3, weight_decay=1e-4, capturable=True)
     # exchange of the late layers' gradients starts from backward hooks, the rest after the backward
@@ -261,6 +277,9 @@ def main():
         from pointvs_amd.radius_graph import attach_radius_graph
 
     def step():
+        nonlocal batch
+        if host_batch is not None:
+            batch = copy.copy(host_batch).to(dev, non_blocking=True)
         if args.build_graph:
             attach_radius_graph(batch, cfg['graph']['edge_radius'])
         if args.infer:
@@ -372,7 +391,9 @@ def main():
                        'graphs_per_gpu': args.batch, 'global_batch': world * args.batch,
                        'parallelism': f'dp{world}', 'final_loss': round(final_loss, 6),
                        'last_layer_coord_update': 'skipped (dead)' if args.skip_dead_coords else 'evaluated',
-                       'launch': 'hipGraph replay of the whole step' if use_graph else 'eager'},
+                       'launch': 'hipGraph replay of the whole step' if use_graph else 'eager',
+                       'inputs': (f'host ({args.host_inputs}) batch copied to the device inside every step'
+                                  if args.host_inputs else 'resident in HBM')},
             'roofline': {
                 'bound': 'hbm', 'kernel': ('k_edge_bwd_mfma<1> (edge backward, one launch per layer)' if h == 32
                                           else 'k_edge_bwd_team_parts (H=64 edge backward, one launch per layer)'),

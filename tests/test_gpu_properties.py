@@ -410,7 +410,7 @@ def test_train_and_val_entry_points(tmp_path):
 @pytest.mark.parametrize('seed', range(8))
 def test_kernel_families_agree_on_random_configurations(seed):
     """Fuzz: random layer flags, hidden size, graph shape (isolated nodes, E not a multiple of the
-    tile, several graphs) - the MFMA kernels (bf16x3 and fp32 products) and the generic kernels give
+    tile, several graphs) - the MFMA kernels (bf16x3 and fp32 products, H=64 with parts or fp32 tiles) and the generic kernels give
     the same outputs and gradients."""
     rng = np.random.default_rng(1000 + seed)
     flags = dict(
@@ -430,8 +430,9 @@ def test_kernel_families_agree_on_random_configurations(seed):
     e = int(rng.integers(1, 40)) * n + int(rng.integers(0, 31))
     g = random_graph(n, e, seed=seed, n_graphs=int(rng.integers(1, 5)))
     runs = {}
-    for name, env in (('mfma', {}), ('fp32', {'PVS_EGNN_BF16X3': '0'}), ('generic', {'PVS_EGNN_KERNELS': 'generic'})):
-        for k_ in ('PVS_EGNN_BF16X3', 'PVS_EGNN_KERNELS'):
+    for name, env in (('mfma', {}), ('fp32', {'PVS_EGNN_BF16X3': '0'}), ('team', {'PVS_TEAM_PARTS': '0'}),
+                      ('generic', {'PVS_EGNN_KERNELS': 'generic'})):
+        for k_ in ('PVS_EGNN_BF16X3', 'PVS_EGNN_KERNELS', 'PVS_TEAM_PARTS'):
             os.environ.pop(k_, None)
         os.environ.update(env)
         try:
@@ -440,7 +441,7 @@ def test_kernel_families_agree_on_random_configurations(seed):
             for k_ in env:
                 os.environ.pop(k_, None)
     y_ref, g_ref = runs['generic']
-    for name in ('mfma', 'fp32'):
+    for name in ('mfma', 'fp32', 'team'):
         y, grads = runs[name]
         assert rel_err(y, y_ref) < TOL, (name, flags)
         for pname in g_ref:
