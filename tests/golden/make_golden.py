@@ -3,7 +3,8 @@
 
 Run from the repo root, in the container that has `/root/reference`:
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py          # all cases
+    python tests/golden/make_golden.py --add    # only cases without a committed .npz
 
 It imports `/root/reference/point_vs` under the import-only stand-ins in `tests/golden/_refstubs`
 (see the README there), drives the reference's own classes
@@ -218,9 +219,17 @@ def main():
         kw.update(changes)
         return kw
 
-    rm = sorted(HERE.glob('*.npz'))
-    for f in rm:
-        f.unlink()
+    # `--add`: keep the committed vectors and write only the cases that do not exist yet
+    add_only = '--add' in sys.argv[1:]
+    if not add_only:
+        for f in sorted(HERE.glob('c[0-9]_*.npz')):
+            f.unlink()
+    _run_case = globals()['run_case']
+
+    def run_case(name, *a, **k):
+        if add_only and (HERE / f'{name}.npz').exists():
+            return
+        _run_case(name, *a, **k)
     # C1: the reference tests' own model kwargs on its own graphs
     run_case('c1_testkwargs_g1', g1, SartorrasEGNN, test_kwargs, with_adam=True)
     run_case('c1_testkwargs_g2', g2, SartorrasEGNN, test_kwargs, sd_from='c1_testkwargs_g1')
@@ -269,6 +278,14 @@ def main():
              var(k=32, num_layers=3, residual=True, gated_residual=True, edge_residual=True,
                  edge_attention=True, node_attention=True, normalize=True, tanh=True,
                  graphnorm=True))
+    # C4: k=64 (the two-wave team kernels of the backward) with and without edge residual / gates
+    run_case('c4_k64_clidefault_g4', g4, SartorrasEGNN, var(k=64))
+    run_case('c4_k64_edgeres_g5', g5, SartorrasEGNN, var(k=64, edge_residual=True, num_layers=3))
+    run_case('c4_k64_edgeres_rezero_att_g4', g4, SartorrasEGNN,
+             var(k=64, edge_residual=True, residual=True, rezero=True, edge_attention=True,
+                 node_attention=True, num_layers=3))
+    run_case('c4_k64_normalize_tanh_att_g5', g5, SartorrasEGNN,
+             var(k=64, normalize=True, tanh=True, edge_attention=True, residual=True), with_adam=True)
 
 
 if __name__ == '__main__':
