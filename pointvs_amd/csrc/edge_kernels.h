@@ -78,6 +78,9 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
                              int att_act, const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs);
 int pvs_edge_v0_supported(int H);
 int pvs_edge_v0_blocks(int N);
+// softmax attention: att[e] (logit) -> exp(att[e] - smax[row]) / ssum[row] once the rows are complete
+int pvs_launch_softmax_finalize(hipStream_t s, const PvsGraph& g, const float* smax, const float* ssum,
+                                float* att);
 int pvs_launch_edge_fwd_v0(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,
                            int att_act, const PvsEdgeFwdIO& io);
 int pvs_launch_edge_bwd_v0(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,

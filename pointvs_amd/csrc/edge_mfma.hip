@@ -241,7 +241,8 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
 #pragma unroll
                         for (int r = 0; r < 16; ++r) dot = fmaf(m[b][r], gMi[b][r], dot);
                     dot += __shfl_xor(dot, 32, 64);
-                    g_l = pvs_att_act_grad(att_act, logit, aval) * dot * vm;
+                    g_l = (flags & PVS_SOFTMAX_ATT) ? aval * (dot - io.softD[i]) * vm      // softD = M_i . g_M_i
+                                             : pvs_att_act_grad(att_act, logit, aval) * dot * vm;
                     if (hh == 0) g_ba += g_l;
                     float wax[HB][16];
                     load_tab<HB>(wat, hh, wax);
@@ -846,7 +847,8 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 const float logit = sum_pd(pdA) + bac;
                 const float dot = sum_pd(pdB);
                 aval = io.att[ee];
-                g_l = pvs_att_act_grad(att_act, logit, aval) * dot * vm;
+                g_l = (flags & PVS_SOFTMAX_ATT) ? aval * (dot - io.softD[i]) * vm      // softD = M_i . g_M_i
+                                             : pvs_att_act_grad(att_act, logit, aval) * dot * vm;
                 if (hh == 0 && cb == 0) { g_ba += g_l; glb[j] = g_l; }
                 float wax[16];
                 load16_tab(wat + co, hh, wax);
@@ -1375,7 +1377,8 @@ k_edge_bwd_team_parts(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEd
                 const float logit = sum_pd(pdA) + bac;
                 const float dot = sum_pd(pdB);
                 aval = io.att[ee];
-                g_l = pvs_att_act_grad(att_act, logit, aval) * dot * vm;
+                g_l = (flags & PVS_SOFTMAX_ATT) ? aval * (dot - io.softD[i]) * vm      // softD = M_i . g_M_i
+                                             : pvs_att_act_grad(att_act, logit, aval) * dot * vm;
                 if (hh == 0 && cb == 0) g_ba += g_l;
                 float wax[16];
                 load16_tab(wat + co, hh, wax);
@@ -1721,6 +1724,6 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
 
 int pvs_edge_bwd_mfma_supported(int H, uint32_t flags, int n_attr) {
     if ((H != 32 && H != 64) || n_attr > 3) return 0;
-    if ((flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT)) return 0;
+    (void)flags;
     return 1;
 }

@@ -232,7 +232,7 @@ __device__ __forceinline__ void reduce_rows_tile(const float* __restrict__ T, co
             acc.x = fmaf(m, v[k].x, acc.x); acc.y = fmaf(m, v[k].y, acc.y);
             acc.z = fmaf(m, v[k].z, acc.z); acc.w = fmaf(m, v[k].w, acc.w);
             accx.x = fmaf(m, dx[k].x, accx.x); accx.y = fmaf(m, dx[k].y, accx.y);
-            accx.z = fmaf(m, dx[k].z, accx.z);
+            accx.z = fmaf(m, dx[k].z, accx.z); accx.w = fmaf(m, dx[k].w, accx.w);
         }
         if (bm == 0u) break;            // the last segment stays open (carried to the next tile)
         flush(cur_row);

@@ -42,6 +42,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
 
     const bool upd = flags & PVS_UPDATE_COORDS;
     const bool eatt = flags & PVS_EDGE_ATTENTION;
+    const bool soft = eatt && (flags & PVS_SOFTMAX_ATT);
     const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
 
     // BF16X3: each 32x32 block takes 3 parts x 2 k-steps x 64 lanes x 16 B = 6 KB
@@ -86,12 +87,21 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
         constexpr int QPR = H / 4;
         const int quad = lane % QPR, rsub = lane / QPR;
 
+        // softmax attention: running maximum of the open row's logits (online softmax: the open row's
+        // sums are rescaled when the maximum grows; tx[.].w carries the weights' sum)
+        float mu_open = -INFINITY;
         auto flush = [&](int row_id) {
             if (row_id >= 0) {
-                const float4 tot = sum_row_slots<HB>(acc);
+                float4 tot = sum_row_slots<HB>(acc);
+                float4 tx4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (upd || soft) tx4 = sum_row_slots<HB>(accx);
+                if (soft) {
+                    const float inv = tx4.w > 0.f ? 1.f / tx4.w : 0.f;
+                    tot.x *= inv; tot.y *= inv; tot.z *= inv; tot.w *= inv;
+                    if (lane == 0) io.ssum[row_id] = tx4.w;
+                }
                 if (rsub == 0) *reinterpret_cast<float4*>(io.Magg + (size_t)row_id * H + 4 * quad) = tot;
                 if (upd) {
-                    const float4 tx4 = sum_row_slots<HB>(accx);
                     if (lane == 0) {
                         if (flags & kFwdRawXsum) {
                             io.x_out[3 * row_id] = tx4.x;
@@ -197,8 +207,33 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
             // ---- attention gate ----
             float a = 1.f;
             if (eatt) {
-                a = pvs_att_act(att_act, dot_tab<HB>(wat, hh, m) + bac);
-                if (valid && hh == 0) io.att_out[e] = a;
+                const float logit = dot_tab<HB>(wat, hh, m) + bac;
+                if (soft) {
+                    // segment = row within the tile (0: the row left open by the previous tile)
+                    const int sg = __popc(bmask & (j == 31 ? 0xffffffffu : ((2u << j) - 1u)));
+                    const int nseg = __popc(bmask);
+                    float shift = 0.f, last = mu_open;
+                    for (int sgi = 0; sgi <= nseg; ++sgi) {
+                        float mx = (valid && sg == sgi) ? logit : -INFINITY;
+#pragma unroll
+                        for (int o = 1; o < 32; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                        if (sgi == 0) {
+                            const float nm = fmaxf(mu_open, mx);
+                            const float f = (mu_open == -INFINITY) ? 0.f : __expf(mu_open - nm);
+                            acc.x *= f; acc.y *= f; acc.z *= f; acc.w *= f;
+                            accx.w *= f;
+                            mx = nm;
+                        }
+                        if (sg == sgi) shift = mx;
+                        last = mx;
+                    }
+                    mu_open = last;
+                    a = valid ? __expf(logit - shift) : 0.f;
+                    if (valid && hh == 0) { io.att_out[e] = logit; io.smax[i] = shift; }   // finalised after the kernel
+                } else {
+                    a = pvs_att_act(att_act, logit);
+                    if (valid && hh == 0) io.att_out[e] = a;
+                }
             }
             // ---- hand the weighted messages to the channel-per-lane reduction ----
             const float wgt = valid ? a : 0.f;
@@ -211,7 +246,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                                     wgt * m[b][4 * gq + 3]);
             if (hh == 0) {
                 const float sv = valid ? s : 0.f;
-                *reinterpret_cast<float4*>(tx + j * 4) = make_float4(d0 * sv, d1 * sv, d2 * sv, 0.f);
+                *reinterpret_cast<float4*>(tx + j * 4) = make_float4(d0 * sv, d1 * sv, d2 * sv, soft ? wgt : 0.f);
                 rowbuf[j] = i;
             }
             I = In;
@@ -244,7 +279,6 @@ __global__ void k_init_fwd(float* __restrict__ Magg, const float* __restrict__ x
 
 int pvs_edge_mfma_supported(int H, uint32_t flags) {
     if (H != 32 && H != 64) return 0;
-    if ((flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT)) return 0;   // generic path
     return 1;
 }
 
@@ -288,6 +322,9 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
         k_edge_fwd_mfma<2, false><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
     }
     PVS_CHECK_LAUNCH();
+    // softmax attention: att_out holds the logits, the rows' maxima and sums are complete now
+    if ((flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT))
+        return pvs_launch_softmax_finalize(s, g, io.smax, io.ssum, io.att_out);
     return 0;
 }
 

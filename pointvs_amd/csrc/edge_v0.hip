@@ -178,7 +178,7 @@ k_edge_fwd_v0(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdIO 
 __global__ void k_softmax_finalize(PvsGraph g, const float* __restrict__ smax,
                                    const float* __restrict__ ssum, float* __restrict__ att) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= g.n_edges) return;
+    if (e >= g.n_edges || (g.n_edges_dev && e >= *g.n_edges_dev)) return;
     int i = g.row[e];
     att[e] = __expf(att[e] - smax[i]) / ssum[i];
 }
@@ -563,10 +563,16 @@ int pvs_launch_edge_fwd_v0(hipStream_t s, int H, const PvsGraph& g, const PvsEdg
         k_edge_fwd_v0<HH><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io);
     });
     PVS_CHECK_LAUNCH();
-    if ((flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT) && g.n_edges > 0) {
-        k_softmax_finalize<<<(g.n_edges + 255) / 256, 256, 0, s>>>(g, io.smax, io.ssum, io.att_out);
-        PVS_CHECK_LAUNCH();
-    }
+    if ((flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT))
+        return pvs_launch_softmax_finalize(s, g, io.smax, io.ssum, io.att_out);
+    return 0;
+}
+
+int pvs_launch_softmax_finalize(hipStream_t s, const PvsGraph& g, const float* smax, const float* ssum,
+                                float* att) {
+    if (g.n_edges <= 0) return 0;
+    k_softmax_finalize<<<(g.n_edges + 255) / 256, 256, 0, s>>>(g, smax, ssum, att);
+    PVS_CHECK_LAUNCH();
     return 0;
 }
 

@@ -326,7 +326,9 @@ __global__ void k_combine_partial(float* __restrict__ Magg, float* __restrict__ 
 int partial_checks(const PvsLayerDesc* d, const PvsGraph* g, const PvsLayerParams* p) {
     PVS_TRY(check_desc(d, g, p, true));
     PVS_REQUIRE(pvs_use_mfma() && pvs_edge_mfma_supported(d->hidden, d->flags),
-                "partial-sum forward needs the MFMA edge kernel (H = 32 or 64, no softmax attention)");
+                "partial-sum forward needs the MFMA edge kernel (H = 32 or 64)");
+    PVS_REQUIRE(!((d->flags & PVS_EDGE_ATTENTION) && (d->flags & PVS_SOFTMAX_ATT)),
+                "partial-sum forward: softmax attention is not supported (row sums of two edge sets do not add)");
     PVS_REQUIRE(!(d->flags & PVS_EDGE_RESIDUAL), "partial-sum forward: edge_residual layers are not supported");
     return 0;
 }

@@ -421,6 +421,8 @@ def test_kernel_families_agree_on_random_configurations(seed):
         update_coords=bool(rng.integers(4) > 0), permutation_invariance=bool(rng.integers(4) == 0),
         attention_activation_fn=str(rng.choice(['sigmoid', 'tanh', 'relu', 'silu'])))
     variant = int(rng.integers(3))
+    if flags['edge_attention'] and seed % 3 == 0:
+        flags['softmax_attention'] = True
     if variant == 1:
         flags['gated_residual'] = True
     elif variant == 2:
