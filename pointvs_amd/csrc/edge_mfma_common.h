@@ -199,7 +199,7 @@ __device__ __forceinline__ void assemble_z1(const TileGather<HB>& G, const float
 // control flow: the first segment continues the carried row, every later one starts at a set bit.
 // acc/accx carry the open row's partial sums (per lane: its quad, summed over its row slots);
 // flush(row) reduces them over the row slots, stores and clears.
-template <int HB, class Flush, class RowStore>
+template <int HB, bool WSUM = false, class Flush, class RowStore>
 __device__ __forceinline__ void reduce_rows_tile(const float* __restrict__ T, const float* __restrict__ tx,
                                                  const int* __restrict__ rowbuf, unsigned bmask, int lane,
                                                  float4& acc, float4& accx, int& cur_row, Flush&& flush,
@@ -232,7 +232,8 @@ __device__ __forceinline__ void reduce_rows_tile(const float* __restrict__ T, co
             acc.x = fmaf(m, v[k].x, acc.x); acc.y = fmaf(m, v[k].y, acc.y);
             acc.z = fmaf(m, v[k].z, acc.z); acc.w = fmaf(m, v[k].w, acc.w);
             accx.x = fmaf(m, dx[k].x, accx.x); accx.y = fmaf(m, dx[k].y, accx.y);
-            accx.z = fmaf(m, dx[k].z, accx.z); accx.w = fmaf(m, dx[k].w, accx.w);
+            accx.z = fmaf(m, dx[k].z, accx.z);
+            if constexpr (WSUM) accx.w = fmaf(m, dx[k].w, accx.w);   // (softmax: the weights' sum)
         }
         if (bm == 0u) break;            // the last segment stays open (carried to the next tile)
         flush(cur_row);

@@ -18,7 +18,7 @@
 
 namespace {
 
-template <int HB, bool BF16X3, int NT = kThreads>
+template <int HB, bool BF16X3, int NT = kThreads, bool SOFT = false>
 __global__ void __launch_bounds__(NT)
 k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdIO io, int n_chunks,
                 int e_lo, int e_hi) {
@@ -42,7 +42,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
 
     const bool upd = flags & PVS_UPDATE_COORDS;
     const bool eatt = flags & PVS_EDGE_ATTENTION;
-    const bool soft = eatt && (flags & PVS_SOFTMAX_ATT);
+    constexpr bool soft = SOFT;      // softmax attention: its own instantiation (keeps the others' registers)
     const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
 
     // BF16X3: each 32x32 block takes 3 parts x 2 k-steps x 64 lanes x 16 B = 6 KB
@@ -95,7 +95,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                 float4 tot = sum_row_slots<HB>(acc);
                 float4 tx4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (upd || soft) tx4 = sum_row_slots<HB>(accx);
-                if (soft) {
+                if constexpr (soft) {
                     const float inv = tx4.w > 0.f ? 1.f / tx4.w : 0.f;
                     tot.x *= inv; tot.y *= inv; tot.z *= inv; tot.w *= inv;
                     if (lane == 0) io.ssum[row_id] = tx4.w;
@@ -208,7 +208,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
             float a = 1.f;
             if (eatt) {
                 const float logit = dot_tab<HB>(wat, hh, m) + bac;
-                if (soft) {
+                if constexpr (soft) {
                     // segment = row within the tile (0: the row left open by the previous tile)
                     const int sg = __popc(bmask & (j == 31 ? 0xffffffffu : ((2u << j) - 1u)));
                     const int nseg = __popc(bmask);
@@ -252,7 +252,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
             I = In;
             pvs_wave_lds_sync();
             if (!(flags & kAblNoReduce))
-                reduce_rows_tile<HB>(tile, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
+                reduce_rows_tile<HB, soft>(tile, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
                                      [](int, int, const float4&) {});
             pvs_wave_lds_sync();
         }
@@ -308,19 +308,23 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
                          (5 + PVS_MAX_EDGE_ATTR) * H +
                          (size_t)nw * (kTile * (H + 4) + kTile * 4 + kTile);
     const size_t lds = words * sizeof(float);
-    if (HB == 2 && bf16x3) {
-        if (set_lds(k_edge_fwd_mfma<2, true, 512>, lds)) return -2;
-        k_edge_fwd_mfma<2, true, 512><<<blocks, 512, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
-    } else if (HB == 1 && bf16x3) {
-        if (set_lds(k_edge_fwd_mfma<1, true>, lds)) return -2;
-        k_edge_fwd_mfma<1, true><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
-    } else if (HB == 1) {
-        if (set_lds(k_edge_fwd_mfma<1, false>, lds)) return -2;
-        k_edge_fwd_mfma<1, false><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
-    } else {
-        if (set_lds(k_edge_fwd_mfma<2, false>, lds)) return -2;
-        k_edge_fwd_mfma<2, false><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges);
-    }
+    const bool soft = (flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT);
+#define PVS_FWD_LAUNCH(HBV, B3, NTV, SF)                                                             \
+    do {                                                                                            \
+        if (set_lds(k_edge_fwd_mfma<HBV, B3, NTV, SF>, lds)) return -2;                             \
+        k_edge_fwd_mfma<HBV, B3, NTV, SF><<<blocks, NTV, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges); \
+    } while (0)
+#define PVS_FWD_PICK(HBV, B3, NTV)                      \
+    do {                                               \
+        if (soft) PVS_FWD_LAUNCH(HBV, B3, NTV, true);  \
+        else PVS_FWD_LAUNCH(HBV, B3, NTV, false);      \
+    } while (0)
+    if (HB == 2 && bf16x3) PVS_FWD_PICK(2, true, 512);
+    else if (HB == 1 && bf16x3) PVS_FWD_PICK(1, true, kThreads);
+    else if (HB == 1) PVS_FWD_PICK(1, false, kThreads);
+    else PVS_FWD_PICK(2, false, kThreads);
+#undef PVS_FWD_PICK
+#undef PVS_FWD_LAUNCH
     PVS_CHECK_LAUNCH();
     // softmax attention: att_out holds the logits, the rows' maxima and sums are complete now
     if ((flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT))
