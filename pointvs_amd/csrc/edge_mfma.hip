@@ -1647,11 +1647,8 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
         else if (eatt) PVS_BWD_LAUNCH(HBV, false, true, BF);      \
         else PVS_BWD_LAUNCH(HBV, false, false, BF);               \
     } while (0)
-    const char* tm = getenv("PVS_EGNN_TEAM");
-    const bool use_team = H == 64 && !(tm && tm[0] == '0');
     if (H == 32 && bf16x3) PVS_BWD_PICK(1, true);
     else if (H == 32) PVS_BWD_PICK(1, false);
-    else if (!use_team) PVS_BWD_PICK(2, false);
     else {
         // team kernel: one team of 2 waves per 128-thread block, two blocks per CU: one wave per SIMD
         // with the whole register file (the 4-team 512-thread block spilled at 256 registers)
