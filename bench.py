@@ -220,10 +220,17 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (there is no CPU path in the product)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # PVS_BENCH_BACKEND=gloo (+ ranks sharing the visible GPUs): a dry run of the multi-rank code path
+    # on a box with fewer GPUs than ranks; the measured configuration is always one rank per GPU over RCCL
+    backend = os.environ.get('PVS_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from pointvs_amd import _lib, graph as pgraph
     from pointvs_amd.distributed import OverlappedGradAllReducer
