@@ -15,6 +15,7 @@ bool pvs_linear_epilogue_supported(int ldy, int ldx, int ldx2, int K, int K2, in
 
 // number of float slabs a column reduction / tsgemm over N rows needs: slabs * width floats
 int pvs_reduce_blocks(int N);
+int pvs_colreduce_blocks(int N);   // slabs of pvs_launch_colreduce: [pvs_colreduce_blocks(N)][C] (<= 4 x pvs_reduce_blocks)
 
 // out[c*ldo + k] (=|+=) sum_n A[n*lda + c] * B[n*ldb + k]   (weight gradients), C*K <= 8192
 int pvs_launch_tsgemm_tn(hipStream_t s, float* out, int ldo, const float* A, int lda, const float* B,

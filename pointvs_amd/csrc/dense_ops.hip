@@ -124,6 +124,60 @@ k_colreduce(int mode, float* __restrict__ slabs, const float* __restrict__ A, in
     }
 }
 
+// The same with 16-byte loads (C % 4 == 0, 16-byte aligned rows): lane = (row lane, quad of columns),
+// four rows in flight per lane.
+__global__ void __launch_bounds__(kThreads)
+k_colreduce4(int mode, float* __restrict__ slabs, const float* __restrict__ A, int lda,
+             const float* __restrict__ B, int ldb, const float* __restrict__ shift, int N, int C,
+             int rows_per_block) {
+    __shared__ float4 part[kThreads];
+    const int tid = threadIdx.x;
+    const int QC = C / 4, R = kThreads / QC;
+    const int q = tid % QC, r = tid / QC;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(N, r0 + rows_per_block);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < R) {
+        const float4 sh = (mode == PVS_COL_SUMSQ_SHIFT) ? *reinterpret_cast<const float4*>(shift + 4 * q)
+                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int UN = 4;
+        for (int n0 = r0 + r; n0 < r1; n0 += UN * R) {
+            float4 a[UN], b[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int n = n0 + u * R;
+                const bool ok = n < r1;
+                a[u] = ok ? *reinterpret_cast<const float4*>(A + (size_t)n * lda + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (mode == PVS_COL_SUM_AB)
+                    b[u] = ok ? *reinterpret_cast<const float4*>(B + (size_t)n * ldb + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                else if (mode == PVS_COL_SUMSQ_SHIFT)
+                    a[u] = ok ? make_float4(a[u].x - sh.x, a[u].y - sh.y, a[u].z - sh.z, a[u].w - sh.w) : a[u];
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                if (mode == PVS_COL_SUM_A) { acc.x += a[u].x; acc.y += a[u].y; acc.z += a[u].z; acc.w += a[u].w; }
+                else if (mode == PVS_COL_SUM_AB) {
+                    acc.x = fmaf(a[u].x, b[u].x, acc.x); acc.y = fmaf(a[u].y, b[u].y, acc.y);
+                    acc.z = fmaf(a[u].z, b[u].z, acc.z); acc.w = fmaf(a[u].w, b[u].w, acc.w);
+                } else {
+                    acc.x = fmaf(a[u].x, a[u].x, acc.x); acc.y = fmaf(a[u].y, a[u].y, acc.y);
+                    acc.z = fmaf(a[u].z, a[u].z, acc.z); acc.w = fmaf(a[u].w, a[u].w, acc.w);
+                }
+            }
+        }
+    }
+    part[tid] = acc;
+    __syncthreads();
+    if (tid < QC) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int rr = 0; rr < R; ++rr) {
+            const float4 v = part[rr * QC + tid];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(slabs + (size_t)blockIdx.x * C + 4 * tid) = s;
+    }
+}
+
 // out[map(o)] (=|+=) scale * sum_g slabs[g][o].  One block per 32 outputs: 8 slab lanes x 32
 // outputs; each slab lane sums its slabs g = lane, lane+8, ... in order, then the 8 partials are
 // added in lane order: a fixed summation tree, so the result is reproducible.
@@ -482,6 +536,15 @@ int pvs_reduce_blocks(int N) {
     return b;
 }
 
+// column reductions read each row once: more, smaller blocks than the products (at most 4x
+// pvs_reduce_blocks, which is what the callers' slab buffers are sized for)
+int pvs_colreduce_blocks(int N) {
+    int b = (N + 127) / 128;
+    if (b < 1) b = 1;
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    return b;
+}
+
 static int rows_per_block_for(int N, int blocks) { return (N + blocks - 1) / blocks; }
 
 bool pvs_linear_epilogue_supported(int ldy, int ldx, int ldx2, int K, int K2, int C, const void* y,
@@ -619,9 +682,12 @@ int pvs_launch_colreduce(hipStream_t s, int mode, float* out, const float* A, in
                          int ldb, const float* shift, int N, int C, float scale, float* slabs,
                          bool accumulate) {
     PVS_REQUIRE(C >= 1 && C <= kThreads, "colreduce: width %d unsupported", C);
-    const int blocks = pvs_reduce_blocks(N);
+    const int blocks = pvs_colreduce_blocks(N);
     const int rpb = rows_per_block_for(N, blocks);
-    k_colreduce<<<blocks, kThreads, 0, s>>>(mode, slabs, A, lda, B, ldb, shift, N, C, rpb);
+    const bool vec4 = C % 4 == 0 && lda % 4 == 0 && (B == nullptr || ldb % 4 == 0) &&
+                      (((uintptr_t)A | (uintptr_t)B | (uintptr_t)shift | (uintptr_t)slabs) & 15) == 0;
+    if (vec4) k_colreduce4<<<blocks, kThreads, 0, s>>>(mode, slabs, A, lda, B, ldb, shift, N, C, rpb);
+    else k_colreduce<<<blocks, kThreads, 0, s>>>(mode, slabs, A, lda, B, ldb, shift, N, C, rpb);
     PVS_CHECK_LAUNCH();
     k_reduce_slabs<<<(C + 31) / 32, kThreads, 0, s>>>(out, C, C, slabs, blocks, C, scale,
                                                       accumulate ? 1 : 0);

@@ -107,7 +107,7 @@ size_t carve_fwd(PvsArena& a, const Dims& m, FwdWs* w) {
     t.smax = a.take<float>(m.N);
     t.ssum = a.take<float>(m.N);
     t.shift = a.take<float>(m.H);
-    t.slabs = a.take<float>((size_t)pvs_reduce_blocks(m.N) * m.H);
+    t.slabs = a.take<float>((size_t)pvs_colreduce_blocks(m.N) * m.H);
     if (w) *w = t;
     return a.off;
 }
