@@ -90,6 +90,10 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
         gate_raw = w.edge_gate[0];
         gate = (flags & PVS_GATED_RESIDUAL) ? fmaxf(gate_raw, 0.f) : gate_raw;
     }
+    // edge residual without per-element branches: m = res_a * m_new + res_b * m_prev
+    // (plain: 1, 1; rezero: g, 1; gated: relu(g), 1 - relu(g))
+    const float res_a = (flags & (PVS_REZERO | PVS_GATED_RESIDUAL)) ? gate : 1.f;
+    const float res_b = (flags & PVS_GATED_RESIDUAL) ? 1.f - gate : 1.f;
 
     // ---- accumulators that live for the whole kernel ----
     f32x16 gW2[HB][HB], gWc1[HB][HB];       // D layout: [c = 32bo + ch(r,hh)][k = 32bi + j]
@@ -206,9 +210,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                     for (int b = 0; b < HB; ++b)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            if (flags & PVS_REZERO) m[b][r] = mp[b][r] + gate * m_new[b][r];
-                            else if (flags & PVS_GATED_RESIDUAL) m[b][r] = gate * m_new[b][r] + (1.f - gate) * mp[b][r];
-                            else m[b][r] = m_new[b][r] + mp[b][r];
+                            m[b][r] = fmaf(res_a, m_new[b][r], res_b * mp[b][r]);
                         }
                 }
                 // m edge-major in T1 (operand of the Wc1 weight gradient and of g_wa)
@@ -685,6 +687,10 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
         gate_raw = w.edge_gate[0];
         gate = (flags & PVS_GATED_RESIDUAL) ? fmaxf(gate_raw, 0.f) : gate_raw;
     }
+    // edge residual without per-element branches: m = res_a * m_new + res_b * m_prev
+    // (plain: 1, 1; rezero: g, 1; gated: relu(g), 1 - relu(g))
+    const float res_a = (flags & (PVS_REZERO | PVS_GATED_RESIDUAL)) ? gate : 1.f;
+    const float res_b = (flags & PVS_GATED_RESIDUAL) ? 1.f - gate : 1.f;
     auto sum_pd = [&](const float* pd) {
         float s = 0.f;
 #pragma unroll
@@ -819,9 +825,7 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 load16_tab(io.m_prev + (size_t)ee * H + co, hh, mp);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    if (flags & PVS_REZERO) m[r] = mp[r] + gate * m_new[r];
-                    else if (flags & PVS_GATED_RESIDUAL) m[r] = gate * m_new[r] + (1.f - gate) * mp[r];
-                    else m[r] = m_new[r] + mp[r];
+                    m[r] = fmaf(res_a, m_new[r], res_b * mp[r]);
                 }
             }
             xwrite_block<HB>(T1, j, hh, cb, m);
@@ -1208,6 +1212,10 @@ k_edge_bwd_team_parts(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEd
         gate_raw = w.edge_gate[0];
         gate = (flags & PVS_GATED_RESIDUAL) ? fmaxf(gate_raw, 0.f) : gate_raw;
     }
+    // edge residual without per-element branches: m = res_a * m_new + res_b * m_prev
+    // (plain: 1, 1; rezero: g, 1; gated: relu(g), 1 - relu(g))
+    const float res_a = (flags & (PVS_REZERO | PVS_GATED_RESIDUAL)) ? gate : 1.f;
+    const float res_b = (flags & PVS_GATED_RESIDUAL) ? 1.f - gate : 1.f;
     auto sum_pd = [&](const float* pd) {
         float s = 0.f;
 #pragma unroll
@@ -1348,9 +1356,7 @@ k_edge_bwd_team_parts(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEd
                 load16_tab(io.m_prev + (size_t)ee * H + co, hh, mp);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    if (flags & PVS_REZERO) m[r] = mp[r] + gate * m_new[r];
-                    else if (flags & PVS_GATED_RESIDUAL) m[r] = gate * m_new[r] + (1.f - gate) * mp[r];
-                    else m[r] = m_new[r] + mp[r];
+                    m[r] = fmaf(res_a, m_new[r], res_b * mp[r]);
                 }
             }
             split_bf16x3(m, own);

@@ -77,6 +77,9 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
         gate = w.edge_gate[0];
         if (flags & PVS_GATED_RESIDUAL) gate = fmaxf(gate, 0.f);
     }
+    // edge residual without per-element branches: m = res_a * m_new + res_b * m_prev
+    const float res_a = (flags & (PVS_REZERO | PVS_GATED_RESIDUAL)) ? gate : 1.f;
+    const float res_b = (flags & PVS_GATED_RESIDUAL) ? 1.f - gate : 1.f;
 
     const int total_waves = gridDim.x * NW;
     for (int chunk = pvs_xcd_block(blockIdx.x, gridDim.x) * NW + wv; chunk < n_chunks; chunk += total_waves) {
@@ -169,9 +172,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             float& mv = m[b][4 * gq + q];
-                            if (flags & PVS_REZERO) mv = mpv[q] + gate * mv;
-                            else if (flags & PVS_GATED_RESIDUAL) mv = gate * mv + (1.f - gate) * mpv[q];
-                            else mv = mv + mpv[q];
+                            mv = fmaf(res_a, mv, res_b * mpv[q]);
                         }
                     }
             }
