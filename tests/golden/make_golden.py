@@ -286,6 +286,11 @@ def main():
                  node_attention=True, num_layers=3))
     run_case('c4_k64_normalize_tanh_att_g5', g5, SartorrasEGNN,
              var(k=64, normalize=True, tanh=True, edge_attention=True, residual=True), with_adam=True)
+    run_case('c4_k64_softmax_g5', g5, SartorrasEGNN,
+             var(k=64, edge_attention=True, softmax_attention=True, node_attention=True))
+    run_case('c4_k32_softmax_edgeres_g4', g4, SartorrasEGNN,
+             var(k=32, edge_attention=True, softmax_attention=True, edge_residual=True, residual=True,
+                 num_layers=3))
 
 
 if __name__ == '__main__':
