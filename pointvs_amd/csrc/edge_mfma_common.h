@@ -134,11 +134,14 @@ __device__ __forceinline__ TileIdx load_tile_idx(const PvsGraph& g, int n_attr, 
     t.e = e0 + j;
     t.valid = t.e < e_end;
     t.ee = t.valid ? t.e : e_end - 1;
+    // an EMPTY chunk at the start of the range (a first row longer than several chunk slots) has
+    // e_end = 0: its index loads are never used, but they must stay inside the arrays
+    t.ee = min(max(t.ee, 0), g.n_edges - 1);
     t.i = g.row[t.ee];
     t.jn = g.col[t.ee];
     if (n_attr & 0x100) { t.i &= 7; t.jn &= 7; }   // ablation: every gather hits 8 hot rows
     t.ty = (n_attr & 0xff) ? (int)g.etype[t.ee] : 0;
-    t.prev_row = (t.ee == e_begin) ? -1 : g.row[t.ee - 1];
+    t.prev_row = (t.ee == e_begin || t.ee == 0) ? -1 : g.row[t.ee - 1];
     return t;
 }
 

@@ -506,6 +506,39 @@ def test_kernel_families_agree_at_baseline_batch_size(config):
             assert rel_err(g_a[pname], g_b[pname]) < 2 * TOL, pname
 
 
+def test_softmax_attention_rows_spanning_tiles_and_chunks():
+    """Softmax edge attention on the MFMA path at the BASELINE graph shape (rows of ~160 edges span
+    several 32-edge tiles: the online rescaling) and on a star graph (a 20,000-edge row spans many
+    chunk-sized pieces of one wave's work): equal to the generic kernels' per-row softmax, and the
+    attention weights of every row sum to one (the property the reference's test_attention checks)."""
+    from pointvs_amd.graph import prepared_for
+    from pointvs_amd.synthetic import CONFIGS, synthetic_batch
+    cfg = CONFIGS['cfg2']
+    kw = dict(edge_attention=True, softmax_attention=True, node_attention=True, residual=True, num_layers=2)
+    model, _ = make_model(seed=9, **kw)
+    n = 20001
+    hub, leaves = np.zeros(n - 1, dtype=np.int64), np.arange(1, n)
+    star = random_graph(n, np.concatenate([np.stack([hub, leaves]), np.stack([leaves, hub])], axis=1), seed=6)
+    for g in (synthetic_batch(cfg['cfg_id'], 2, **cfg['graph']), star):
+        os.environ.pop('PVS_EGNN_KERNELS', None)
+        y_a, g_a = gpu_run(model, g)
+        layer = model.layers[1]
+        att = np.asarray(layer.att_val).reshape(-1)
+        rows = np.asarray(g.edge_index[0])
+        sums = np.bincount(rows, weights=att.astype(np.float64), minlength=int(g.x.shape[0]))
+        has_edges = np.bincount(rows, minlength=int(g.x.shape[0])) > 0
+        assert np.abs(sums[has_edges] - 1.0).max() < 1e-4
+        os.environ['PVS_EGNN_KERNELS'] = 'generic'
+        try:
+            y_b, g_b = gpu_run(model, g)
+        finally:
+            os.environ.pop('PVS_EGNN_KERNELS', None)
+        assert rel_err(y_a, y_b) < TOL
+        for pname in g_a:
+            if g_a[pname] is not None:
+                assert rel_err(g_a[pname], g_b[pname]) < 1e-4, pname
+
+
 def test_last_layer_coordinates_are_available_on_demand():
     """The model forward skips the last layer's coordinate branch (nothing reads x_L); the layer's
     `intermediate_coords` side attribute (egnn_satorras.py:175) must still give the reference value."""
