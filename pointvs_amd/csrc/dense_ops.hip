@@ -189,7 +189,18 @@ k_reduce_slabs(float* __restrict__ out, int ldo, int inner, const float* __restr
     const int o = blockIdx.x * 32 + ol;
     float s = 0.f;
     if (o < width)
-        for (int gidx = sl; gidx < n_slabs; gidx += 8) s += slabs[(size_t)gidx * width + o];
+    {   // four independent partial sums per lane (loads in flight), combined in a fixed order
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int gidx = sl;
+        for (; gidx + 24 < n_slabs; gidx += 32) {
+            a0 += slabs[(size_t)gidx * width + o];
+            a1 += slabs[(size_t)(gidx + 8) * width + o];
+            a2 += slabs[(size_t)(gidx + 16) * width + o];
+            a3 += slabs[(size_t)(gidx + 24) * width + o];
+        }
+        for (; gidx < n_slabs; gidx += 8) a0 += slabs[(size_t)gidx * width + o];
+        s = (a0 + a1) + (a2 + a3);
+    }
     part[sl][ol] = s;
     __syncthreads();
     if (sl == 0 && o < width && (o % inner) < inner_valid) {
@@ -217,7 +228,18 @@ k_reduce_slabs2(float* __restrict__ out_a, const float* __restrict__ slabs_a, in
     const int o = ((int)blockIdx.x - (is_a ? 0 : blocks_a)) * 32 + ol;
     float s = 0.f;
     if (o < width)
-        for (int gidx = sl; gidx < n_slabs; gidx += 8) s += slabs[(size_t)gidx * width + o];
+    {   // four independent partial sums per lane (loads in flight), combined in a fixed order
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int gidx = sl;
+        for (; gidx + 24 < n_slabs; gidx += 32) {
+            a0 += slabs[(size_t)gidx * width + o];
+            a1 += slabs[(size_t)(gidx + 8) * width + o];
+            a2 += slabs[(size_t)(gidx + 16) * width + o];
+            a3 += slabs[(size_t)(gidx + 24) * width + o];
+        }
+        for (; gidx < n_slabs; gidx += 8) a0 += slabs[(size_t)gidx * width + o];
+        s = (a0 + a1) + (a2 + a3);
+    }
     part[sl][ol] = s;
     __syncthreads();
     if (sl == 0 && o < width && !(is_a && o >= skip_lo && o < skip_hi)) {
