@@ -49,11 +49,71 @@ def algorithmic_bytes_edge_bwd(n, e, h):
     return 4 * e * h + 9 * e + 3 * (4 * h + 12) * n
 
 
-def algorithmic_flops_per_step(n, e, h, a, layers, edge_att=False, node_att=False):
-    """SURVEY.md §8d reference-formulation FLOPs: 3 x forward (fwd + dgrad + wgrad)."""
+def algorithmic_flops_per_step(n, e, h, a, layers, edge_att=False, node_att=False, training=True):
+    """SURVEY.md §8d reference-formulation FLOPs (2/MAC, GEMM-like terms of the reference's own
+    formulation): forward, x3 for a training step (fwd + dgrad + wgrad)."""
     f_e = 2 * h * (2 * h + 1 + a) + 2 * h * h + (2 * h * h + 2 * h) + (2 * h if edge_att else 0)
     f_n = 6 * h * h + (2 * h if node_att else 0)
-    return 3 * layers * (f_e * e + f_n * n)
+    return (3 if training else 1) * layers * (f_e * e + f_n * n)
+
+
+def executed_flops_per_step(n, e, h, layers, edge_att=False, node_att=False, training=True):
+    """FLOPs the kernels actually execute. The per-node split of edge_mlp.0 removes the
+    [E, 2H+4] x [2H+4, H] product: per edge the forward runs W2 and Wc1 (4H^2 + 2H for wc2, + 2H for the
+    attention logit), the backward recomputes those two and runs two dgrad and two wgrad products
+    (12H^2 + 4H); per node the forward runs P, Q (4H^2) and the node MLP (6H^2), the backward their
+    dgrad and wgrad (20H^2)."""
+    att = 2 * h if edge_att else 0
+    f_e_fwd = 4 * h * h + 2 * h + att
+    f_n_fwd = 10 * h * h + (2 * h if node_att else 0)
+    if not training:
+        return layers * (f_e_fwd * e + f_n_fwd * n)
+    f_e_bwd = 12 * h * h + 4 * h + 2 * att
+    f_n_bwd = 20 * h * h + (4 * h if node_att else 0)
+    return layers * ((f_e_fwd + f_e_bwd) * e + (f_n_fwd + f_n_bwd) * n)
+
+
+def algorithmic_bytes_edge_fwd(n, e, h):
+    """Forward share of the §8d formula when the messages are not materialised (inference, cfg5:
+    `5E + 2(4H+12)N` per layer): col + type per edge, node rows in and out."""
+    return 5 * e + 2 * (4 * h + 12) * n
+
+
+def flag_summary(model_kwargs):
+    on = [k for k in ('residual', 'edge_residual', 'edge_attention', 'node_attention', 'normalize', 'tanh',
+                      'graphnorm', 'permutation_invariance', 'gated_residual', 'rezero', 'softmax_attention')
+          if model_kwargs.get(k)]
+    return 'CLI-default layer flags (all off)' if not on else 'layer flags on: ' + ', '.join(on)
+
+
+def measured_traffic(config, kernel):
+    """HBM bytes per launch of `kernel` from the PMC passes of the same command (separate rocprofv3
+    --pmc runs, tools/measure_traffic.sh -> profiles/rNN_<config>_traffic.json; a PMC pass cannot run
+    inside this process). The newest round's file wins; None when the config was never measured."""
+    for tfile in sorted((ROOT / 'profiles').glob(f'r[0-9][0-9]_{config}_traffic.json'), reverse=True):
+        kern = json.loads(tfile.read_text()).get('kernels', {})
+        for name, rec in kern.items():
+            if name.startswith(kernel) and rec.get('hbm_bytes_per_launch'):
+                return rec['hbm_bytes_per_launch'], tfile.name
+    return None, None
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N fresh ranks of this script under
+    torch.distributed.run and exit with their status. Runs BEFORE anything touches the GPU (a process
+    that has initialised HIP must never be replaced or forked into ranks)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    if torch.cuda.device_count() < args.gpus and 'PVS_BENCH_BACKEND' not in env:
+        raise SystemExit(f'--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible; set '
+                         f'PVS_BENCH_BACKEND=gloo for a dry run of the multi-rank path with ranks sharing devices')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(cfg, seconds_budget=15.0):
@@ -213,11 +273,13 @@ def main():
             raise SystemExit(f'--global-batch {args.global_batch} is not divisible by --gpus {args.gpus}')
         args.batch = args.global_batch // args.gpus
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (there is no CPU path in the product)')
     # PVS_BENCH_BACKEND=gloo (+ ranks sharing the visible GPUs): a dry run of the multi-rank code path
@@ -361,31 +423,39 @@ def main():
     if rank == 0:
         h = cfg['model']['k']
         layers = cfg['model']['num_layers']
+        eatt, natt = cfg['model']['edge_attention'], cfg['model']['node_attention']
+        training = not args.infer
         ms_step = elapsed / args.steps * 1e3
         graphs_per_s = world * args.batch * args.steps / elapsed
         bwd_ms, bwd_n = kernel_ms('edge_bwd')
         fwd_ms, fwd_n = kernel_ms('edge_fwd')
         col_ms, col_n = kernel_ms('col_gather')
         prep_ms, prep_n = kernel_ms('graph_prepare')
-        dom_avg_ms = bwd_ms / max(bwd_n, 1)
-        dom_bytes = algorithmic_bytes_edge_bwd(n_nodes, n_edges, h)
+        if training:     # dominant kernel: the edge backward (one launch per layer)
+            dom_ms, dom_n = bwd_ms, bwd_n
+            dom_bytes = algorithmic_bytes_edge_bwd(n_nodes, n_edges, h)
+            dom_flops = (12.0 * h * h + 4 * h) * n_edges     # 2 recompute + 2 dgrad + 2 wgrad products
+            dom_symbol = 'k_edge_bwd_mfma' if h == 32 else 'k_edge_bwd_team_parts'
+            dom_name = (f'{dom_symbol} (H={h} edge backward, one launch per layer)')
+            step_bytes = layers * algorithmic_bytes_per_layer(n_nodes, n_edges, h)
+        else:            # forward only: the edge forward
+            dom_ms, dom_n = fwd_ms, fwd_n
+            dom_bytes = algorithmic_bytes_edge_fwd(n_nodes, n_edges, h)
+            dom_flops = (4.0 * h * h + 2 * h) * n_edges
+            dom_symbol = 'k_edge_fwd_mfma'
+            dom_name = f'k_edge_fwd_mfma (H={h} edge forward, one launch per layer)'
+            step_bytes = layers * dom_bytes
+        dom_avg_ms = dom_ms / max(dom_n, 1)
         achieved = dom_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
-        step_bytes = layers * algorithmic_bytes_per_layer(n_nodes, n_edges, h)
-        step_flops = algorithmic_flops_per_step(
-            n_nodes, n_edges, h, 1 if args.infer else 3, layers, cfg['model']['edge_attention'],
-            cfg['model']['node_attention'])
-        traffic = None
-        tfile = ROOT / 'profiles' / f'r01_{args.config}_traffic.json'
-        if tfile.exists():   # PMC passes cannot run inside this process: tools/measure_traffic.sh
-            kern = json.loads(tfile.read_text()).get('kernels', {})
-            traffic = kern.get('k_edge_bwd_mfma', {}).get('hbm_bytes_per_launch')
+        dom_tflops = dom_flops / (dom_avg_ms * 1e-3) / 1e12 if dom_avg_ms > 0 else 0.0
+        ref_flops = algorithmic_flops_per_step(n_nodes, n_edges, h, 3, layers, eatt, natt, training)
+        exec_flops = executed_flops_per_step(n_nodes, n_edges, h, layers, eatt, natt, training)
+        traffic, traffic_src = measured_traffic(args.config, dom_symbol)
+        what = 'forward only (inference)' if args.infer else 'fwd+bwd (+Adam step)'
+        shape = ('3-layer EGNN ch=32, ~2k nodes r=10A' if args.config == 'cfg2' else
+                 '12-layer EGNN ch=64 edge+node attention, ~2k nodes r=6A')
         out = {
-            'metric': 'protein-ligand graphs/sec forward only (inference), 3-layer EGNN ch=32, '
-                      '~2k nodes r=10A' if args.infer else
-                      'protein-ligand graphs/sec fwd+bwd (+Adam step), 3-layer EGNN ch=32, '
-                      '~2k nodes r=10A' if args.config == 'cfg2' else
-                      'protein-ligand graphs/sec fwd+bwd (+Adam step), 12-layer EGNN ch=64 '
-                      'edge+node attention, ~2k nodes r=6A',
+            'metric': f'protein-ligand graphs/sec {what}, {shape}',
             'value': round(graphs_per_s, 2), 'unit': 'graphs/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 3),
             'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
@@ -393,8 +463,10 @@ def main():
             'config': {'workload': f'{args.config}: {layers}-layer EGNN, channels={h}, '
                                    f'edge_radius={cfg["graph"]["edge_radius"]}A, '
                                    f'{args.batch} graphs/GPU x {cfg["graph"]["n_nodes"]} atoms, '
-                                   f'N={n_nodes} nodes E={n_edges} edges per rank, CLI-default '
-                                   f'layer flags, Adam lr 2e-3 wd 1e-4 clip 1.0, random init',
+                                   f'N={n_nodes} nodes E={n_edges} edges per rank, '
+                                   f'{flag_summary(cfg["model"])}, '
+                                   + ('torch.no_grad forward' if args.infer else
+                                      'Adam lr 2e-3 wd 1e-4 clip 1.0') + ', random init',
                        'graphs_per_gpu': args.batch, 'global_batch': world * args.batch,
                        'parallelism': f'dp{world}', 'final_loss': round(final_loss, 6),
                        'last_layer_coord_update': 'skipped (dead)' if args.skip_dead_coords else 'evaluated',
@@ -402,21 +474,22 @@ def main():
                        'inputs': (f'host ({args.host_inputs}) batch copied to the device inside every step'
                                   if args.host_inputs else 'resident in HBM')},
             'roofline': {
-                'bound': 'hbm', 'kernel': ('k_edge_bwd_mfma<1> (edge backward, one launch per layer)' if h == 32
-                                          else 'k_edge_bwd_team_parts (H=64 edge backward, one launch per layer)'),
+                'bound': 'hbm', 'kernel': dom_name,
                 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
+                'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
                 'algorithmic_bytes_per_launch': dom_bytes,
-                'avg_launch_ms': round(dom_avg_ms, 4), 'launches': bwd_n,
-                # the kernel is ALU-bound (SURVEY §8d "the fused path is fp32-MFMA-bound"): its
-                # executed HxH products (2 recompute + 2 dgrad + 2 wgrad = 12 H^2 flop/edge) against
-                # the fp32 matrix peak, beside the HBM fraction north_star asks for
-                'kernel_fp32': {'achieved': round(12.0 * h * h * n_edges / (dom_avg_ms * 1e-3) / 1e12, 2)
-                                if dom_avg_ms > 0 else 0.0, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                'frac': round(12.0 * h * h * n_edges / (dom_avg_ms * 1e-3) / 1e12
-                                              / FP32_PEAK_TFLOPS, 5) if dom_avg_ms > 0 else 0.0},
+                'avg_launch_ms': round(dom_avg_ms, 4), 'launches': dom_n,
+                # the kernel is ALU-bound, not HBM-bound: its EXECUTED products against the
+                # fp32 matrix peak, beside the HBM fraction north_star asks for. Four of the six products
+                # run as bf16x3 on the bf16 pipe, so this is an effective fp32 rate, not a utilisation:
+                # the PMC busy figures in profiles/ are the utilisation
+                'kernel_exec_fp32': {'achieved': round(dom_tflops, 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                     'frac': round(dom_tflops / FP32_PEAK_TFLOPS, 5)},
                 'step_hbm_frac': round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                'step_fp32_frac': round(step_flops / (ms_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5),
+                # executed FLOPs of the step (the P/Q split removes 4H^2 per edge per pass of the
+                # reference formulation) and, for comparison, the reference formulation's count
+                'step_exec_fp32_frac': round(exec_flops / (ms_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5),
+                'step_ref_formulation_fp32_frac': round(ref_flops / (ms_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5),
                 'kernel_ms_per_step': {
                     'edge_fwd': round(fwd_ms / prof_steps, 3),
                     'edge_bwd': round(bwd_ms / prof_steps, 3),

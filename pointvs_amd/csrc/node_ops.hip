@@ -319,7 +319,7 @@ k_adam_clip(const PvsAdamEntry* __restrict__ table, float lr, float beta1, float
          i += (long long)gridDim.x * blockDim.x) {
         float g = e.grad[i];
         if (clip > 0.f) {
-            g = fminf(fmaxf(g, -clip), clip);
+            g = (g != g) ? g : fminf(fmaxf(g, -clip), clip);   // torch.clamp propagates NaN (fminf/fmaxf drop it)
             e.grad[i] = g;                       // clip_grad_value_ is in place
         }
         const float p = e.param[i];

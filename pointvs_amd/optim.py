@@ -22,7 +22,8 @@ class FusedClipAdam(torch.optim.Adam):
     def _fusable(self):
         for group in self.param_groups:
             if group.get('amsgrad') or group.get('maximize') or group.get('capturable') \
-                    or group.get('differentiable') or isinstance(group['lr'], torch.Tensor):
+                    or group.get('differentiable') or group.get('decoupled_weight_decay') \
+                    or isinstance(group['lr'], torch.Tensor):
                 return False
             for p in group['params']:
                 if p.grad is not None and (not p.is_cuda or p.dtype != torch.float32 or p.grad.is_sparse
@@ -78,4 +79,7 @@ class FusedClipAdam(torch.optim.Adam):
                     float(group['eps']), float(group['weight_decay']), 1.0 - beta1 ** step, 1.0 - beta2 ** step,
                     float(clip_value) if clip_value is not None else 0.0,
                     torch.cuda.current_stream(dev).cuda_stream), 'pvs_adam_clip_step')
+                # the kernel wrote through raw pointers: tell autograd (and anything that caches by
+                # version, e.g. ReceptorScreen) that the parameters changed, as an in-place op would
+                torch.autograd.graph.increment_version([p for p, _ in items])
         return loss

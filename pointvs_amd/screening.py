@@ -31,9 +31,9 @@ class ReceptorScreen:
     def __init__(self, model, rec_pos, feats, n_lig, batch_size, edge_radius, intra_radius=None):
         layers = list(model.layers)
         self.model, self.embed, self.egnn = model, layers[0], layers[1:]
-        first = self.egnn[0]
-        self.reuse = (first.hidden_nf in (32, 64) and not first.softmax_attention
-                      and not first.edge_residual and len(self.egnn) > 0)
+        first = self.egnn[0] if self.egnn else None
+        self.reuse = (first is not None and first.hidden_nf in (32, 64) and not first.softmax_attention
+                      and not first.edge_residual)
         dev = rec_pos.device
         self.batcher = PoseBatcher(rec_pos, feats, n_lig, batch_size, edge_radius, intra_radius)
         self.n_lig, self.b = n_lig, batch_size
@@ -45,10 +45,24 @@ class ReceptorScreen:
         # the specialised pose-batch builder (pvs_screen_graph_build) leaves the edge counts on the
         # device; layers that return edge messages (edge_residual) need them on the host
         self.fast_graph = self.reuse and n_lig <= 64 and not any(l.edge_residual for l in self.egnn)
-        if not self.reuse:
-            return
+        self._rec_pos, self._feats = rec_pos, feats
+        if self.reuse:
+            self._cache_receptor_sums()
+
+    def _weights_fingerprint(self):
+        """Version counters of everything the cached receptor-receptor sums were computed from (the
+        embedding and the first layer): an optimiser step or load_weights() bumps them."""
+        mods = [self.embed.m, self.egnn[0]]
+        return tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
+
+    def _cache_receptor_sums(self):
+        """Per-node sums of the first layer's receptor-receptor messages (pose independent)."""
         lib = _lib.lib()
+        rec_pos, feats, first = self._rec_pos, self._feats, self.egnn[0]
+        n_lig, batch_size = self.n_lig, self.b
+        dev = rec_pos.device
         n_rec = rec_pos.shape[0]
+        self._fingerprint = self._weights_fingerprint()
         with torch.no_grad():
             feats_rec = feats[n_lig:].to(dev).float()
             h_rec = self.embed.embed(feats_rec, rec_pos)
@@ -244,6 +258,12 @@ class ReceptorScreen:
         model = self.model
         if not self.reuse:
             return model(self.batcher.load(lig_poses))
+        if self._fingerprint != self._weights_fingerprint():
+            # the weights changed under the screen (load_weights(), a training step): the cached sums
+            # are stale - recompute them once (never inside a captured graph, which bakes them in)
+            if torch.cuda.is_current_stream_capturing() or getattr(self, '_graph', None) is not None:
+                raise RuntimeError('ReceptorScreen: the model\'s weights changed after capture(); build a new screen')
+            self._cache_receptor_sums()
         if self.fast_graph:
             pg_full, g_lig = self._build_fast(lig_poses)
             batch = self.batcher.batch

@@ -12,6 +12,11 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu via gpurun)')
+    # The multi-process GPU test forks its ranks from a fork server. Start that server NOW, before
+    # anything in this process initialises HIP: a process that has touched the GPU must never be
+    # forked into ranks or exec another program (the pool's machines do not survive it).
+    import multiprocessing.forkserver as forkserver
+    forkserver.ensure_running()
 
 
 def pytest_collection_modifyitems(config, items):

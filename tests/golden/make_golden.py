@@ -98,8 +98,28 @@ def clone_graph(g):
                  lig_fname=g.lig_fname, rec_fname=g.rec_fname)
 
 
+def config1_graphs():
+    """BASELINE config 1 / the README working example (README.md:56-65): the first batches the
+    reference's own loader yields on data/small_chembl_test (pose) and
+    data/multi_classification_sample (affinity) with the CLI defaults of point_vs.py:108-121
+    (radius 10, edge_radius 4, no --compact => 22 input features, no --estimate_bonds)."""
+    common = dict(
+        dataset_class=PygPointCloudDataset, batch_size=3, compact=False, radius=10,
+        use_atomic_numbers=False, rot=False, polar_hydrogens=False, fname_suffix='parquet',
+        edge_radius=4.0, estimate_bonds=False, prune=False, extended_atom_types=False,
+        include_strain_info=False, mode='val')
+    pose = next(iter(get_data_loader(
+        Path('data/small_chembl_test'), types_fname=Path('data/small_chembl_test.types'),
+        model_task='classification', **common)))
+    affinity = next(iter(get_data_loader(
+        Path('data/multi_classification_sample'),
+        types_fname=Path('data/multi_classification_sample.types'), model_task='regression',
+        **common)))
+    return pose, affinity
+
+
 def run_case(name, graph, cls, kwargs, task='classification', lr=2e-3, wd=1e-4, seed=2,
-             sd_from=None, with_grads=True, with_adam=False):
+             sd_from=None, with_grads=True, with_adam=False, use_labels=False):
     torch.manual_seed(seed)
     np.random.seed(seed)
     kw = dict(kwargs)
@@ -131,7 +151,9 @@ def run_case(name, graph, cls, kwargs, task='classification', lr=2e-3, wd=1e-4, 
     y_pred, y_true, _, _ = model.unpack_input_data_and_predict(g)
     for h_ in handles:
         h_.remove()
-    if task == 'classification':
+    if use_labels:
+        y_true = y_true.reshape(-1).float()   # the labels the loader read from the types file
+    elif task == 'classification':
         y_true = torch.ones_like(y_pred)  # BCE against y=1
     else:
         y_true = torch.full_like(y_pred, 6.5)
@@ -288,6 +310,22 @@ def main():
              var(k=64, normalize=True, tanh=True, edge_attention=True, residual=True), with_adam=True)
     run_case('c4_k64_softmax_g5', g5, SartorrasEGNN,
              var(k=64, edge_attention=True, softmax_attention=True, node_attention=True))
+    # C5: BASELINE config 1 = the README example: `multitask ... --model_task both --layers 3` on the
+    # reference's real data through its own loader, every model kwarg as point_vs.py:189-221 sets it
+    pose, affinity = config1_graphs()
+    readme_kwargs = {
+        'act': 'relu', 'bn': True, 'cache': False, 'ds_frac': 1.0, 'k': 32, 'num_layers': 3,
+        'dropout': 0.0, 'dim_input': 22, 'dim_output': 1, 'norm_coords': False,
+        'norm_feats': False, 'thin_mlps': False, 'edge_attention': False, 'attention': False,
+        'tanh': False, 'normalize': False, 'residual': False, 'edge_residual': False,
+        'graphnorm': False, 'multi_fc': False, 'update_coords': True, 'node_final_act': False,
+        'permutation_invariance': False, 'attention_activation_fn': 'sigmoid',
+        'node_attention': False, 'gated_residual': False, 'rezero': False,
+        'include_strain_info': False, 'final_softplus': False, 'softmax_attention': False}
+    run_case('c5_config1_pose_real3', pose, MultitaskSatorrasEGNN, readme_kwargs,
+             use_labels=True, with_adam=True)
+    run_case('c5_config1_affinity_real3', affinity, MultitaskSatorrasEGNN, readme_kwargs,
+             task='regression', use_labels=True, sd_from='c5_config1_pose_real3')
     run_case('c4_k32_softmax_edgeres_g4', g4, SartorrasEGNN,
              var(k=32, edge_attention=True, softmax_attention=True, edge_residual=True, residual=True,
                  num_layers=3))

@@ -203,6 +203,111 @@ def test_overlapped_allreduce_matches_flat_gloo_world2():
         assert ga is None or torch.equal(ga, gb)
 
 
+def _accum_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, str(ROOT))
+        from pointvs_amd.distributed import GradAllReducer, OverlappedGradAllReducer
+        res = {}
+        n_local = 3 if rank == 0 else 2          # uneven shards: 5 "graphs" over 2 ranks
+        for name in ('flat', 'overlap_nosync', 'overlap_double'):
+            torch.manual_seed(0)
+            net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.SiLU(), torch.nn.Linear(8, 1))
+            params = list(net.parameters())
+            red = GradAllReducer(params) if name == 'flat' else OverlappedGradAllReducer(params)
+            steps = []
+            for step in range(3):
+                for p in params:
+                    p.grad = None
+                xs = [torch.randn(n_local, 6, generator=torch.Generator().manual_seed(100 * step + 10 * rank + k))
+                      for k in range(2)]           # two micro-batches per optimiser step
+                if name == 'overlap_nosync':
+                    with red.no_sync():
+                        net(xs[0]).square().mean().backward()
+                    net(xs[1]).square().mean().backward()
+                else:                              # 'overlap_double': second backward without no_sync()
+                    net(xs[0]).square().mean().backward()
+                    net(xs[1]).square().mean().backward()
+                red(weight=n_local)
+                steps.append([p.grad.clone() for p in params])
+            res[name] = steps
+        # what single-process training on the global batch would give: mean over all 5 rows of each
+        # micro-batch, summed over the two micro-batches
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.SiLU(), torch.nn.Linear(8, 1))
+        single = []
+        for step in range(3):
+            net.zero_grad()
+            for k in range(2):
+                x = torch.cat([torch.randn(n, 6, generator=torch.Generator().manual_seed(100 * step + 10 * r + k))
+                               for r, n in ((0, 3), (1, 2))])
+                net(x).square().mean().backward()
+            single.append([p.grad.clone() for p in net.parameters()])
+        res['single'] = single
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_accumulation_and_uneven_shards_gloo_world2():
+    """(1) a second backward before reducer() must not drop gradients, with and without
+    no_sync(); (2) ranks holding 3 and 2 graphs give the gradient of the GLOBAL mean loss."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_accum_worker, args=(2, port, out), nprocs=2, join=True)
+    for rank in range(2):
+        for name in ('flat', 'overlap_nosync', 'overlap_double'):
+            for got, want in zip(out[rank][name], out[rank]['single']):
+                for a, b in zip(got, want):
+                    assert torch.allclose(a, b, atol=1e-6), name
+
+
+def _mismatch_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, str(ROOT))
+        from pointvs_amd.distributed import OverlappedGradAllReducer
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.SiLU(), torch.nn.Linear(4, 1))
+        extra = torch.nn.Parameter(torch.zeros(2))
+        params = list(net.parameters()) + [extra]
+        red = OverlappedGradAllReducer(params)
+        raised = []
+        for step in range(3):
+            for p in params:
+                p.grad = None
+            y = net(torch.randn(3, 4)).sum()
+            if step == 2 and rank == 1:          # only rank 1's gradient set changes
+                y = y + extra.sum()
+            y.backward()
+            try:
+                red()
+                raised.append(False)
+            except RuntimeError:
+                raised.append(True)
+        out[rank] = raised
+    finally:
+        dist.destroy_process_group()
+
+
+def test_changed_gradient_set_raises_on_every_rank_gloo_world2():
+    """the 'set of parameters changed' error must reach all ranks (no hang)."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_mismatch_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out[0] == [False, False, True] and out[1] == [False, False, True]
+
+
 def test_fused_clip_adam_falls_back_to_torch_on_cpu_tensors():
     """No GPU here: FusedClipAdam must behave exactly like clip_grad_value_ + torch.optim.Adam."""
     from pointvs_amd.optim import FusedClipAdam
@@ -221,3 +326,27 @@ def test_fused_clip_adam_falls_back_to_torch_on_cpu_tensors():
     for pa, pb in zip(a, b):
         assert torch.equal(pa, pb)
     assert set(oa.state_dict()['state'][0]) == set(ob.state_dict()['state'][0])
+
+
+def test_rank_sampler_shards_one_seeded_draw():
+    """data_loaders.py:181-186 under data parallelism: the union of the ranks' shares is the draw a
+    single process's WeightedRandomSampler makes with the same generator; equal length on all ranks."""
+    from pointvs_amd.data_loaders import GraphLoader, RankWeightedSampler, class_balance_weights
+    from pointvs_amd.synthetic import synthetic_graph
+    labels = [0] * 9 + [1] * 4
+    w = class_balance_weights(labels)
+    assert torch.allclose(w[:9], torch.full((9,), 1 / 9, dtype=torch.double)) and float(w[-1]) == 0.25
+    assert class_balance_weights([1, 1, 1]) is None
+    ranks = [RankWeightedSampler(w, rank=r, world=3, seed=11) for r in range(3)]
+    for epoch in (0, 1):
+        for s in ranks:
+            s.set_epoch(epoch)
+        ref = list(torch.utils.data.WeightedRandomSampler(
+            w, len(w), generator=torch.Generator().manual_seed(11 + epoch)))
+        shares = [list(s) for s in ranks]
+        assert len({len(x) for x in shares}) == 1 and len(shares[0]) == len(ranks[0]) == 5
+        padded = ref + ref[:2]
+        assert all(shares[r] == padded[r::3] for r in range(3))
+    data = [synthetic_graph(s, n_nodes=40, n_lig=4, edge_radius=5.0) for s in range(13)]
+    batches = list(GraphLoader(data, batch_size=2, sampler=ranks[0]))
+    assert [b.num_graphs for b in batches] == [2, 2, 1] and len(GraphLoader(data, 2, ranks[0])) == 3
