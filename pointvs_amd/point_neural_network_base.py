@@ -10,6 +10,8 @@ plain logging.
 """
 import math
 import os
+import re
+import sys
 import time
 from abc import abstractmethod
 from collections import OrderedDict
@@ -130,13 +132,21 @@ class PointNeuralNetworkBase(nn.Module):
         return init_epoch, time.time()
 
     def train_model(self, data_loader, epochs=1, epoch_end_validation_set=None, top1_on_end=False):
+        """Training loop (:136-205): per batch predict + backprop, per epoch checkpoint (+ optional
+        validation, :470-490). No host synchronisation inside the loop: losses are drained every
+        `log_interval` steps."""
         init_epoch, _ = self.training_setup(data_loader=data_loader, epochs=epochs)
         losses = []
-        for _ in range(init_epoch, epochs):
+        sampler = getattr(data_loader, 'sampler', None)
+        for epoch in range(init_epoch, epochs):
             self.train()
+            if hasattr(sampler, 'set_epoch'):      # per-rank seeded draw (pointvs_amd/data_loaders.py)
+                sampler.set_epoch(epoch)
             pending = []
             for self.batch, graph in enumerate(data_loader):
                 y_pred, y_true, _, _ = self.unpack_input_data_and_predict(graph)
+                if hasattr(self.grad_sync, 'set_weight'):     # uneven shards: weight by local graphs
+                    self.grad_sync.set_weight(float(y_pred.numel()))
                 pending.append(self.backprop(y_true, y_pred, sync=False))
                 if self.scheduler is not None:
                     self.scheduler.step()
@@ -151,27 +161,37 @@ class PointNeuralNetworkBase(nn.Module):
                 self.p_epoch += 1
             if not self.only_save_best_models:
                 self.save()
+            if epoch_end_validation_set is not None:
+                done = self.a_epoch if 'regression' in self.model_task else self.p_epoch
+                fname = Path(self.predictions_file.parent, f'predictions_epoch_{done}.txt')
+                best = self.val(epoch_end_validation_set, predictions_file=fname, top1_on_end=top1_on_end)
+                if self.only_save_best_models and best:
+                    self.save()
         return losses
 
     @torch.no_grad()
     def val(self, data_loader, predictions_file=None, top1_on_end=False, rich_ctx=None):
-        """Inference loop; writes `<label> | <prediction> <receptor> <ligand>` lines like the
-        reference's predictions file (:287-325, simplified)."""
+        """Inference loop (:208-360): writes `<save_path>/<pose|affinity>_<predictions file name>` in
+        the reference's line format. The loop never waits for the host: scores leave the device
+        through pinned buffers and a writer thread formats and appends them every `log_interval`
+        batches, as the reference's write_predictions does (pointvs_amd/predictions.py).
+        Returns True like the reference (top-1 / Pearson model selection is analysis code outside
+        the path)."""
+        from .predictions import PredictionsWriter
         predictions_file = Path(predictions_file or self.predictions_file)
-        lines = []
+        predictions_file = (predictions_file.parent /
+                            f'{self.model_task_for_fnames}_{predictions_file.name}').expanduser()
         self.eval()
-        held = []      # predictions stay on the device until the loop is over: no sync per batch
-        for self.batch, graph in enumerate(data_loader):
-            y_pred, y_true, ligands, receptors = self.unpack_input_data_and_predict(graph)
-            if self.model_task == 'classification':
-                y_pred = torch.sigmoid(y_pred)
-            held.append((y_true.reshape(-1), y_pred.reshape(-1), ligands, receptors))
-        for y_true, y_pred, ligands, receptors in held:
-            for yt, yp, lig, rec in zip(y_true.tolist(), y_pred.tolist(), ligands, receptors):
-                lines.append(f'{yt:.3f} | {yp:.3f} {rec} {lig}')
-        predictions_file.parent.mkdir(parents=True, exist_ok=True)
-        predictions_file.write_text('\n'.join(lines) + '\n')
-        return lines
+        self.val_iter = 0
+        with PredictionsWriter(predictions_file, self.model_task, flush_every=self.log_interval) as writer:
+            for self.batch, graph in enumerate(data_loader):
+                self.val_iter += 1
+                y_pred, y_true, ligands, receptors = self.unpack_input_data_and_predict(graph)
+                if self.model_task == 'classification':
+                    y_pred = torch.sigmoid(y_pred)
+                writer.submit(y_pred, y_true, receptors, ligands)
+        self.last_predictions_file = predictions_file
+        return True
 
     def save(self, save_path=None):
         epoch = self.a_epoch if 'regression' in self.model_task else self.p_epoch
@@ -195,20 +215,39 @@ class PointNeuralNetworkBase(nn.Module):
         return out
 
     def load_weights(self, checkpoint_file, silent=False):
+        """Restore a checkpoint written by save() or by the reference (:528-565). Same-task
+        checkpoints restore weights, optimiser state and epoch counters; a checkpoint of the OTHER
+        task (per the model_kwargs.yaml two levels above it) only has its tensors copied by name,
+        leaving optimiser and epochs alone, as the reference does. Legacy key names
+        (`edge_attention_mlp`, `node_attention_mlp`, the 4-element `att_mlp` Sequential with its
+        Linear at index 2) are tried only after a plain strict load fails."""
         checkpoint_file = Path(checkpoint_file).expanduser()
         if checkpoint_file.is_dir():
             found = sorted(checkpoint_file.glob('**/*.pt'), key=lambda p: p.stat().st_mtime)
             checkpoint_file = found[-1]
         checkpoint = torch.load(str(checkpoint_file), map_location=DEVICE)
-        state = self._transform_names(checkpoint['model_state_dict'])
-        # older checkpoints hold att_mlp as a 4-element Sequential (Linear at index 2, :540-546)
-        state = OrderedDict((k.replace('att_mlp.2.', 'att_mlp.0.'), v) for k, v in state.items())
-        self.load_state_dict(state)
+        state = checkpoint['model_state_dict']
+        kwargs_file = checkpoint_file.parents[1] / 'model_kwargs.yaml' if len(checkpoint_file.parents) > 1 else None
+        ckpt_task = self.model_task
+        if kwargs_file is not None and kwargs_file.is_file():
+            ckpt_task = (yaml.safe_load(kwargs_file.read_text()) or {}).get('model_task', 'classification')
+        if ckpt_task != self.model_task:
+            own = self.state_dict()
+            for name, value in state.items():
+                own[name].copy_(value)
+            return
+        try:
+            self.load_state_dict(state)
+        except RuntimeError:
+            renamed = self._transform_names(state)
+            # the older 4-element att_mlp Sequential: Linear at index 2 (anchored: not node_att_mlp)
+            renamed = OrderedDict((re.sub(r'(^|\.)att_mlp\.2\.', r'\1att_mlp.0.', k), v) for k, v in renamed.items())
+            self.load_state_dict(renamed)
         if 'optimiser_state_dict' in checkpoint:
             try:
                 self.optimiser.load_state_dict(checkpoint['optimiser_state_dict'])
-            except ValueError:
-                pass
+            except ValueError as exc:     # e.g. a checkpoint of a model with a different parameter list
+                print(f'pointvs_amd: optimiser state of {checkpoint_file} not restored ({exc})', file=sys.stderr)
         self.p_epoch = checkpoint.get('p_epoch', checkpoint.get('epoch', 0))
         self.a_epoch = checkpoint.get('a_epoch', 0)
 

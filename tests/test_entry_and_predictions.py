@@ -1,0 +1,80 @@
+"""Boundary pieces around the path that need no GPU: the reference CLI surface of point_vs.py /
+point_vs.parse_args, the reference import paths (point_vs.models.geometric.*), and the predictions
+file the validation loop writes, pinned on a file written by the reference's own val()."""
+import argparse
+import importlib
+import json
+from pathlib import Path
+
+import numpy as np
+import torch
+
+GOLDEN = Path(__file__).resolve().parent / 'golden'
+
+
+def test_cli_flags_match_the_reference_parser():
+    """Every option string, type, default and store_true switch of
+    /root/reference/point_vs/parse_args.py:6-236 (captured as data by make_golden_cli.py)."""
+    from point_vs.parse_args import build_parser
+    ref = json.loads((GOLDEN / 'cli_flags.json').read_text())['flags']
+    mine = {a.dest: a for a in build_parser()._actions if not isinstance(a, argparse._HelpAction)}
+    assert len(ref) == 76
+    for f in ref:
+        a = mine[f['dest']]
+        assert sorted(list(a.option_strings) or [a.dest]) == sorted(f['names']), f['dest']
+        assert a.default == f['default'], f['dest']
+        assert (None if a.type is None else a.type.__name__) == f['type'], f['dest']
+        assert isinstance(a, argparse._StoreTrueAction) == f['store_true'], f['dest']
+    assert set(mine) - {f['dest'] for f in ref} == {'synthetic_graphs', 'synthetic_atoms'}
+
+
+def test_readme_command_line_maps_to_the_reference_model_kwargs():
+    """The README example's flags -> build_net kwargs as point_vs.py:189-221 derives them; the
+    expected dict is the `kwargs` recorded in the config-1 golden (made from the reference)."""
+    import point_vs as entry_pkg   # the package (directory) shadows the script, as in the reference
+    spec = importlib.util.spec_from_file_location('pvs_entry', Path(entry_pkg.__file__).parents[1] / 'point_vs.py')
+    entry = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(entry)
+    from point_vs.parse_args import parse_args
+    args = parse_args(['multitask', '/tmp/x', '--model_task', 'both', '-ea', '1', '-ep', '1', '--layers', '3'])
+    kw = entry.model_kwargs_from_args(args, 22, 'regression')
+    kw['model_task'] = 'classification'         # point_vs.py:223-224 for --model_task both
+    want = json.loads(str(np.load(GOLDEN / 'c5_config1_pose_real3.npz')['cfg']))['kwargs']
+    assert {k: kw[k] for k in want} == want
+
+
+def test_reference_import_paths_resolve_to_the_hip_classes():
+    import pointvs_amd.egnn_multitask as mt
+    import pointvs_amd.egnn_satorras as sat
+    assert importlib.import_module('point_vs.models.geometric.egnn_satorras').EGNNLayer is sat.EGNNLayer
+    assert importlib.import_module('point_vs.models.geometric.egnn_satorras').SartorrasEGNN is sat.SartorrasEGNN
+    assert importlib.import_module('point_vs.models.geometric.egnn_multitask').MultitaskSatorrasEGNN \
+        is mt.MultitaskSatorrasEGNN
+    base = importlib.import_module('point_vs.models.geometric.pnn_geometric_base')
+    assert base.PygLinearPass.__module__ == 'pointvs_amd.pnn_geometric_base'
+    assert importlib.import_module('point_vs.models.point_neural_network_base').PointNeuralNetworkBase
+    assert importlib.import_module('point_vs.global_objects').DEVICE is not None
+
+
+def test_predictions_writer_reproduces_the_reference_file(tmp_path):
+    """Feeding the reference model's raw outputs through the streaming writer gives the file the
+    reference's val() wrote, byte for byte (line format :287-325, periodic append :492-499)."""
+    from pointvs_amd.predictions import PredictionsWriter
+    ref = json.loads((GOLDEN / 'predictions_reference.json').read_text())
+    for tag, rec in ref.items():
+        path = tmp_path / rec['file_name']
+        with PredictionsWriter(path, rec['task'], flush_every=2) as w:
+            for b in rec['batches']:
+                y = torch.tensor(b['y_pred'])
+                w.submit(torch.sigmoid(y) if rec['task'] == 'classification' else y, torch.tensor(b['y_true']),
+                         b['receptors'], b['ligands'])
+        assert path.read_text() == rec['text'], tag
+        assert w.lines_written == 7
+
+
+def test_prediction_line_formats_without_labels_and_multi_target():
+    from pointvs_amd.predictions import format_lines
+    assert format_lines('classification', [0.25], None, ['r'], ['l']) == ['0.250 | r l']
+    assert format_lines('multi_regression', [[1, 2, 3]], None, ['r'], ['l']) == ['1.000 2.000 3.000 | r l']
+    got = format_lines('multi_regression', [[1, 2, 3], [4, 5, 6]], [[-1, 7, -1], [8, -1, -1]], ['ra', 'rb'], ['la', 'lb'])
+    assert got == ['7.000 | 2.000 ra la | pkd', '8.000 | 4.000 rb lb | pki']

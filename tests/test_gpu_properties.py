@@ -402,9 +402,38 @@ def test_train_and_val_entry_points(tmp_path):
     losses = model.train_model(loader, epochs=2)
     assert len(losses) == 4 and all(np.isfinite(losses))
     assert not torch.equal(before, model.layers[1].edge_mlp[0].weight.detach())
-    lines = model.val(loader, predictions_file=tmp_path / 'pred.txt')
-    assert len(lines) == 6 and (tmp_path / 'pred.txt').read_text().count('\n') == 6
+    assert model.val(loader, predictions_file=tmp_path / 'pred.txt') is True
+    text = (tmp_path / 'pose_pred.txt').read_text()      # <task>_<name>, point_neural_network_base.py:223-224
+    assert text.count('\n') == 6
+    with torch.no_grad():                                  # the file holds sigmoid(model(batch)), in order
+        want = torch.cat([torch.sigmoid(model(b.to('cuda')).reshape(-1)) for b in loader]).cpu().tolist()
+    for line, g, p in zip(text.splitlines(), gs, want):
+        assert line == f'{int(g.y):.3f} | {p:.3f} {g.rec_fname} {g.lig_fname}'
     assert (tmp_path / 'm' / 'checkpoints' / 'pose_ckpt_epoch_2.pt').exists()
+
+
+def test_point_vs_entry_runs_the_readme_sequence_on_synthetic_graphs(tmp_path):
+    """`point_vs.py multitask <dir> --model_task both -ea 1 -ep 1 --layers 3` (README.md:56-65) on
+    synthetic graphs: pose training -> pose validation -> affinity training -> affinity validation,
+    with the reference's records in save_path (point_vs.py:85-86, 258-275)."""
+    import importlib.util
+    import yaml
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location('pvs_entry', root / 'point_vs.py')
+    entry = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(entry)
+    model = entry.main(['multitask', str(tmp_path / 'run'), '--model_task', 'both', '-ea', '1', '-ep', '1',
+                        '--layers', '3', '--synthetic_graphs', '12', '--synthetic_atoms', '150', '-b', '4',
+                        '--edge_radius', '6', '--end_flag'])
+    run = tmp_path / 'run'
+    assert yaml.safe_load((run / 'cmd_args.yaml').read_text())['layers'] == 3
+    assert yaml.safe_load((run / 'model_kwargs.yaml').read_text())['model_task'] == 'classification'
+    assert (run / 'checkpoints' / 'pose_ckpt_epoch_1.pt').exists()
+    assert (run / 'checkpoints' / 'affinity_ckpt_epoch_1.pt').exists()
+    assert (run / 'pose_predictions.txt').read_text().count('\n') == 12
+    assert (run / 'affinity_predictions.txt').read_text().count('\n') == 12
+    assert (run / '_FINISHED').exists()
+    assert model.model_task == 'regression' and model.p_epoch == 1 and model.a_epoch == 1
 
 
 @pytest.mark.parametrize('seed', range(8))
