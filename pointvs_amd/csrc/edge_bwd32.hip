@@ -1,0 +1,527 @@
+// H = 32 edge backward with EVERY product on the bf16 matrix pipe ("bf16x3", edge_mfma_common.h).
+//
+// k_edge_bwd_mfma (edge_mfma.hip) runs the two weight-gradient products  gW2 = sum_e g_z2 (x) a1,
+// gWc1 = sum_e g_zc (x) m  as fp32 MFMAs (v_mfma_f32_32x32x2_f32): 2048 of its 3584 matrix cycles per
+// tile, and those never co-execute with VALU work (PMC), so with two waves per SIMD they
+// are pure serial time. Here both become 6-term bf16 products over the EDGE index (768 cycles per tile,
+// co-executing with the partner wave's VALU). Their operands need the edge index on the k axis, i.e.
+// the transpose of the X layout (edge on the lane, channels in the registers) everything else lives in:
+//   * activation side (a1, m): the three bf16 parts - computed anyway for the chain products - go to
+//     LDS as swizzled row-major [edge][channel] images (12 ds_write_b64) and come back as B operands
+//     through gfx950's transposing read (ds_read_b64_tr_b16), like the H = 64 parts kernel;
+//   * gradient side (g_zc, g_z2): transposed ON THE MATRIX CORE. A part in X layout is a valid A operand
+//     (lane = row = edge, registers = k = channel), so  D = part x I  (I: the 32x32 identity in the X
+//     layout's k order, a constant B operand kept in LDS) leaves  D[edge][channel]  in accumulator
+//     layout = lane: channel, registers: edges - exactly the A operand of the weight-gradient product.
+//     bf16 x 1.0 accumulated in fp32 is exact, so the parts survive bit for bit; 2 MFMAs + 8 v_perm
+//     per part. No LDS round trip, no third image slot (which 8 waves per CU could not afford).
+// The fp32 edge-major tiles of the old kernel disappear (per wave: two 6 KB images, SiLU'(z1), and the
+// g_z1 tile that reuses the dead m image). Column sums that used to ride on the fp32 tile reads (g_b2,
+// g_bc1, g_wa) are X-layout register accumulators reduced once at the end of the kernel.
+//
+// Reference semantics: autograd of EGNNLayer.edge_model / coord_model / node_model's aggregation,
+// /root/reference/point_vs/models/geometric/egnn_satorras.py:123-206 (SURVEY.md §8a "Backward spec").
+#include "edge_mfma_common.h"
+
+namespace {
+
+// acc += W v (TRANSPOSE: W^T v), v given as its three bf16 parts (B operand, X layout)
+template <bool TRANSPOSE>
+__device__ __forceinline__ void chain_parts32(const unsigned short* __restrict__ img, int lane,
+                                              const Bf16Parts& b, f32x16& acc) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const bf16x8 ah = img_fragment<1, TRANSPOSE>(img, lane, 0, 0, s);
+        const bf16x8 am = img_fragment<1, TRANSPOSE>(img + 32 * 32, lane, 0, 0, s);
+        const bf16x8 al = img_fragment<1, TRANSPOSE>(img + 2 * 32 * 32, lane, 0, 0, s);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.hi[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.lo[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.mid[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.hi[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.mid[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.hi[s], acc, 0, 0, 0);
+    }
+}
+
+// one bf16 part of a [32 edges][32 channels] tensor, X layout -> row-major image (8-byte chunks)
+__device__ __forceinline__ void write_part_image(unsigned short* __restrict__ part, int j, int hh,
+                                                 const bf16x8 (&p)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const uint4 u = __builtin_bit_cast(uint4, p[s]);
+        // registers 8s..8s+3 hold channels 16s + 4hh + (0..3), registers 8s+4..8s+7 channels 16s + 8 + 4hh + (0..3)
+        *reinterpret_cast<uint2*>(part + img_off<1>(j, 16 * s + 4 * hh)) = make_uint2(u.x, u.y);
+        *reinterpret_cast<uint2*>(part + img_off<1>(j, 16 * s + 8 + 4 * hh)) = make_uint2(u.z, u.w);
+    }
+}
+
+__device__ __forceinline__ void write_image(unsigned short* __restrict__ img, int j, int hh, const Bf16Parts& b) {
+    write_part_image(img, j, hh, b.hi);
+    write_part_image(img + 32 * 32, j, hh, b.mid);
+    write_part_image(img + 2 * 32 * 32, j, hh, b.lo);
+}
+
+// X-layout part (A operand: lane = edge) -> its transpose as the A operand of a product over the edge
+// index (lane = channel, 8 edges per k-step in the accumulator's row order), through the matrix core.
+__device__ __forceinline__ void transpose_part(const bf16x8 (&p)[2], const bf16x8 (&ident)[2], bf16x8 (&out)[2]) {
+    f32x16 t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = 0.f;
+    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p[0], ident[0], t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p[1], ident[1], t, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        uint4 u;
+        u.x = pvs_pack_hi16(t[8 * s + 0], t[8 * s + 1]);
+        u.y = pvs_pack_hi16(t[8 * s + 2], t[8 * s + 3]);
+        u.z = pvs_pack_hi16(t[8 * s + 4], t[8 * s + 5]);
+        u.w = pvs_pack_hi16(t[8 * s + 6], t[8 * s + 7]);
+        out[s] = __builtin_bit_cast(bf16x8, u);
+    }
+}
+
+// gW (D layout [c = ch(r,hh)][k = j]) += sum over the tile's edges of G[e][c] * Act[e][k]:
+// G = the gradient tensor's parts in X layout (transposed here), Act = the activation's image.
+__device__ __forceinline__ void wgrad_tile(const Bf16Parts& g, const unsigned short* __restrict__ act_img,
+                                           const unsigned* __restrict__ idt, int lane, f32x16& gW) {
+    // operands are fetched from LDS where they are used (the register file is the scarce resource here:
+    // two waves per SIMD), the compiler may keep what fits
+    bf16x8 ident[2];
+    ident[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(idt + (0 * 64 + lane) * 4));
+    ident[1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(idt + (1 * 64 + lane) * 4));
+    const unsigned short* hi = act_img;
+    const unsigned short* mid = act_img + 32 * 32;
+    const unsigned short* lo = act_img + 2 * 32 * 32;
+    bf16x8 y[2];
+    transpose_part(g.lo, ident, y);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        gW = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[s], img_fragment<1, true>(hi, lane, 0, 0, s), gW, 0, 0, 0);
+    transpose_part(g.mid, ident, y);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        gW = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[s], img_fragment<1, true>(mid, lane, 0, 0, s), gW, 0, 0, 0);
+        gW = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[s], img_fragment<1, true>(hi, lane, 0, 0, s), gW, 0, 0, 0);
+    }
+    transpose_part(g.hi, ident, y);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        gW = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[s], img_fragment<1, true>(lo, lane, 0, 0, s), gW, 0, 0, 0);
+        gW = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[s], img_fragment<1, true>(mid, lane, 0, 0, s), gW, 0, 0, 0);
+        gW = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[s], img_fragment<1, true>(hi, lane, 0, 0, s), gW, 0, 0, 0);
+    }
+}
+
+constexpr int kT32Threads = 512, kT32Waves = 8;
+constexpr int kImgShorts = 3 * 32 * 32;                        // one tensor's three part images
+constexpr int kT32WaveBytes = 2 * kImgShorts * 2 + 16 * 64 * 4;   // a1 image, m image (later the g_z1 tile), SiLU'(z1)
+constexpr int kT32TS = 36;                                     // g_z1 tile row stride (floats)
+static_assert(kTile * kT32TS * 4 + kTile * 16 + kTile * 4 <= kImgShorts * 2, "g_z1 tile + tx + rowbuf must fit the m image");
+
+template <bool ERES, bool EATT>
+__global__ void __launch_bounds__(kT32Threads, 2)
+k_edge_bwd32(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks, int e_lo, int e_hi) {
+    constexpr int H = 32, HB = 1, NT = kT32Threads, NW = kT32Waves;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* W2i = reinterpret_cast<unsigned short*>(smem);         // 3 parts x [32][32] bf16
+    unsigned short* Wc1i = W2i + kImgShorts;
+    float* b2t = smem + 2 * kImgShorts / 2;
+    float* bc1t = b2t + H;
+    float* wc2t = bc1t + H;
+    float* wat = wc2t + H;
+    float* wrhot = wat + H;
+    float* attrt = wrhot + H;                                  // [PVS_MAX_EDGE_ATTR][H]
+    unsigned* idt = reinterpret_cast<unsigned*>(attrt + PVS_MAX_EDGE_ATTR * H);   // [2 k-steps][64 lanes][4]
+    char* wave_base = reinterpret_cast<char*>(idt + 2 * 64 * 4);
+
+    const bool upd = (flags & PVS_UPDATE_COORDS) && io.gxagg != nullptr;
+
+    stage_weights_img<HB>(W2i, w.w2);
+    if (upd) stage_weights_img<HB>(Wc1i, w.wc1);
+    for (int c = threadIdx.x; c < H; c += NT) {
+        b2t[c] = w.b2[c];
+        bc1t[c] = upd ? w.bc1[c] : 0.f;
+        wc2t[c] = upd ? w.wc2[c] : 0.f;
+        wat[c] = EATT ? w.wa[c] : 0.f;
+        wrhot[c] = w.w1[c * w.ld1 + w.off_rho];
+        for (int t = 0; t < PVS_MAX_EDGE_ATTR; ++t)
+            attrt[t * H + c] = t < w.n_attr ? w.w1[c * w.ld1 + w.off_rho + 1 + t] : 0.f;
+    }
+    // identity in the X layout's k order as a B operand: lane (col, hh), k-step s, element j' is
+    // 1.0 iff channel ch(8s + j', hh) == col
+    for (int i = threadIdx.x; i < 2 * 64 * 4; i += NT) {
+        const int q = i & 3, l = (i >> 2) & 63, s = i >> 8;
+        const int col = l & 31, lh = l >> 5;
+        const unsigned lo16 = xch(8 * s + 2 * q, lh) == col ? 0x3f80u : 0u;
+        const unsigned hi16 = xch(8 * s + 2 * q + 1, lh) == col ? 0x3f80u : 0u;
+        idt[i] = lo16 | (hi16 << 16);
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    unsigned short* A1I = reinterpret_cast<unsigned short*>(wave_base + wv * kT32WaveBytes);
+    unsigned short* MI = A1I + kImgShorts;
+    float* d1b = reinterpret_cast<float*>(MI + kImgShorts);    // SiLU'(z1), X layout, lane-private
+    // once the m image is dead (after the Wc1 weight gradient) its slot holds the g_z1 tile
+    float* T1 = reinterpret_cast<float*>(MI);
+    float* tx = T1 + kTile * kT32TS;
+    int* rowbuf = reinterpret_cast<int*>(tx + kTile * 4);
+
+    const float bac = EATT ? w.ba[0] : 0.f;
+    float gate_raw = 0.f, gate = 1.f;
+    if (ERES && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
+        gate_raw = w.edge_gate[0];
+        gate = (flags & PVS_GATED_RESIDUAL) ? fmaxf(gate_raw, 0.f) : gate_raw;
+    }
+    const float res_a = (flags & (PVS_REZERO | PVS_GATED_RESIDUAL)) ? gate : 1.f;
+    const float res_b = (flags & PVS_GATED_RESIDUAL) ? 1.f - gate : 1.f;
+
+    // ---- accumulators that live for the whole kernel ----
+    f32x16 gW2, gWc1;                          // D layout: [c = ch(r,hh)][k = j]
+    float g_wc2x[16], g_b2x[16], g_bc1x[16];   // X layout (channel in the register, edges on lanes)
+    float g_wax[EATT ? 16 : 1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { gW2[r] = 0.f; gWc1[r] = 0.f; g_wc2x[r] = 0.f; g_b2x[r] = 0.f; g_bc1x[r] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < (EATT ? 16 : 1); ++r) g_wax[r] = 0.f;
+    float g_ba = 0.f, g_gate = 0.f;
+
+    const int total_waves = gridDim.x * NW;
+    for (int chunk = pvs_xcd_block(blockIdx.x, gridDim.x) * NW + wv; chunk < n_chunks; chunk += total_waves) {
+        const int e_begin = chunk_begin(g, chunk, n_chunks, e_lo, e_hi);
+        const int e_end = chunk_begin(g, chunk + 1, n_chunks, e_lo, e_hi);
+        int cur_row = -1;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accx = acc;   // open row: lane = (row slot, quad)
+        constexpr int QPR = H / 4;
+        const int quad = lane % QPR, rsub = lane / QPR;
+        auto flush = [&](int row_id) {
+            if (row_id >= 0) {
+                const float4 tot = sum_row_slots<HB>(acc);
+                if (rsub == 0) *reinterpret_cast<float4*>(io.gPQ + (size_t)row_id * 2 * H + 4 * quad) = tot;
+                const float4 tx4 = sum_row_slots<HB>(accx);
+                if (lane == 0) {
+                    io.gx_row[3 * row_id] = tx4.x;
+                    io.gx_row[3 * row_id + 1] = tx4.y;
+                    io.gx_row[3 * row_id + 2] = tx4.z;
+                }
+            }
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            accx = acc;
+        };
+        TileIdx I = load_tile_idx(g, w.n_attr, e_begin, e_begin, e_end, j);
+        for (int e0 = e_begin; e0 < e_end; e0 += kTile) {
+            const int e_next = (e0 + kTile < e_end) ? e0 + kTile : e0;
+            const TileIdx In = load_tile_idx(g, w.n_attr, e_next, e_begin, e_end, j);
+            const int e = I.e, ee = I.ee, i = I.i, ty = I.ty;
+            const bool valid = I.valid;
+            const float vm = valid ? 1.f : 0.f;
+            const unsigned bmask = (unsigned)__ballot(valid && hh == 0 && i != I.prev_row);
+            float d0, d1, d2, rho;
+            Bf16Parts pb;                     // parts of the tensor being pushed through a product
+
+            // ---- recompute: z1, a1 = SiLU(z1), SiLU'(z1) -> LDS; a1 image; z2 = W2 a1 + b2 ----
+            f32x16 acc2;
+            {
+                TileGather<HB> G;
+                gather_tile<HB>(io.PQ, io.x, I, hh, G);
+                d0 = G.d0; d1 = G.d1; d2 = G.d2;
+                rho = d0 * d0 + d1 * d1 + d2 * d2;
+                float a1[HB][16];
+                assemble_z1<HB>(G, attrt, wrhot, ty, hh, rho, a1);
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    float dd[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float z = a1[0][4 * gq + q];
+                        const float sg = pvs_sigmoid(z);
+                        const float av = z * sg;
+                        dd[q] = fmaf(av, 1.0f - sg, sg);       // SiLU'(z) = s + z s (1 - s)
+                        a1[0][4 * gq + q] = av;
+                    }
+                    *reinterpret_cast<float4*>(d1b + (gq * 64 + lane) * 4) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+                }
+                split_bf16x3(a1[0], pb);
+                write_image(A1I, j, hh, pb);
+                float bias[HB][16];
+                load_tab<HB>(b2t, hh, bias);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[r] = bias[0][r];
+                chain_parts32<false>(W2i, lane, pb, acc2);
+            }
+            float dz2[16], m[16];             // SiLU'(z2) and the message
+            float m_new[ERES ? 16 : 1], mp[ERES ? 16 : 1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float z2 = acc2[r];
+                const float sg = pvs_sigmoid(z2);
+                m[r] = z2 * sg;
+                dz2[r] = fmaf(m[r], 1.0f - sg, sg);
+                if constexpr (ERES) m_new[r] = m[r];
+            }
+            if constexpr (ERES) {
+                float mpx[HB][16];
+                load_x<HB>(io.m_prev + (size_t)ee * H, hh, mpx);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    mp[r] = mpx[0][r];
+                    m[r] = fmaf(res_a, m_new[r], res_b * mp[r]);
+                }
+            }
+
+            // ---- gradient wrt m: the coordinate branch's term comes from the matrix core first; the external,
+            // aggregated-message and attention terms are added AFTER it (g_m is then not live across the
+            // coordinate branch: 16 registers fewer where the pressure peaks) ----
+            f32x16 gm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gm[r] = 0.f;
+            auto add_row_terms = [&]() {
+                if (io.g_m_out) {
+                    float init[HB][16];
+                    load_x<HB>(io.g_m_out + (size_t)ee * H, hh, init);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gm[r] = fmaf(init[0][r], vm, gm[r]);
+                }
+                float gMi[HB][16];
+                load_x<HB>(io.gM + (size_t)i * H, hh, gMi);
+                if constexpr (EATT) {
+                    float wax[HB][16];
+                    load_tab<HB>(wat, hh, wax);
+                    float logit = 0.f, dot = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        logit = fmaf(wax[0][r], m[r], logit);
+                        dot = fmaf(m[r], gMi[0][r], dot);
+                    }
+                    logit += __shfl_xor(logit, 32, 64);
+                    dot += __shfl_xor(dot, 32, 64);
+                    logit += bac;
+                    const float aval = io.att[ee];
+                    const float g_l = (flags & PVS_SOFTMAX_ATT) ? aval * (dot - io.softD[i]) * vm   // softD = M_i . g_M_i
+                                                                : pvs_att_act_grad(att_act, logit, aval) * dot * vm;
+                    if (hh == 0) g_ba += g_l;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        gm[r] += (aval * vm) * gMi[0][r] + g_l * wax[0][r];
+                        g_wax[r] = fmaf(g_l, m[r], g_wax[r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gm[r] = fmaf(vm, gMi[0][r], gm[r]);
+                }
+            };
+            float s_coord = 0.f, nrm = 1.f;
+            float gT0 = 0.f, gT1 = 0.f, gT2 = 0.f;
+            if (upd) {
+                gT0 = io.gxagg[3 * i]; gT1 = io.gxagg[3 * i + 1]; gT2 = io.gxagg[3 * i + 2];
+                f32x16 accc;
+                {
+                    float bias2[HB][16];
+                    load_tab<HB>(bc1t, hh, bias2);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accc[r] = bias2[0][r];
+                }
+                split_bf16x3(m, pb);
+                write_image(MI, j, hh, pb);
+                chain_parts32<false>(Wc1i, lane, pb, accc);          // zc = Wc1 m + bc1
+                float wc2x[HB][16];
+                load_tab<HB>(wc2t, hh, wc2x);
+                float q[16], dq[16];
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float zc = accc[r];
+                    const float sg = pvs_sigmoid(zc);
+                    q[r] = zc * sg;
+                    dq[r] = fmaf(q[r], 1.0f - sg, sg);
+                    s = fmaf(wc2x[0][r], q[r], s);
+                }
+                s += __shfl_xor(s, 32, 64);
+                float dact = 1.f;
+                if (flags & PVS_TANH) { s = pvs_tanh(s); dact = 1.f - s * s; }
+                if (flags & PVS_NORMALIZE) nrm = 1.f / (sqrtf(rho) + 1e-8f);
+                s_coord = s;
+                const float g_s = (d0 * gT0 + d1 * gT1 + d2 * gT2) * nrm * dact * vm;
+                float g_zc[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    g_zc[r] = g_s * wc2x[0][r] * dq[r];
+                    g_wc2x[r] = fmaf(g_s, q[r], g_wc2x[r]);
+                    g_bc1x[r] += g_zc[r];
+                }
+                split_bf16x3(g_zc, pb);
+                chain_parts32<true>(Wc1i, lane, pb, gm);             // g_m += Wc1^T g_zc
+                pvs_wave_lds_sync();                                  // the m image is complete
+                wgrad_tile(pb, MI, idt, lane, gWc1);               // gWc1 += g_zc (x) m over the tile's edges
+            }
+            add_row_terms();
+            // ---- edge residual; g_z2 = g_m_new * SiLU'(z2) ----
+            float g_z2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float gmv = gm[r];
+                float gnew = gmv;
+                if constexpr (ERES) {
+                    if (flags & PVS_REZERO) {
+                        gnew = gate * gmv;
+                        g_gate = fmaf(gmv, m_new[r], g_gate);
+                        mp[r] = gmv;
+                    } else if (flags & PVS_GATED_RESIDUAL) {
+                        gnew = gate * gmv;
+                        if (gate_raw > 0.f) g_gate = fmaf(gmv, m_new[r] - mp[r], g_gate);
+                        mp[r] = (1.f - gate) * gmv;
+                    } else {
+                        mp[r] = gmv;
+                    }
+                }
+                g_z2[r] = gnew * dz2[r];
+                g_b2x[r] += g_z2[r];
+            }
+            if constexpr (ERES) {
+                if (valid) {
+                    float mpx[HB][16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mpx[0][r] = mp[r];
+                    store_x<HB>(io.g_m_prev + (size_t)e * H, hh, mpx);
+                }
+            }
+            // ---- g_a1 = W2^T g_z2 ; gW2 += g_z2 (x) a1 ; g_z1 = g_a1 * SiLU'(z1) ----
+            split_bf16x3(g_z2, pb);
+            f32x16 ga1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ga1[r] = 0.f;
+            chain_parts32<true>(W2i, lane, pb, ga1);
+            if (!upd) pvs_wave_lds_sync();                            // (a1 image: no earlier sync on this path)
+            wgrad_tile(pb, A1I, idt, lane, gW2);
+            float g_z1[HB][16];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 dd = *reinterpret_cast<const float4*>(d1b + (gq * 64 + lane) * 4);
+                g_z1[0][4 * gq] = ga1[4 * gq] * dd.x;
+                g_z1[0][4 * gq + 1] = ga1[4 * gq + 1] * dd.y;
+                g_z1[0][4 * gq + 2] = ga1[4 * gq + 2] * dd.z;
+                g_z1[0][4 * gq + 3] = ga1[4 * gq + 3] * dd.w;
+            }
+            const float g_rho = dot_tab<HB>(wrhot, hh, g_z1);
+            const float k1 = s_coord * nrm * vm;
+            const float gd0 = fmaf(k1, gT0, 2.f * d0 * g_rho);
+            const float gd1 = fmaf(k1, gT1, 2.f * d1 * g_rho);
+            const float gd2 = fmaf(k1, gT2, 2.f * d2 * g_rho);
+            pvs_wave_lds_sync();          // every read of the m image (its slot becomes the g_z1 tile) is done
+            // per edge: grad wrt (x_row - x_col) and rho, 16 B, for the node gather kernel
+            if (hh == 0) {
+                *reinterpret_cast<float4*>(tx + j * 4) = make_float4(gd0, gd1, gd2, 0.f);
+                rowbuf[j] = i;
+                if (valid)
+                    pvs_store_nt(io.gd + (size_t)e * 4, make_float4(gd0, gd1, gd2, pvs_pack_rho_type(rho, ty)));
+            }
+            // ---- g_z1 edge-major, then whole 128-B rows to HBM + the row-side sums from the same reads ----
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *reinterpret_cast<float4*>(T1 + j * kT32TS + 8 * gq + 4 * hh) =
+                    make_float4(g_z1[0][4 * gq], g_z1[0][4 * gq + 1], g_z1[0][4 * gq + 2], g_z1[0][4 * gq + 3]);
+            pvs_wave_lds_sync();
+            reduce_rows_tile<HB>(T1, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
+                                 [&](int rl, int q, const float4& v) {
+                                     if (e0 + rl < e_end)   // streamed once: non-temporal
+                                         pvs_store_nt(io.gz1 + (size_t)(e0 + rl) * H + 4 * q, v);
+                                 });
+            I = In;
+            pvs_wave_lds_sync();
+        }
+        flush(cur_row);
+    }
+
+    // ---- block reduction into one slab, fixed order ----
+    const PvsSlabLayout L = pvs_slab_layout(H);
+    __syncthreads();
+    float* slab = smem;
+    for (int i = threadIdx.x; i < L.total; i += NT) slab[i] = 0.f;
+    __syncthreads();
+    // X-layout vectors: sum over the 32 edge lanes of each half
+    auto lanes32 = [](float v) {
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        g_wc2x[r] = lanes32(g_wc2x[r]);
+        g_b2x[r] = lanes32(g_b2x[r]);
+        g_bc1x[r] = lanes32(g_bc1x[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < (EATT ? 16 : 1); ++r) g_wax[r] = lanes32(g_wax[r]);
+    g_ba += __shfl_xor(g_ba, 32, 64);          // only hh == 0 lanes accumulated
+    g_ba = lanes32(g_ba);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) g_gate += __shfl_xor(g_gate, o, 64);
+    for (int turn = 0; turn < NW; ++turn) {
+        if (wv == turn) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = xch(r, hh);
+                slab[L.w2 + c * H + j] += gW2[r];
+                slab[L.wc1 + c * H + j] += gWc1[r];
+            }
+            if (j == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = xch(r, hh);
+                    slab[L.wc2 + c] += g_wc2x[r];
+                    slab[L.b2 + c] += g_b2x[r];
+                    slab[L.bc1 + c] += g_bc1x[r];
+                    if constexpr (EATT) slab[L.wa + c] += g_wax[r];
+                }
+            }
+            if (lane == 0) { slab[L.ba] += g_ba; slab[L.gate] += g_gate; }
+        }
+        __syncthreads();
+    }
+    float* dst = io.slabs + (size_t)blockIdx.x * L.total;
+    for (int i = threadIdx.x; i < L.total; i += NT) dst[i] = slab[i];
+}
+
+}  // namespace
+
+// Same contract as pvs_launch_edge_bwd_mfma (edge_mfma.hip) for H = 32.
+int pvs_launch_edge_bwd32(hipStream_t s, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags, int att_act,
+                          const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs) {
+    PVS_REQUIRE(w.n_attr <= 3, "MFMA edge backward supports up to 3 edge classes (got %d)", w.n_attr);
+    *n_slabs = 0;
+    if (e_hi <= e_lo) return 0;
+    constexpr int nw = kT32Waves;
+    int blocks, n_chunks;
+    {
+        const int E = e_hi - e_lo;
+        long long b = ((long long)E + (long long)nw * 512 - 1) / ((long long)nw * 512);   // fill the chip first
+        if (b < 1) b = 1;
+        if (b > 256) b = 256;
+        const long long waves = b * nw;
+        long long per_wave = ((long long)E + waves * 4096 - 1) / (waves * 4096);
+        if (per_wave < 1) per_wave = 1;
+        blocks = (int)b;
+        n_chunks = (int)(waves * per_wave);
+    }
+    *n_slabs = blocks;
+    PvsProfScope prof(s, PVS_PROF_EDGE_BWD);
+    const PvsSlabLayout L = pvs_slab_layout(32);
+    size_t lds = (size_t)2 * kImgShorts * 2 + (5 + PVS_MAX_EDGE_ATTR) * 32 * 4 + 2 * 64 * 16 +
+                 (size_t)nw * kT32WaveBytes;
+    if (lds < (size_t)L.total * 4) lds = (size_t)L.total * 4;
+    const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
+    const bool eatt = flags & PVS_EDGE_ATTENTION;
+#define PVS_BWD32_LAUNCH(ER, EA)                                                                         \
+    do {                                                                                                \
+        if (set_lds(k_edge_bwd32<ER, EA>, lds)) return -2;                                              \
+        k_edge_bwd32<ER, EA><<<blocks, kT32Threads, lds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi); \
+    } while (0)
+    if (eres && eatt) PVS_BWD32_LAUNCH(true, true);
+    else if (eres) PVS_BWD32_LAUNCH(true, false);
+    else if (eatt) PVS_BWD32_LAUNCH(false, true);
+    else PVS_BWD32_LAUNCH(false, false);
+#undef PVS_BWD32_LAUNCH
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
