@@ -276,6 +276,8 @@ k_edge_bwd32(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO i
             f32x16 gm;
 #pragma unroll
             for (int r = 0; r < 16; ++r) gm[r] = 0.f;
+            float gMi[HB][16];
+            auto load_row_terms = [&]() { load_x<HB>(io.gM + (size_t)i * H, hh, gMi); };
             auto add_row_terms = [&]() {
                 if (io.g_m_out) {
                     float init[HB][16];
@@ -283,8 +285,6 @@ k_edge_bwd32(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO i
 #pragma unroll
                     for (int r = 0; r < 16; ++r) gm[r] = fmaf(init[0][r], vm, gm[r]);
                 }
-                float gMi[HB][16];
-                load_x<HB>(io.gM + (size_t)i * H, hh, gMi);
                 if constexpr (EATT) {
                     float wax[HB][16];
                     load_tab<HB>(wat, hh, wax);
@@ -351,9 +351,12 @@ k_edge_bwd32(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO i
                     g_bc1x[r] += g_zc[r];
                 }
                 split_bf16x3(g_zc, pb);
-                chain_parts32<true>(Wc1i, lane, pb, gm);             // g_m += Wc1^T g_zc
                 pvs_wave_lds_sync();                                  // the m image is complete
-                wgrad_tile(pb, MI, idt, lane, gWc1);               // gWc1 += g_zc (x) m over the tile's edges
+                chain_parts32<true>(Wc1i, lane, pb, gm);             // g_m += Wc1^T g_zc
+                wgrad_tile(pb, MI, idt, lane, gWc1);                 // gWc1 += g_zc (x) m over the tile's edges
+                load_row_terms();
+            } else {
+                load_row_terms();
             }
             add_row_terms();
             // ---- edge residual; g_z2 = g_m_new * SiLU'(z2) ----
@@ -391,8 +394,8 @@ k_edge_bwd32(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO i
             f32x16 ga1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ga1[r] = 0.f;
-            chain_parts32<true>(W2i, lane, pb, ga1);
             if (!upd) pvs_wave_lds_sync();                            // (a1 image: no earlier sync on this path)
+            chain_parts32<true>(W2i, lane, pb, ga1);
             wgrad_tile(pb, A1I, idt, lane, gW2);
             float g_z1[HB][16];
 #pragma unroll
