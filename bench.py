@@ -166,73 +166,153 @@ def cpu_baseline(cfg, seconds_budget=15.0):
                       f'{n_cpu}-CPU host, torch {torch.__version__} CPU'}
 
 
+def cpu_baseline_screening(cfg, lig, rec, feats, seconds_budget=15.0):
+    """The CPU oracle on the host cores for the virtual-screening shape: per pose, the oracle's
+    generate_edges (cdist + the reference edge rule) and one forward of the model (torch.no_grad)."""
+    from oracle import egnn_oracle as orc
+    from oracle.generate_edges_oracle import generate_edges as oracle_edges
+    from pointvs_amd.egnn_satorras import SartorrasEGNN
+    from pointvs_amd.synthetic import random_poses
+    torch.manual_seed(0)
+    model = SartorrasEGNN(Path('/tmp/pvs_bench_cpu'), 2e-3, 1e-4, silent=True, **cfg['model'])
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items() if v.is_floating_point()}
+    ocfg = dict(cfg['model'], _class='SartorrasEGNN')
+    r = cfg['graph']['edge_radius']
+    bp = feats[:, -1].numpy()
+    poses = random_poses(lig, 16, seed=99)
+    n_cpu = os.cpu_count() or 1
+    threads = min(n_cpu, 16)
+    torch.set_num_threads(threads)
+    batch = torch.zeros(lig.shape[0] + rec.shape[0], dtype=torch.long)
+
+    def one_pose(p):
+        pos = torch.cat([p, rec], 0)
+        _, (rows, cols), attrs = oracle_edges(pos.numpy(), bp, r, r, prune=False)
+        ei = torch.from_numpy(np.vstack([rows, cols])).long()
+        ea = torch.nn.functional.one_hot(torch.from_numpy(attrs).long(), 3)
+        with torch.no_grad():
+            return orc.model_forward(sd, ocfg, feats, pos, ei, ea, batch, n_graphs=1), ei.shape[1]
+
+    one_pose(poses[0])
+    times, t_start, n_edges = [], time.perf_counter(), 0
+    for p in poses[1:]:
+        t0 = time.perf_counter()
+        _, n_edges = one_pose(p)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > seconds_budget and len(times) >= 3:
+            break
+    med = float(np.median(times))
+    return {'value': round(1.0 / med, 4), 'unit': 'graphs/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{len(times)} timed poses (1 warm-up) of the CPU oracle: radius graph (cdist + reference edge '
+                      f'rule, E={n_edges}) + forward of the same model on N={batch.numel()} atoms, median '
+                      f'{med * 1e3:.0f} ms/pose, {threads} torch threads on a {n_cpu}-CPU host, torch '
+                      f'{torch.__version__} CPU'}
+
+
 def screening_bench(args, rank, world, dev):
     """BASELINE config 5: poses/s of the forward pass (torch.no_grad) with the radius graph of every
-    pose built on the GPU from its coordinates. One step = one batch of `--batch` poses; every rank
-    screens its own poses (no collective: pose shards are independent)."""
+    pose built on the GPU from its coordinates, the whole step replayed from a hipGraph, scores
+    streamed to a predictions file by the writer thread. One step = one batch of `--batch` poses;
+    `--sweep P` screens P poses per rank instead of `--steps` batches (BASELINE: 100k over 8 GPUs =
+    12.5k per rank). Every rank screens its own poses (no collective: pose shards are independent)."""
+    from pointvs_amd import _lib
     from pointvs_amd.egnn_satorras import SartorrasEGNN
-    from pointvs_amd.radius_graph import PoseBatcher
+    from pointvs_amd.screening import ScreeningSweep
     from pointvs_amd.synthetic import CONFIGS, random_poses, screening_set
     cfg = CONFIGS['cfg2']
+    lib = _lib.lib()
     lig, rec, feats = screening_set()
+    n_lig = lig.shape[0]
     torch.manual_seed(0)
     model = SartorrasEGNN(Path('/tmp/pvs_bench'), 2e-3, 1e-4, silent=True, **cfg['model']).eval()
-    batcher = PoseBatcher(rec.to(dev), feats, lig.shape[0], args.batch, cfg['graph']['edge_radius'])
-    n_steps = args.warmup + args.steps
-    poses = random_poses(lig, n_steps * args.batch, seed=7 + rank, device=dev).view(n_steps, args.batch, -1, 3)
-    scores = []
+    if args.sweep:
+        args.steps = -(-args.sweep // args.batch)
+    n_warm = max(args.warmup, 1)
+    poses = random_poses(lig, (n_warm + args.steps) * args.batch, seed=7 + rank, device=dev)
+    warm, timed = poses[:n_warm * args.batch], poses[n_warm * args.batch:]
+    captured = bool(args.graph)
+    sweep = ScreeningSweep(model, rec.to(dev), feats[n_lig:].to(dev), cfg['graph']['edge_radius'], args.batch,
+                           capture=captured)
+    lig_feats = feats[:n_lig]
+    out_dir = Path(os.environ.get('PVS_BENCH_OUT', '/tmp/pvs_bench'))
+    pred_file = out_dir / f'screen_predictions_rank{rank}.txt'
 
-    from pointvs_amd.screening import ReceptorScreen
-    screen = None
-    if not os.environ.get('PVS_BENCH_NO_REUSE'):   # first-layer receptor-receptor sums computed once
-        screen = ReceptorScreen(model, rec.to(dev), feats, lig.shape[0], args.batch, cfg['graph']['edge_radius'])
-        batcher = screen.batcher
-
-    captured = bool(args.graph) and screen is not None and screen.fast_graph
-    if captured:
-        screen.capture(poses[0])
-
-    def step(k):
-        with torch.no_grad():
-            if captured:
-                out = screen.replay(poses[k]).clone()
-            else:
-                out = screen(poses[k]) if screen is not None else model(batcher.load(poses[k]))
-            scores.append(torch.sigmoid(out.reshape(-1)))
-
-    for k in range(args.warmup):
-        step(k)
+    sweep.run([('warm', lig_feats, warm)])           # builds the bucket, captures the step
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for k in range(args.warmup, n_steps):
-        step(k)
+    scores = sweep.run([('lig0', lig_feats, timed)], predictions_file=pred_file)['lig0']
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if screen is not None:
-        screen.check()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    n_lines = sum(1 for _ in open(pred_file))
+    assert n_lines == timed.shape[0], (n_lines, timed.shape[0])
+
+    # kernel timings of the same step, eager (HIP events cannot be read out of a replayed graph)
+    screen = sweep.buckets[n_lig]
+    lib.pvs_profile_reset()
+    lib.pvs_profile_enable(1)
+    prof_steps = 5
+    for k in range(prof_steps):
+        screen(timed[k * args.batch:(k + 1) * args.batch].contiguous())
+    torch.cuda.synchronize(dev)
+    lib.pvs_profile_enable(0)
+
+    def kernel_ms(name):
+        tot, cnt = C.c_double(0.0), C.c_int64(0)
+        rc = lib.pvs_profile_read(name.encode(), C.byref(tot), C.byref(cnt))
+        return (tot.value, cnt.value) if rc == 0 else (0.0, 0)
+
     if rank == 0:
-        e = batcher.batch.prepared.n_edges
-        print(json.dumps({
+        h, layers = cfg['model']['k'], cfg['model']['num_layers']
+        n_nodes = args.batch * (n_lig + rec.shape[0])
+        n_edges = int(screen._fast['rowptr'][n_nodes].item()) if screen._fast else screen.batcher.batch.prepared.n_edges
+        n_edges_lig = int(screen._fast['rowptr_l'][n_nodes].item()) if screen._fast else 0
+        fwd_ms, fwd_n = kernel_ms('edge_fwd')
+        part_ms, part_n = kernel_ms('edge_fwd_partial')
+        prep_ms, _ = kernel_ms('graph_prepare')
+        dom_avg_ms = fwd_ms / max(fwd_n, 1)
+        dom_bytes = algorithmic_bytes_edge_fwd(n_nodes, n_edges, h)
+        achieved = dom_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
+        dom_tflops = (4.0 * h * h + 2 * h) * n_edges / (dom_avg_ms * 1e-3) / 1e12 if dom_avg_ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic('cfg5', 'k_edge_fwd_mfma')
+        ms_step = elapsed / args.steps * 1e3
+        out = {
             'metric': 'ligand poses/sec, forward only (virtual-screening sweep), 3-layer EGNN ch=32, one '
                       'receptor of 1970 atoms, r=10A, graphs built on the GPU',
-            'value': round(world * args.batch * args.steps / elapsed, 2), 'unit': 'graphs/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'value': round(world * timed.shape[0] / elapsed, 2), 'unit': 'graphs/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': n_warm, 'ms_per_step': round(ms_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'cfg5: {args.batch} poses/GPU per step, 30-atom ligand + 1970-atom receptor, '
-                                   f'E={e} edges in the last batch, radius graph from coordinates every step, first-layer '
-                                   f'receptor-receptor sums reused: {screen is not None and screen.reuse}, '
-                                   f'hipGraph replay: {captured}',
+            'config': {'workload': f'cfg5: {timed.shape[0]} poses/GPU streamed in batches of {args.batch}, 30-atom '
+                                   f'ligand + 1970-atom receptor, N={n_nodes} nodes E={n_edges} edges per batch '
+                                   f'({n_edges_lig} touch the ligand), radius graph from coordinates every step, '
+                                   f'first-layer receptor-receptor sums reused: {screen.reuse}, hipGraph replay: '
+                                   f'{bool(screen._captured)}, predictions streamed to a file ({n_lines} lines)',
                        'graphs_per_gpu': args.batch, 'global_batch': world * args.batch, 'parallelism': f'dp{world}',
-                       'mean_score': round(float(torch.cat(scores[-args.steps:]).mean()), 6)}}))
+                       'mean_score': round(float(scores.mean()), 6)},
+            'roofline': {
+                'bound': 'hbm', 'kernel': f'k_edge_fwd_mfma (H={h} edge forward over the full pose-batch graph, '
+                                          f'{layers - 1} launches per step; the first layer runs over the ligand edges only)',
+                'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
+                'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_ms': round(dom_avg_ms, 4), 'launches': fwd_n,
+                'kernel_exec_fp32': {'achieved': round(dom_tflops, 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                     'frac': round(dom_tflops / FP32_PEAK_TFLOPS, 5)},
+                'kernel_ms_per_step': {'edge_fwd_full_layers': round(fwd_ms / prof_steps, 3),
+                                       'edge_fwd_first_layer_ligand_edges': round(part_ms / prof_steps, 3),
+                                       'graph_build': round(prep_ms / prof_steps, 3)}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline_screening(cfg, lig, rec, feats)
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -245,6 +325,9 @@ def main():
                     help='cfg5: virtual-screening sweep (BASELINE config 5): forward only, random poses '
                          'of one ligand against one receptor, graphs built on the GPU per batch')
     ap.add_argument('--batch', type=int, default=32, help='graphs per GPU')
+    ap.add_argument('--sweep', type=int, default=0,
+                    help='cfg5: screen this many poses per rank (sets --steps = ceil(sweep / batch)); BASELINE '
+                         'config 5 is 100k poses over 8 GPUs')
     ap.add_argument('--global-batch', type=int, default=0,
                     help='strong scaling (BASELINE config 4): fixed global batch, --batch becomes global/gpus')
     ap.add_argument('--skip-dead-coords', action='store_true',
@@ -262,9 +345,12 @@ def main():
                     help='hand every step a HOST batch (as the reference\'s DataLoader does) and count the '
                          'host-to-device copy in the step: the PCIe-inclusive rate noted in DESIGN.md, never '
                          'the headline value (inputs resident in HBM)')
-    ap.add_argument('--graph', type=int, default=int(os.environ.get('PVS_BENCH_GRAPH', '0')),
-                    help='1: capture the whole training step in a hipGraph and time replays')
+    ap.add_argument('--graph', type=int, default=None,
+                    help='1: capture the whole step in a hipGraph and time replays (default: 1 for cfg5, the '
+                         'configuration BASELINE names; 0 for the training configurations)')
     args = ap.parse_args()
+    if args.graph is None:
+        args.graph = int(os.environ.get('PVS_BENCH_GRAPH', '1' if args.config == 'cfg5' else '0'))
     strong = args.global_batch > 0
     if not args.skip_dead_coords:      # same per-step work as the reference: every layer updates x
         os.environ['PVS_EGNN_KEEP_DEAD_COORDS'] = '1'

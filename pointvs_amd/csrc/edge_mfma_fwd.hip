@@ -295,7 +295,7 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
         PVS_CHECK_LAUNCH();
     }
     if (g.n_edges == 0) return 0;
-    PvsProfScope prof(s, PVS_PROF_EDGE_FWD);
+    PvsProfScope prof(s, pvs_prof_fwd_tag());
     const int HB = H / 32;
     const char* bf = getenv("PVS_EGNN_BF16X3");
     const char* bf64 = getenv("PVS_EGNN_BF16X3_H64");

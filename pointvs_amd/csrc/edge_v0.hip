@@ -446,7 +446,26 @@ k_node_gather(PvsGraph g, const float* __restrict__ gz1, const float* __restrict
     auto fma4 = [](float4& a, const float4& v, float s) {
         a.x = fmaf(v.x, s, a.x); a.y = fmaf(v.y, s, a.y); a.z = fmaf(v.z, s, a.z); a.w = fmaf(v.w, s, a.w);
     };
-    for (int n = n_lo + blockIdx.x * kWaves + wv; n < n_hi; n += total_waves) {
+    // Column -> wave map. The 16-byte per-edge records (gd4) are read at scattered positions: a read
+    // fetches a whole 128-byte line = the records of 8 CONSECUTIVE sorted edges, i.e. 8 neighbours of
+    // one row with ascending column ids (TCC request counters: these lines cost as many bytes as the
+    // gradient rows themselves when every column pulls its own copy through the fabric). So each XCD
+    // (blocks b, b + 8, ... share one, MI355X_MICROARCH.md) takes a CONTIGUOUS range of columns and
+    // its resident waves sweep it as a window of adjacent columns: the 8 columns that need a line are
+    // then in flight on the same L2 at about the same time. Speed only - any map is correct.
+    int n_first, n_stride, n_stop;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int per_xcd = (n_hi - n_lo + 7) / 8;
+        n_first = n_lo + xcd * per_xcd + slot * kWaves + wv;
+        n_stride = (gridDim.x >> 3) * kWaves;
+        n_stop = min(n_hi, n_lo + (xcd + 1) * per_xcd);
+    } else {
+        n_first = n_lo + blockIdx.x * kWaves + wv;
+        n_stride = total_waves;
+        n_stop = n_hi;
+    }
+    for (int n = n_first; n < n_stop; n += n_stride) {
         float4 accc = make_float4(0.f, 0.f, 0.f, 0.f);
         float axc = 0.f;     // lanes with quad < 3 own coordinate component `quad`
         const int p0 = g.colptr[n], p1 = g.colptr[n + 1];

@@ -4,6 +4,7 @@
 #include "dense_ops.h"
 #include "edge_kernels.h"
 #include "node_ops.h"
+#include "profile.h"
 
 #include <stdlib.h>
 
@@ -386,7 +387,10 @@ extern "C" int pvs_egnn_layer_fwd_partial(const PvsLayerDesc* d, const PvsGraph*
     PvsEdgeFwdIO io;
     io.PQ = sPQ; io.x = x; io.m_prev = nullptr; io.Magg = Magg; io.x_out = x_out; io.m_out = nullptr;
     io.att_out = att; io.smax = w.smax; io.ssum = w.ssum;
-    PVS_TRY(pvs_launch_edge_fwd_mfma(s, H, *g, ew, d->flags | kFwdRawXsumFlag, d->att_act, io));
+    pvs_prof_set_fwd_tag(PVS_PROF_EDGE_FWD_PARTIAL);      // timed apart from the full-graph layers (bench.py)
+    const int rc_partial = pvs_launch_edge_fwd_mfma(s, H, *g, ew, d->flags | kFwdRawXsumFlag, d->att_act, io);
+    pvs_prof_set_fwd_tag(PVS_PROF_EDGE_FWD);
+    PVS_TRY(rc_partial);
     const long long threads = (long long)m.N * (H / 4);
     k_combine_partial<<<(int)((threads + 255) / 256), 256, 0, s>>>(Magg, x_out, x, base_magg, base_xsum, base_deg,
                                                                    g->rowptr, m.N, H,

@@ -9,8 +9,12 @@ struct Rec { int id; hipEvent_t a, b; };
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Rec*> g_recs;
-const char* kNames[PVS_PROF_COUNT] = {"edge_fwd", "edge_bwd", "col_gather", "graph_prepare"};
+const char* kNames[PVS_PROF_COUNT] = {"edge_fwd", "edge_bwd", "col_gather", "graph_prepare", "edge_fwd_partial"};
+thread_local int t_fwd_tag = PVS_PROF_EDGE_FWD;
 }  // namespace
+
+void pvs_prof_set_fwd_tag(int id) { t_fwd_tag = id; }
+int pvs_prof_fwd_tag() { return t_fwd_tag; }
 
 PvsProfScope::PvsProfScope(hipStream_t stream, int id) : s(stream), rec(nullptr) {
     if (!g_on) return;

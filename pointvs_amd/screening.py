@@ -280,3 +280,87 @@ class ReceptorScreen:
         if model.feats_linear_layers is None:
             return h
         return model._run_head(model.feats_linear_layers, model._pool(h, self._graph_ptr, self.b))
+
+
+class ScreeningSweep:
+    """Virtual-screening sweep (BASELINE config 5; the reference's `val` / inference.py loop,
+    point_neural_network_base.py:208-360, inference.py:77-146): many ligands, each with many rigid
+    poses, against ONE receptor, forward only.
+
+    Poses are streamed in fixed-size batches through a `ReceptorScreen` per SIZE BUCKET (= number of
+    ligand atoms: a captured hipGraph has fixed shapes, so every distinct ligand size gets its own
+    captured step, built on first use and replayed for every later batch of that size; the ligand's
+    features are written into the bucket's static input buffers). The last batch of a ligand is
+    padded with copies of its last pose; the padding's scores are dropped. Scores leave the device
+    through `PredictionsWriter` (pinned buffers + a writer thread, reference line format
+    `'{score:.3f} | {receptor} {pose name}'`, :318-325), so the loop never waits for the host.
+
+        sweep = ScreeningSweep(model, rec_pos, rec_feats, edge_radius=10.0, batch_size=32)
+        scores = sweep.run([(name, lig_feats [n_lig,F], poses [P,n_lig,3]), ...], 'predictions.txt')
+    """
+
+    def __init__(self, model, rec_pos, rec_feats, edge_radius, batch_size=32, intra_radius=None, capture=True,
+                 receptor_name='receptor'):
+        self.model, self.rec_pos, self.rec_feats = model, rec_pos, rec_feats
+        self.edge_radius, self.intra_radius, self.b = edge_radius, intra_radius, int(batch_size)
+        self.capture, self.receptor_name = capture, receptor_name
+        self.buckets = {}          # n_lig -> ReceptorScreen (captured when possible)
+        self.batches_run = 0
+
+    def _bucket(self, n_lig, lig_feats, example_poses):
+        screen = self.buckets.get(n_lig)
+        if screen is None:
+            feats = torch.cat([lig_feats.to(self.rec_feats.device), self.rec_feats], 0)
+            screen = ReceptorScreen(self.model, self.rec_pos, feats, n_lig, self.b, self.edge_radius, self.intra_radius)
+            screen._captured = False
+            if self.capture and screen.fast_graph:
+                screen.capture(example_poses)
+                screen._captured = True
+            self.buckets[n_lig] = screen
+        return screen
+
+    @staticmethod
+    def _set_ligand_feats(screen, lig_feats):
+        """The bucket's static node-feature buffer: ligand rows of every pose slot <- this ligand."""
+        x = screen.batcher.batch.x
+        x.view(screen.b, screen.batcher.n, -1)[:, :screen.n_lig] = lig_feats.to(x.device, x.dtype)
+
+    @torch.no_grad()
+    def run(self, ligands, predictions_file=None, sigmoid=None):
+        """ligands: iterable of (name, lig_feats [n_lig,F], poses [P,n_lig,3] on the device).
+        Returns {name: scores [P, ...] on the device} (raw model outputs; sigmoid-ed like `val` does for
+        classification models when sigmoid is None/True). predictions_file: optional path."""
+        from .predictions import PredictionsWriter
+        if sigmoid is None:
+            sigmoid = getattr(self.model, 'model_task', 'classification') == 'classification'
+        writer = PredictionsWriter(predictions_file, 'regression', flush_every=10) if predictions_file else None
+        out = {}
+        try:
+            for name, lig_feats, poses in ligands:
+                n_poses, n_lig = int(poses.shape[0]), int(poses.shape[1])
+                if n_poses == 0:
+                    continue
+                pad = (-n_poses) % self.b
+                if pad:
+                    poses = torch.cat([poses, poses[-1:].expand(pad, -1, -1)], 0)
+                screen = self._bucket(n_lig, lig_feats, poses[:self.b].contiguous())
+                self._set_ligand_feats(screen, lig_feats)
+                scores = []
+                for k in range(0, poses.shape[0], self.b):
+                    chunk = poses[k:k + self.b]
+                    y = screen.replay(chunk).clone() if screen._captured else screen(chunk.contiguous())
+                    y = y.reshape(self.b, -1)
+                    if sigmoid:
+                        y = torch.sigmoid(y)
+                    keep = min(self.b, n_poses - k)
+                    scores.append(y[:keep])
+                    if writer is not None:
+                        writer.submit(y[:keep, 0], None, [self.receptor_name] * keep,
+                                      [f'{name}_pose{k + i}' for i in range(keep)])
+                    self.batches_run += 1
+                out[name] = torch.cat(scores, 0)
+                screen.check()
+        finally:
+            if writer is not None:
+                writer.close()
+        return out

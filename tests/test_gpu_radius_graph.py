@@ -240,3 +240,42 @@ def test_captured_screening_step_replays_on_new_poses():
         got = graph.replay(poses[4 * k:4 * k + 4]).reshape(-1).clone()
         assert torch.equal(got, want[k])
     graph.check()
+
+
+def test_screening_sweep_streams_size_buckets_and_writes_predictions(tmp_path):
+    """ScreeningSweep: ligands of two sizes (two captured buckets, the second ligand of a size reuses the
+    first one's captured step with its own features), pose counts that are not multiples of the batch,
+    scores equal to the plain forward of the same poses, predictions file in the reference line format."""
+    import tempfile
+    from pointvs_amd.egnn_satorras import SartorrasEGNN
+    from pointvs_amd.radius_graph import PoseBatcher
+    from pointvs_amd.screening import ScreeningSweep
+    from pointvs_amd.synthetic import random_poses, screening_set
+    kw = dict(dim_input=12, k=32, dim_output=1, num_layers=3, residual=False, edge_residual=False,
+              edge_attention=False, normalize=False, tanh=False, dropout=0.0, graphnorm=False, update_coords=True,
+              permutation_invariance=False, node_attention=False, gated_residual=False, rezero=False,
+              softmax_attention=False, model_task='classification')
+    torch.manual_seed(2)
+    model = SartorrasEGNN(tempfile.mkdtemp(), 2e-3, 1e-4, silent=True, **kw).eval()
+    lig_a, rec, feats_a = screening_set(seed=5003, n_nodes=400, n_lig=12)
+    rec_feats = feats_a[12:]
+    gen = torch.Generator().manual_seed(0)
+    ligs = [('ligA', feats_a[:12], lig_a, 7), ('ligB', feats_a[:9].roll(1, 0), lig_a[:9] * 0.9, 5),
+            ('ligC', feats_a[:12].roll(3, 0), lig_a.flip(0), 4)]
+    work = [(name, f, random_poses(pos, n, seed=20 + k, max_shift=4.0).cuda())
+            for k, (name, f, pos, n) in enumerate(ligs)]
+    sweep = ScreeningSweep(model, rec.cuda(), rec_feats, edge_radius=6.0, batch_size=4)
+    got = sweep.run(work, predictions_file=tmp_path / 'screen.txt')
+    assert sorted(sweep.buckets) == [9, 12] and sweep.batches_run == 2 + 2 + 1
+    lines = (tmp_path / 'screen.txt').read_text().splitlines()
+    assert len(lines) == 7 + 5 + 4
+    at = 0
+    for name, f, poses in work:
+        n_lig = f.shape[0]
+        plain = PoseBatcher(rec.cuda(), torch.cat([f, rec_feats], 0), n_lig, 1, edge_radius=6.0)
+        for k in range(poses.shape[0]):
+            with torch.no_grad():
+                want = torch.sigmoid(model(plain.load(poses[k:k + 1])).reshape(-1))[0]
+            assert abs(float(got[name][k, 0]) - float(want)) < 1e-5 * max(1.0, abs(float(want))), (name, k)
+            assert lines[at] == f'{float(got[name][k, 0]):.3f} | receptor {name}_pose{k}'
+            at += 1
