@@ -248,22 +248,88 @@ class EGNNLayer(nn.Module):
         h_out, x_out, m_sorted = self.forward_prepared(pg, h, coord, m_prev, need_m=True)
         return h_out, x_out, edge_attr, PF.rows_to_input_order(m_sorted, pg)
 
-    def _fused(self, name):
-        raise NotImplementedError(
-            f'EGNNLayer.{name} is fused into pvs_egnn_layer_fwd (include/pvs_egnn.h); call the '
-            f'layer itself')
+    # ---- the reference's public sub-methods (egnn_satorras.py:123-187) ----
+    # Nothing in the reference calls these from outside `forward`; the layer itself runs fused
+    # (pvs_egnn_layer_fwd/bwd). They are kept for code written against the decomposed API: the dense
+    # products and the segment reductions go through the C ABI (pvs_linear_*, pvs_segment_reduce_*),
+    # the per-edge gathers / concatenation / activations are plain torch ops on the HIP tensors, with
+    # autograd. Same values as the fused layer up to fp32 summation order
+    # (tests/test_gpu_properties.py::test_public_submethods_compose_to_the_fused_layer).
+    @staticmethod
+    def _mlp(seq, x):
+        for mod in seq:
+            if isinstance(mod, nn.Linear):
+                x = PF.linear(x, mod.weight, mod.bias)
+            elif isinstance(mod, GraphNorm):      # no batch vector: one graph
+                _lib.require_hip(x)
+                out = x - x.mean(dim=0, keepdim=True) * mod.mean_scale
+                x = mod.weight * out / (out.pow(2).mean(dim=0, keepdim=True) + mod.eps).sqrt() + mod.bias
+            else:
+                x = mod(x)
+        return x
 
     def edge_model(self, source, target, radial, edge_attr):
-        self._fused('edge_model')
+        """:123-132: edge_mlp on [h_i, h_j, radial, edge_attr] (or [h_i + h_j, ...])."""
+        _lib.require_hip(source, target, radial)
+        inp = [source + target, radial] if self.permutation_invariance else [source, target, radial]
+        if edge_attr is not None:
+            inp.append(edge_attr.to(source.dtype))
+        return self._mlp(self.edge_mlp, torch.cat(inp, dim=1))
 
     def node_model(self, x, edge_index, m_ij):
-        self._fused('node_model')
+        """:134-166: attention gate, sum aggregation by row, node_mlp, node gate, residual variants.
+        Returns (out, cat([x, agg]))."""
+        _lib.require_hip(x, m_ij)
+        row = edge_index[0]
+        n = x.size(0)
+        if self.edge_attention:
+            att_val = self._mlp(self.att_mlp, m_ij)
+            if self.softmax_attention:      # scatter_softmax over the edges that share a row
+                idx = row.unsqueeze(-1)
+                gmax = torch.full((n, 1), float('-inf'), dtype=att_val.dtype, device=att_val.device)
+                gmax = gmax.scatter_reduce(0, idx, att_val.detach(), 'amax', include_self=True)
+                shifted = (att_val - gmax[row]).exp()
+                att_val = shifted / unsorted_segment_sum(shifted, row, n)[row]
+            self._att_src = lambda: att_val.detach()
+            agg = unsorted_segment_sum(att_val * m_ij, row, num_segments=n)
+        else:
+            agg = unsorted_segment_sum(m_ij, row, num_segments=n)
+        agg = torch.cat([x, agg], dim=1)
+        out = self._mlp(self.node_mlp, agg)
+        if self.node_attention:
+            natt = self._mlp(self.node_att_mlp, out)
+            out = out * natt
+            self._natt_src = lambda: natt.detach()
+        if self.residual:
+            if self.rezero:
+                out = x + self.node_gate_parameter * out
+            elif self.gated_residual:
+                gate = torch.relu(self.node_gate_parameter)
+                out = gate * out + (1 - gate) * x
+            else:
+                out = x + out
+        return out, agg
 
     def coord_model(self, coord, edge_index, coord_diff, edge_feat):
-        self._fused('coord_model')
+        """:168-176: coord + mean over the row's edges of coord_diff * coord_mlp(m). Out of place
+        (the reference adds in place; returned values are identical)."""
+        if not self.use_coords:
+            return coord
+        _lib.require_hip(coord, coord_diff, edge_feat)
+        trans = coord_diff * self._mlp(self.coord_mlp, edge_feat)
+        out = coord + unsorted_segment_mean(trans, edge_index[0], num_segments=coord.size(0))
+        self._coords_src = lambda: out.detach()
+        return out
 
     def coord2radial(self, edge_index, coord):
-        self._fused('coord2radial')
+        """:178-187: squared distance and (optionally normalised, norm detached) difference per edge."""
+        _lib.require_hip(coord)
+        row, col = edge_index[0], edge_index[1]
+        coord_diff = coord[row] - coord[col]
+        radial = torch.sum(coord_diff ** 2, 1).unsqueeze(1)
+        if self.normalize:
+            coord_diff = coord_diff / (torch.sqrt(radial).detach() + self.epsilon)
+        return radial, coord_diff
 
 
 class SartorrasEGNN(PNNGeometricBase):

@@ -623,3 +623,33 @@ def test_bitwise_reproducible_at_baseline_size(changes):
         for name, gr in grads.items():
             if gr is not None:
                 assert gr.tobytes() == runs[0][1][name].tobytes(), name
+
+
+@pytest.mark.parametrize('flags', [dict(), dict(edge_attention=True, node_attention=True, residual=True, tanh=True,
+                                                normalize=True),
+                                   dict(edge_attention=True, softmax_attention=True, graphnorm=True,
+                                        permutation_invariance=True, gated_residual=True, residual=True)])
+def test_public_submethods_compose_to_the_fused_layer(flags):
+    """EGNNLayer.coord2radial / edge_model / coord_model / node_model (egnn_satorras.py:123-187) chained the
+    way the reference's forward chains them (:189-206) give the fused layer's outputs and input gradients."""
+    from pointvs_amd.egnn_satorras import EGNNLayer
+    torch.manual_seed(4)
+    layer = EGNNLayer(32, 32, 32, edges_in_d=3, **flags).cuda()
+    g = random_graph(150, 2500, seed=8).to('cuda')
+    h0 = torch.randn(150, 32, device='cuda')
+    outs = []
+    for fused in (True, False):
+        h = h0.clone().requires_grad_(True)
+        x = g.pos.clone().requires_grad_(True)
+        if fused:
+            h_out, x_out, _, m = layer(h, g.edge_index, x, g.edge_attr)
+        else:
+            row, col = g.edge_index
+            radial, diff = layer.coord2radial(g.edge_index, x)
+            m = layer.edge_model(h[row], h[col], radial, g.edge_attr)
+            x_out = layer.coord_model(x, g.edge_index, diff, m)
+            h_out, _ = layer.node_model(h, g.edge_index, m)
+        (h_out.square().sum() + x_out.square().sum() + m.sum()).backward()
+        outs.append([t.detach().cpu().numpy() for t in (h_out, x_out, m, h.grad, x.grad)])
+    for a, b, name in zip(outs[0], outs[1], ('h', 'x', 'm', 'g_h', 'g_x')):
+        assert rel_err(a, b) < 2e-5, name

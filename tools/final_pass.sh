@@ -5,14 +5,20 @@ tag=$1
 out=gpurun_out/final_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-python3 bench.py > $out/bench_cfg2.json 2> $out/bench_cfg2.err
+python3 bench.py --steps 20 --warmup 5 > $out/bench_cfg2.json 2> $out/bench_cfg2.err
 python3 bench.py --config cfg3 --no-cpu-baseline > $out/bench_cfg3.json 2>/dev/null
 python3 bench.py --infer --no-cpu-baseline > $out/bench_cfg2_infer.json 2>/dev/null
-python3 bench.py --config cfg5 --steps 100 --warmup 10 > $out/bench_cfg5.json 2>/dev/null
+python3 bench.py --config cfg5 --sweep 12500 > $out/bench_cfg5.json 2>/dev/null
 python3 bench.py --skip-dead-coords --no-cpu-baseline > $out/bench_cfg2_skip.json 2>/dev/null
+PVS_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 5 --warmup 2 > $out/bench_cfg2_gpus2_gloo_shared_gpu.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg2 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/prof_cfg2.json 2> $out/prof_cfg2.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg3 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --config cfg3 > $out/prof_cfg3.json 2> $out/prof_cfg3.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg5 -- python3 bench.py --config cfg5 --steps 50 --warmup 5 --graph 0 --no-cpu-baseline > $out/prof_cfg5.json 2> $out/prof_cfg5.err
 # keep only the summaries (the traces are large)
 find $out -name '*kernel_trace.csv' -delete
-tools/measure_traffic.sh ${tag}_cfg2 > $out/traffic.log 2>&1
+tools/measure_traffic.sh ${tag}_cfg2 > $out/traffic_cfg2.log 2>&1
+tools/measure_traffic.sh ${tag}_cfg5 --config cfg5 --steps 5 --graph 0 > $out/traffic_cfg5.log 2>&1
+tools/pmc_sq.sh ${tag} > $out/pmc_sq.log 2>&1
+python3 tools/pmc_summary.py gpurun_out/pmc_${tag} k_edge_bwd k_edge_fwd k_node_gather > $out/pmc_sq_summary.txt 2>&1
+find gpurun_out/pmc_${tag} gpurun_out/traffic_${tag}_cfg2 gpurun_out/traffic_${tag}_cfg5 -name '*.csv' -size +1M -delete
 for f in $out/bench_*.json $out/prof_cfg*.json; do echo "$f: $(cut -c1-260 $f | grep -o '"value": [0-9.]*')"; done
