@@ -82,26 +82,35 @@ __device__ __forceinline__ void transpose_part(const bf16x8 (&p)[2], const bf16x
 
 // gW (D layout [c = ch(r,hh)][k = j]) += sum over the tile's edges of G[e][c] * Act[e][k]:
 // G = the gradient tensor's parts in X layout (transposed here), Act = the activation's image.
+// Also: gB[.][col] += sum over the tile's edges of G[e][.] - the bias gradient belonging to G, as a
+// product of the SAME transposed operand with a B operand that is all ones in column `col` (`ones`, a
+// constant in LDS; bf16 1.0 is exact): the matrix core does the sum over the edges that an X-layout
+// register accumulator would need 16 VALU adds, 16 registers and a final cross-lane reduction for.
 __device__ __forceinline__ void wgrad_tile(const Bf16Parts& g, const unsigned short* __restrict__ act_img,
-                                           const unsigned* __restrict__ idt, int lane, f32x16& gW) {
+                                           const unsigned* __restrict__ idt, const unsigned* __restrict__ ones,
+                                           int lane, f32x16& gW, f32x16& gB) {
     // operands are fetched from LDS where they are used (the register file is the scarce resource here:
     // two waves per SIMD), the compiler may keep what fits
     bf16x8 ident[2];
     ident[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(idt + (0 * 64 + lane) * 4));
     ident[1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(idt + (1 * 64 + lane) * 4));
+    const bf16x8 one = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ones + lane * 4));
     const unsigned short* hi = act_img;
     const unsigned short* mid = act_img + 32 * 32;
     const unsigned short* lo = act_img + 2 * 32 * 32;
     bf16x8 y[2];
     transpose_part(g.lo, ident, y);
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s) {
         gW = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[s], img_fragment<1, true>(hi, lane, 0, 0, s), gW, 0, 0, 0);
+        gB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[s], one, gB, 0, 0, 0);
+    }
     transpose_part(g.mid, ident, y);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         gW = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[s], img_fragment<1, true>(mid, lane, 0, 0, s), gW, 0, 0, 0);
         gW = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[s], img_fragment<1, true>(hi, lane, 0, 0, s), gW, 0, 0, 0);
+        gB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[s], one, gB, 0, 0, 0);
     }
     transpose_part(g.hi, ident, y);
 #pragma unroll
@@ -109,6 +118,7 @@ __device__ __forceinline__ void wgrad_tile(const Bf16Parts& g, const unsigned sh
         gW = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[s], img_fragment<1, true>(lo, lane, 0, 0, s), gW, 0, 0, 0);
         gW = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[s], img_fragment<1, true>(mid, lane, 0, 0, s), gW, 0, 0, 0);
         gW = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[s], img_fragment<1, true>(hi, lane, 0, 0, s), gW, 0, 0, 0);
+        gB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[s], one, gB, 0, 0, 0);
     }
 }
 
@@ -132,7 +142,9 @@ k_edge_bwd32(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO i
     float* wrhot = wat + H;
     float* attrt = wrhot + H;                                  // [PVS_MAX_EDGE_ATTR][H]
     unsigned* idt = reinterpret_cast<unsigned*>(attrt + PVS_MAX_EDGE_ATTR * H);   // [2 k-steps][64 lanes][4]
-    char* wave_base = reinterpret_cast<char*>(idt + 2 * 64 * 4);
+    unsigned* ones0 = idt + 2 * 64 * 4;             // [64 lanes][4]: bf16 ones for the lanes of column 0 (g_bc1)
+    unsigned* ones1 = ones0 + 64 * 4;               // ... of column 1 (g_b2)
+    char* wave_base = reinterpret_cast<char*>(ones1 + 64 * 4);
 
     const bool upd = (flags & PVS_UPDATE_COORDS) && io.gxagg != nullptr;
 
@@ -155,6 +167,11 @@ k_edge_bwd32(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO i
         const unsigned lo16 = xch(8 * s + 2 * q, lh) == col ? 0x3f80u : 0u;
         const unsigned hi16 = xch(8 * s + 2 * q + 1, lh) == col ? 0x3f80u : 0u;
         idt[i] = lo16 | (hi16 << 16);
+    }
+    for (int i = threadIdx.x; i < 64 * 4; i += NT) {
+        const int col = (i >> 2) & 31;
+        ones0[i] = col == 0 ? 0x3f803f80u : 0u;
+        ones1[i] = col == 1 ? 0x3f803f80u : 0u;
     }
     __syncthreads();
 
@@ -179,10 +196,11 @@ k_edge_bwd32(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO i
 
     // ---- accumulators that live for the whole kernel ----
     f32x16 gW2, gWc1;                          // D layout: [c = ch(r,hh)][k = j]
-    float g_wc2x[16], g_b2x[16], g_bc1x[16];   // X layout (channel in the register, edges on lanes)
+    f32x16 gB;                                 // column 0: g_bc1, column 1: g_b2 (rows = channels, D layout)
+    float g_wc2x[16];                          // X layout (channel in the register, edges on lanes)
     float g_wax[EATT ? 16 : 1];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { gW2[r] = 0.f; gWc1[r] = 0.f; g_wc2x[r] = 0.f; g_b2x[r] = 0.f; g_bc1x[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { gW2[r] = 0.f; gWc1[r] = 0.f; gB[r] = 0.f; g_wc2x[r] = 0.f; }
 #pragma unroll
     for (int r = 0; r < (EATT ? 16 : 1); ++r) g_wax[r] = 0.f;
     float g_ba = 0.f, g_gate = 0.f;
@@ -348,12 +366,11 @@ k_edge_bwd32(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO i
                 for (int r = 0; r < 16; ++r) {
                     g_zc[r] = g_s * wc2x[0][r] * dq[r];
                     g_wc2x[r] = fmaf(g_s, q[r], g_wc2x[r]);
-                    g_bc1x[r] += g_zc[r];
                 }
                 split_bf16x3(g_zc, pb);
                 pvs_wave_lds_sync();                                  // the m image is complete
                 chain_parts32<true>(Wc1i, lane, pb, gm);             // g_m += Wc1^T g_zc
-                wgrad_tile(pb, MI, idt, lane, gWc1);                 // gWc1 += g_zc (x) m over the tile's edges
+                wgrad_tile(pb, MI, idt, ones0, lane, gWc1, gB);                 // gWc1 += g_zc (x) m over the tile's edges
                 load_row_terms();
             } else {
                 load_row_terms();
@@ -379,7 +396,6 @@ k_edge_bwd32(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO i
                     }
                 }
                 g_z2[r] = gnew * dz2[r];
-                g_b2x[r] += g_z2[r];
             }
             if constexpr (ERES) {
                 if (valid) {
@@ -396,7 +412,7 @@ k_edge_bwd32(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO i
             for (int r = 0; r < 16; ++r) ga1[r] = 0.f;
             if (!upd) pvs_wave_lds_sync();                            // (a1 image: no earlier sync on this path)
             chain_parts32<true>(W2i, lane, pb, ga1);
-            wgrad_tile(pb, A1I, idt, lane, gW2);
+            wgrad_tile(pb, A1I, idt, ones1, lane, gW2, gB);
             float g_z1[HB][16];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
@@ -451,8 +467,6 @@ k_edge_bwd32(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO i
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         g_wc2x[r] = lanes32(g_wc2x[r]);
-        g_b2x[r] = lanes32(g_b2x[r]);
-        g_bc1x[r] = lanes32(g_bc1x[r]);
     }
 #pragma unroll
     for (int r = 0; r < (EATT ? 16 : 1); ++r) g_wax[r] = lanes32(g_wax[r]);
@@ -473,10 +487,12 @@ k_edge_bwd32(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO i
                 for (int r = 0; r < 16; ++r) {
                     const int c = xch(r, hh);
                     slab[L.wc2 + c] += g_wc2x[r];
-                    slab[L.b2 + c] += g_b2x[r];
-                    slab[L.bc1 + c] += g_bc1x[r];
                     if constexpr (EATT) slab[L.wa + c] += g_wax[r];
                 }
+            }
+            if (j <= 1) {      // bias gradients: column 0 of gB is g_bc1, column 1 is g_b2
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[(j == 0 ? L.bc1 : L.b2) + xch(r, hh)] += gB[r];
             }
             if (lane == 0) { slab[L.ba] += g_ba; slab[L.gate] += g_gate; }
         }
@@ -510,7 +526,7 @@ int pvs_launch_edge_bwd32(hipStream_t s, const PvsGraph& g, const PvsEdgeW& w, u
     *n_slabs = blocks;
     PvsProfScope prof(s, PVS_PROF_EDGE_BWD);
     const PvsSlabLayout L = pvs_slab_layout(32);
-    size_t lds = (size_t)2 * kImgShorts * 2 + (5 + PVS_MAX_EDGE_ATTR) * 32 * 4 + 2 * 64 * 16 +
+    size_t lds = (size_t)2 * kImgShorts * 2 + (5 + PVS_MAX_EDGE_ATTR) * 32 * 4 + 4 * 64 * 16 +
                  (size_t)nw * kT32WaveBytes;
     if (lds < (size_t)L.total * 4) lds = (size_t)L.total * 4;
     const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
