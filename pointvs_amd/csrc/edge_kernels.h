@@ -76,9 +76,10 @@ int pvs_edge_bwd_mfma_supported(int H, uint32_t flags, int n_attr);
 int pvs_edge_bwd_mfma_max_blocks(int H);
 int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,
                              int att_act, const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs);
-// H = 32 backward with all six products on the bf16 matrix pipe (edge_bwd32.hip); same contract
-int pvs_launch_edge_bwd32(hipStream_t s, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags, int att_act,
-                          const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs);
+// H = 32 / 64 backward with all six products on the bf16 matrix pipe, one wave per tile (edge_bwd_bf16.hip);
+// same contract as pvs_launch_edge_bwd_mfma
+int pvs_launch_edge_bwd_bf16(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags, int att_act,
+                             const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs);
 int pvs_edge_v0_supported(int H);
 int pvs_edge_v0_blocks(int N);
 // softmax attention: att[e] (logit) -> exp(att[e] - smax[row]) / ssum[row] once the rows are complete

@@ -1613,12 +1613,21 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     if (e_hi <= e_lo) return 0;
     const char* bf = getenv("PVS_EGNN_BF16X3");
     const bool bf16x3 = !(bf && bf[0] == '0') && H == 32;
-    {   // default for H = 32: weight gradients on the bf16 pipe too (PVS_BWD32=0: fp32 weight-gradient MFMAs)
+    {   // defaults: the all-bf16 one-wave-per-tile kernels of edge_bwd_bf16.hip.
+        // PVS_BWD32=0: H = 32 with fp32 weight-gradient MFMAs (k_edge_bwd_mfma).
+        // (H = 32 with edge residual needs ~100 more registers than two waves per SIMD have: round-1 kernel)
         const char* b32 = getenv("PVS_BWD32");
-        // (with edge residual the all-bf16 kernel needs ~100 more registers than two waves per SIMD have)
+        const char* b64 = getenv("PVS_BWD64");
         const bool eres_on = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
-        if (bf16x3 && !eres_on && !(b32 && b32[0] == '0'))
-            return pvs_launch_edge_bwd32(s, g, w, flags, att_act, io, e_lo, e_hi, n_slabs);
+        const bool all_bf16 = !(bf && bf[0] == '0');
+        if (H == 32 && all_bf16 && !eres_on && !(b32 && b32[0] == '0'))
+            return pvs_launch_edge_bwd_bf16(s, H, g, w, flags, att_act, io, e_lo, e_hi, n_slabs);
+#ifdef PVS_BWD_BF16_H64      // (see edge_bwd_bf16.hip: measured slower than the team kernel, not built by default)
+        if (H == 64 && all_bf16 && !(b64 && b64[0] == '0'))
+            return pvs_launch_edge_bwd_bf16(s, H, g, w, flags, att_act, io, e_lo, e_hi, n_slabs);
+#else
+        (void)b64;
+#endif
     }
     const int nt = bf16x3 ? 512 : kThreads, nw = nt / 64;
     // resident blocks per launch: H=32 fp32: 2 x 256 threads per CU; bf16x3: 1 x 512; H=64: 1 x 256
