@@ -566,7 +566,12 @@ def main():
                        'last_layer_coord_update': 'skipped (dead)' if args.skip_dead_coords else 'evaluated',
                        'launch': 'hipGraph replay of the whole step' if use_graph else 'eager',
                        'inputs': (f'host ({args.host_inputs}) batch copied to the device inside every step'
-                                  if args.host_inputs else 'resident in HBM')},
+                                  if args.host_inputs else 'resident in HBM'),
+                       'graph_prepare': ('radius graph built on the GPU from the coordinates' if args.build_graph else
+                                         'int64 COO + one-hot parsed every step; generate_edges-ordered batch merged by '
+                                         'counting (verified on the device)'
+                                         if pgraph.runs_layout(batch) is not None else
+                                         'int64 COO + one-hot parsed every step (two radix sorts)')},
             'roofline': {
                 'bound': 'hbm', 'kernel': dom_name,
                 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

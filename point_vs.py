@@ -11,7 +11,8 @@ checkpoints/, predictions files).
 Data sources. Turning parquet structure files into graphs is the reference's CPU data layer and is
 outside the hot-path scope; this entry reads
   * a data root holding one `.npz` per graph: `x [N,F]`, `pos [N,3]`, `y`, and either
-    `edge_index [2,E]` + `edge_type [E]` (as the reference's loader emits them) or, without edges,
+    `edge_index [2,E]` + `edge_type [E]` (as the reference's loader emits them; an optional
+    `edge_layout = 'generate_edges'` entry promises that order and selects the sort-free preparation) or, without edges,
     the ligand/receptor bit in the last column of `x` - the radius graph is then built on the GPU
     with --edge_radius (pvs_radius_graph_*); a types file, when given, lists the files to use
     (last column = file name relative to the root, first column = label);
@@ -94,6 +95,8 @@ class NpzGraphs:
         if 'edge_index' in z.files:
             item['edge_index'] = torch.from_numpy(z['edge_index'].astype(np.int64))
             item['edge_attr'] = torch.nn.functional.one_hot(torch.from_numpy(z['edge_type'].astype(np.int64)), 3)
+            if 'edge_layout' in z.files:      # e.g. 'generate_edges': lists dumped from the reference loader
+                item['edge_layout'] = str(z['edge_layout'])
         return self._data_cls(**item)
 
 

@@ -149,6 +149,227 @@ extern "C" int pvs_graph_prepare(const int64_t* edge_index, const int64_t* edge_
     return 0;
 }
 
+// ---- pvs_graph_prepare_runs: the same result for an edge list with the reference's layout, without the
+// by-row radix sort. `generate_edges` (preprocessing.py:108-142) emits, per graph, the inter-molecular
+// block and then the intra-molecular block, each row-major (np.where order): TWO ROW-SORTED RUNS per
+// graph, and PyG collation concatenates the graphs. A stable sort by row of such a list is a two-way
+// merge per graph, and a merge of sorted runs is a counting problem: the sorted position of edge e of run
+// X with row r is  rowptr[r] + [X is the second run] * count_first(r) + (e - first edge of X with row r).
+// The counts come from binary searches over the runs (4 per node), not from a pass over the edges.
+// The layout is a CONTRACT of the caller (graph.edge_layout == 'generate_edges'), never inferred; it is
+// verified on the device (at most one descent per graph, every offset inside its row's count, rows inside
+// the graph's node range) and a violation sets status bit 4 -> the host raises.
+namespace {
+
+// graph of edge e: one binary search per workgroup (for its first edge, shared through LDS), then a
+// short walk - consecutive edges belong to the same or the next few graphs
+__device__ __forceinline__ int graph_of_edge(const int32_t* __restrict__ edge_ptr, int n_graphs, int e, int E) {
+    __shared__ int g_first;
+    if (threadIdx.x == 0) {
+        const int e0 = min(blockIdx.x * blockDim.x, E - 1);
+        int lo = 0, hi = n_graphs;          // last g with edge_ptr[g] <= e0
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (edge_ptr[mid] <= e0) lo = mid; else hi = mid;
+        }
+        g_first = lo;
+    }
+    __syncthreads();
+    int g = g_first;
+    while (g + 1 < n_graphs && edge_ptr[g + 1] <= e) ++g;
+    return g;
+}
+
+__global__ void k_extract_runs(const int64_t* __restrict__ ei, const int64_t* __restrict__ ea, int A, int N, int E,
+                               int n_graphs, const int32_t* __restrict__ node_ptr, const int32_t* __restrict__ edge_ptr,
+                               int32_t* __restrict__ row32, int32_t* __restrict__ col32, uint8_t* __restrict__ etype_in,
+                               int32_t* __restrict__ iota, int32_t* __restrict__ split, int32_t* __restrict__ status) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = graph_of_edge(edge_ptr, n_graphs, min(e, E - 1), E);
+    if (e >= E) return;
+    int64_t r = ei[e], c = ei[(size_t)E + e];
+    int bad = 0;
+    if (r < 0 || r >= N || c < 0 || c >= N) { bad |= 1; r = 0; c = 0; }
+    if (r < node_ptr[g] || r >= node_ptr[g + 1] || c < node_ptr[g] || c >= node_ptr[g + 1]) bad |= 4;
+    if (e > edge_ptr[g] && ei[e - 1] > r) {          // a descent inside the graph: the second run starts here
+        const int old = atomicMin(&split[g], e);
+        if (old != edge_ptr[g + 1]) bad |= 4;          // more than one descent: not two sorted runs
+    }
+    row32[e] = (int32_t)r;
+    col32[e] = (int32_t)c;
+    iota[e] = e;
+    if (A > 0) {
+        int hot = -1, ones = 0, other = 0;
+        for (int a = 0; a < A; ++a) {
+            int64_t v = ea[(size_t)e * A + a];
+            if (v == 1) { ones++; hot = a; }
+            else if (v != 0) other = 1;
+        }
+        if (ones != 1 || other) { bad |= 2; if (hot < 0) hot = 0; }
+        etype_in[e] = (uint8_t)hot;
+    }
+    if (bad) atomicOr(status, bad);
+}
+
+__global__ void k_init_split(int n_graphs, const int32_t* __restrict__ edge_ptr, int32_t* __restrict__ split) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_graphs) split[g] = edge_ptr[g + 1];      // no descent: the second run is empty
+}
+
+// per node: where its edges start in the first / second run of its graph, how many the first run has, degree
+__global__ void k_run_starts(const int32_t* __restrict__ row32, int N, int E, int n_graphs,
+                             const int32_t* __restrict__ status, const int32_t* __restrict__ node_ptr,
+                             const int32_t* __restrict__ edge_ptr, const int32_t* __restrict__ split,
+                             int32_t* __restrict__ start_a, int32_t* __restrict__ start_b, int32_t* __restrict__ cnt_a,
+                             int32_t* __restrict__ deg, float* __restrict__ inv_deg) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    if (*status & 4) {      // broken contract (all of it is known after k_extract_runs): a SAFE graph - every
+        // edge a self-edge of node 0 - so that nothing downstream indexes out of bounds before the host raises
+        start_a[n] = 0; start_b[n] = 0; cnt_a[n] = 0;
+        deg[n] = n == 0 ? E : 0;
+        if (n == N - 1) deg[N] = 0;
+        inv_deg[n] = 1.0f;
+        return;
+    }
+    int lo = 0, hi = n_graphs;          // graph of node n
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (node_ptr[mid] <= n) lo = mid; else hi = mid;
+    }
+    const int g = lo;
+    auto lb = [&](int first, int last, int key) {     // first position in [first, last) with row >= key
+        while (first < last) {
+            const int mid = (first + last) >> 1;
+            if (row32[mid] < key) first = mid + 1; else last = mid;
+        }
+        return first;
+    };
+    const int a0 = edge_ptr[g], a1 = split[g], b1 = edge_ptr[g + 1];
+    const int sa = lb(a0, a1, n), sa_next = lb(sa, a1, n + 1);
+    const int sb = lb(a1, b1, n), sb_next = lb(sb, b1, n + 1);
+    start_a[n] = sa;
+    start_b[n] = sb;
+    cnt_a[n] = sa_next - sa;
+    const int d = (sa_next - sa) + (sb_next - sb);
+    deg[n] = d;
+    if (n == N - 1) deg[N] = 0;
+    inv_deg[n] = 1.0f / (float)(d > 1 ? d : 1);
+}
+
+__global__ void k_place_runs(const int32_t* __restrict__ row32, const int32_t* __restrict__ col32,
+                             const uint8_t* __restrict__ etype_in, int E, int n_graphs,
+                             const int32_t* __restrict__ edge_ptr, const int32_t* __restrict__ split,
+                             const int32_t* __restrict__ rowptr, const int32_t* __restrict__ start_a,
+                             const int32_t* __restrict__ start_b, const int32_t* __restrict__ cnt_a,
+                             int32_t* __restrict__ row, int32_t* __restrict__ col, uint8_t* __restrict__ etype,
+                             int32_t* __restrict__ perm, const int32_t* __restrict__ status) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = graph_of_edge(edge_ptr, n_graphs, min(e, E - 1), E);
+    if (e >= E) return;
+    if (*status & 4) {      // the safe graph of k_run_starts
+        row[e] = 0; col[e] = 0; perm[e] = e;
+        if (etype) etype[e] = 0;
+        return;
+    }
+    // (two sorted runs per graph with rows inside the graph's range - verified by k_extract_runs - make the
+    // positions below a bijection onto [0, E): every slot is written exactly once)
+    const int r = row32[e];
+    const bool second = e >= split[g];
+    const int off = second ? e - start_b[r] : e - start_a[r];
+    const int local = second ? cnt_a[r] + off : off;
+    const int pos = rowptr[r] + local;
+    row[pos] = r;
+    col[pos] = col32[e];
+    if (etype) etype[pos] = etype_in[e];
+    perm[pos] = e;
+}
+
+struct RunsWs {
+    int32_t *row32, *col32, *iota, *keys_tmp, *split, *start_a, *start_b, *cnt_a, *deg;
+    uint8_t* etype_in;
+    void *sort_tmp, *scan_tmp;
+    size_t sort_bytes, scan_bytes;
+};
+
+size_t carve_runs(PvsArena& a, int N, int E, int B, RunsWs* w) {
+    const size_t e = (size_t)(E > 0 ? E : 1);
+    RunsWs t;
+    t.row32 = a.take<int32_t>(e);
+    t.col32 = a.take<int32_t>(e);
+    t.iota = a.take<int32_t>(e);
+    t.keys_tmp = a.take<int32_t>(e);
+    t.etype_in = a.take<uint8_t>(e);
+    t.split = a.take<int32_t>((size_t)B + 1);
+    t.start_a = a.take<int32_t>((size_t)N);
+    t.start_b = a.take<int32_t>((size_t)N);
+    t.cnt_a = a.take<int32_t>((size_t)N);
+    t.deg = a.take<int32_t>((size_t)N + 1);
+    t.sort_bytes = sort_temp_bytes(E > 0 ? E : 1, key_bits(N > 1 ? N : 2));
+    t.sort_tmp = a.take<char>(t.sort_bytes);
+    t.scan_bytes = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, t.scan_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, N + 1, 0);
+    t.scan_tmp = a.take<char>(t.scan_bytes);
+    if (w) *w = t;
+    return a.off;
+}
+
+}  // namespace
+
+extern "C" size_t pvs_graph_prepare_runs_workspace_bytes(int32_t n_nodes, int32_t n_edges, int32_t n_graphs) {
+    PvsArena a(nullptr, 0);
+    return carve_runs(a, n_nodes, n_edges, n_graphs, nullptr) + 256;
+}
+
+extern "C" int pvs_graph_prepare_runs(const int64_t* edge_index, const int64_t* edge_attr, int32_t n_edge_attr,
+                                      int32_t N, int32_t E, int32_t n_graphs, const int32_t* node_ptr,
+                                      const int32_t* edge_ptr, int32_t* rowptr, int32_t* row, int32_t* col,
+                                      uint8_t* etype, int32_t* perm, int32_t* colptr, int32_t* cedge, float* inv_deg,
+                                      int32_t* status, void* workspace, size_t workspace_bytes, pvs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PVS_REQUIRE(N > 0 && E >= 0 && n_graphs > 0, "pvs_graph_prepare_runs: bad sizes N=%d E=%d B=%d", N, E, n_graphs);
+    PVS_REQUIRE(n_edge_attr >= 0 && n_edge_attr <= 255, "pvs_graph_prepare_runs: bad n_edge_attr %d", n_edge_attr);
+    PVS_REQUIRE(n_edge_attr == 0 || (edge_attr && etype), "pvs_graph_prepare_runs: edge_attr/etype NULL");
+    PVS_REQUIRE(node_ptr && edge_ptr, "pvs_graph_prepare_runs: node_ptr / edge_ptr NULL");
+    PVS_REQUIRE((colptr == nullptr) == (cedge == nullptr), "pvs_graph_prepare_runs: colptr and cedge go together");
+    PvsArena arena(workspace, workspace_bytes);
+    RunsWs w;
+    carve_runs(arena, N, E, n_graphs, &w);
+    PVS_REQUIRE(arena.ok(), "pvs_graph_prepare_runs: workspace too small (%zu < %zu)", workspace_bytes, arena.off);
+    PvsProfScope prof(stream, PVS_PROF_PREPARE);
+    PVS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), stream));
+    const int T = 256;
+    k_init_split<<<(n_graphs + T - 1) / T, T, 0, stream>>>(n_graphs, edge_ptr, w.split);
+    PVS_CHECK_LAUNCH();
+    if (E > 0) {
+        k_extract_runs<<<(E + T - 1) / T, T, 0, stream>>>(edge_index, edge_attr, n_edge_attr, N, E, n_graphs, node_ptr,
+                                                          edge_ptr, w.row32, w.col32, w.etype_in, w.iota, w.split, status);
+        PVS_CHECK_LAUNCH();
+    }
+    k_run_starts<<<(N + T - 1) / T, T, 0, stream>>>(w.row32, N, E, n_graphs, status, node_ptr, edge_ptr, w.split, w.start_a,
+                                                    w.start_b, w.cnt_a, w.deg, inv_deg);
+    PVS_CHECK_LAUNCH();
+    size_t sb = w.scan_bytes;
+    PVS_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(w.scan_tmp, sb, w.deg, rowptr, N + 1, stream));
+    if (E > 0) {
+        k_place_runs<<<(E + T - 1) / T, T, 0, stream>>>(w.row32, w.col32, w.etype_in, E, n_graphs, edge_ptr, w.split,
+                                                        rowptr, w.start_a, w.start_b, w.cnt_a, row, col,
+                                                        n_edge_attr ? etype : nullptr, perm, status);
+        PVS_CHECK_LAUNCH();
+        if (cedge) {   // by-column lists: only the backward reads them
+            size_t tb = w.sort_bytes;
+            const int bits = key_bits(N > 1 ? N : 2);
+            PVS_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(w.sort_tmp, tb, col, w.keys_tmp, w.iota, cedge, E, 0,
+                                                             bits, stream));
+        }
+    }
+    if (cedge) {
+        k_lower_bounds<<<(N + 1 + T - 1) / T, T, 0, stream>>>(w.keys_tmp, E, N, colptr, nullptr);
+        PVS_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
 // CSC of an existing CSR (shared with the radius-graph builder): cedge = CSR positions grouped by
 // column, stable; colptr = offsets.
 namespace {

@@ -8,6 +8,7 @@ int64 one-hot; every layer's forward and backward of a step share one instance.
 """
 import collections
 import ctypes as C
+import os
 
 import torch
 
@@ -53,6 +54,11 @@ class Batch(Data):
                 merged[key] = None
             else:
                 merged[key] = vals
+        # 'generate_edges' = every graph's edge list is the reference loader's: the inter-molecular block then
+        # the intra-molecular block, each row-major (preprocessing.py:108-142). Collation keeps that per graph,
+        # so the batch can be prepared by merging sorted runs (pvs_graph_prepare_runs) instead of sorting.
+        tags = {getattr(item, 'edge_layout', None) for item in items}
+        merged['edge_layout'] = tags.pop() if len(tags) == 1 else None
         merged['batch'] = torch.cat(batch_vec)
         merged['ptr'] = torch.tensor(ptr, dtype=torch.long)
         merged['num_graphs'] = len(items)
@@ -104,6 +110,10 @@ class PreparedGraph:
         if code & 2:
             raise ValueError('edge_attr rows must be one-hot (the reference data loader emits '
                              'one_hot(edge_type, 3)); dense edge attributes are not supported')
+        if code & 4:
+            raise ValueError("the batch promises edge_layout == 'generate_edges' (per graph: two row-sorted runs, "
+                             "node ids inside the graph's range) but its edge list is not laid out that way; "
+                             "drop the tag (batch.edge_layout = None) to use the general sort")
         self._status_checked = True
 
     def check_status(self):
@@ -115,10 +125,29 @@ class PreparedGraph:
 _PENDING = []
 
 
-def prepare_graph(edge_index, edge_attr, n_nodes, need_backward=None):
+def runs_layout(graph, device=None):
+    """(node_ptr, edge_ptr) device int32 tensors of a batch that carries the 'generate_edges' tag, else
+    None. Cached on the batch object (one small host-to-device copy per batch)."""
+    if getattr(graph, 'edge_layout', None) != 'generate_edges' or os.environ.get('PVS_PREPARE_RUNS') == '0':
+        return None
+    cached = getattr(graph, '_runs_layout', None)
+    if cached is not None and (device is None or cached[0].device == torch.device(device)):
+        return cached
+    counts, ptr = getattr(graph, 'graph_edge_counts', None), getattr(graph, 'ptr', None)
+    if counts is None or ptr is None:
+        return None
+    dev = graph.edge_index.device if device is None else device
+    edge_ptr = torch.tensor([0] + list(counts), dtype=torch.int64).cumsum(0).to(dtype=torch.int32)
+    layout = (ptr.to(device=dev, dtype=torch.int32).contiguous(), edge_ptr.to(dev, non_blocking=True))
+    graph._runs_layout = layout
+    return layout
+
+
+def prepare_graph(edge_index, edge_attr, n_nodes, need_backward=None, layout=None):
     """int64 COO `[2,E]` (+ int64 one-hot `[E,A]` or None) -> PreparedGraph on the same device.
     need_backward=False (default: torch.is_grad_enabled()) skips the by-column lists that only the
-    backward reads."""
+    backward reads. layout = runs_layout(batch): the batch's edge list has the reference loader's
+    layout (two row-sorted runs per graph), prepared by merging instead of sorting (checked on the device)."""
     if need_backward is None:
         need_backward = torch.is_grad_enabled()
     _lib.require_hip(edge_index, edge_attr)
@@ -149,15 +178,27 @@ def prepare_graph(edge_index, edge_attr, n_nodes, need_backward=None):
         t['etype'] = torch.empty(e_alloc, dtype=torch.uint8, device=dev)
     if need_backward:
         t['colptr'], t['cedge'] = torch.empty(n_nodes + 1, **i32), torch.empty(e_alloc, **i32)
-    ws_bytes = lib.pvs_graph_prepare_workspace_bytes(n_nodes, n_edges)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    rc = lib.pvs_graph_prepare(
-        _lib.ptr(edge_index), _lib.ptr(edge_attr), n_attr, n_nodes, n_edges,
-        _lib.ptr(t['rowptr']), _lib.ptr(t['row']), _lib.ptr(t['col']), _lib.ptr(t.get('etype')),
-        _lib.ptr(t['perm']), _lib.ptr(t.get('colptr')), _lib.ptr(t.get('cedge')), _lib.ptr(t['inv_deg']),
-        _lib.ptr(t['status']), _lib.ptr(ws), ws_bytes, stream)
-    _lib.check(rc, 'pvs_graph_prepare')
+    outputs = (_lib.ptr(t['rowptr']), _lib.ptr(t['row']), _lib.ptr(t['col']), _lib.ptr(t.get('etype')),
+               _lib.ptr(t['perm']), _lib.ptr(t.get('colptr')), _lib.ptr(t.get('cedge')), _lib.ptr(t['inv_deg']),
+               _lib.ptr(t['status']))
+    if layout is not None and n_edges > 0:
+        node_ptr, edge_ptr = layout
+        n_graphs = int(node_ptr.numel()) - 1
+        ws_bytes = lib.pvs_graph_prepare_runs_workspace_bytes(n_nodes, n_edges, n_graphs)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        rc = lib.pvs_graph_prepare_runs(
+            _lib.ptr(edge_index), _lib.ptr(edge_attr), n_attr, n_nodes, n_edges, n_graphs, _lib.ptr(node_ptr),
+            _lib.ptr(edge_ptr), *outputs, _lib.ptr(ws), ws_bytes, stream)
+        _lib.check(rc, 'pvs_graph_prepare_runs')
+        t['_layout'] = layout      # (keeps the pointer tables alive until the kernels have run)
+    else:
+        ws_bytes = lib.pvs_graph_prepare_workspace_bytes(n_nodes, n_edges)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        rc = lib.pvs_graph_prepare(
+            _lib.ptr(edge_index), _lib.ptr(edge_attr), n_attr, n_nodes, n_edges, *outputs, _lib.ptr(ws), ws_bytes,
+            stream)
+        _lib.check(rc, 'pvs_graph_prepare')
     return PreparedGraph(n_nodes, n_edges, n_attr, t)
 
 
@@ -205,13 +246,13 @@ _CACHE_SIZE = 4
 CACHE_ENABLED = True   # bench.py turns this off: a training step prepares every batch afresh
 
 
-def prepared_for(edge_index, edge_attr, n_nodes):
+def prepared_for(edge_index, edge_attr, n_nodes, layout=None):
     """Cached `prepare_graph`: the L layers of a forward are called with the same edge tensors."""
     pre = _take_prefetched(edge_index, edge_attr, n_nodes)
     if pre is not None:
         return pre
     if not CACHE_ENABLED:
-        return prepare_graph(edge_index, edge_attr, n_nodes)
+        return prepare_graph(edge_index, edge_attr, n_nodes, layout=layout)
     key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
            None if edge_attr is None else (edge_attr.data_ptr(), edge_attr._version), n_nodes,
            torch.is_grad_enabled())      # a forward-only graph has no by-column lists
@@ -219,7 +260,7 @@ def prepared_for(edge_index, edge_attr, n_nodes):
     if hit is not None:
         _CACHE.move_to_end(key)
         return hit[0]
-    pg = prepare_graph(edge_index, edge_attr, n_nodes)
+    pg = prepare_graph(edge_index, edge_attr, n_nodes, layout=layout)
     _CACHE[key] = (pg, edge_index, edge_attr)  # hold the inputs so data_ptr keys stay unique
     while len(_CACHE) > _CACHE_SIZE:
         _CACHE.popitem(last=False)

@@ -13,7 +13,7 @@ from torch import nn
 
 from . import functional as PF
 from .global_objects import DEVICE
-from .graph import prepared_for
+from .graph import prepared_for, runs_layout
 from .point_neural_network_base import PointNeuralNetworkBase
 
 
@@ -44,7 +44,7 @@ class PNNGeometricBase(PointNeuralNetworkBase):
         graph_ptr = ptr.to(device=feats.device, dtype=torch.int32).contiguous()
         pg = getattr(graph, 'prepared', None)     # built on the GPU (radius_graph.attach_radius_graph)
         if pg is None:
-            pg = prepared_for(edges, edge_attributes, n_nodes)
+            pg = prepared_for(edges, edge_attributes, n_nodes, layout=runs_layout(graph, feats.device))
         pg.poll_status()
         feats, _, _ = self.embed_prepared(pg, feats, coords, need_coords=False)
         return feats, pg, graph_ptr, n_graphs

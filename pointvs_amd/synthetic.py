@@ -40,7 +40,8 @@ def synthetic_graph(seed, n_nodes=2000, n_lig=30, edge_radius=10.0, density=0.05
         x=torch.from_numpy(feats), pos=torch.from_numpy(pts),
         edge_index=torch.from_numpy(np.vstack([e_rows, e_cols]).astype(np.int64)),
         edge_attr=torch.from_numpy(np.eye(3, dtype=np.int64)[e_type]),   # int64 one-hot(3)
-        y=torch.tensor(seed % 2), lig_fname=f'lig_{seed}', rec_fname=f'rec_{seed}')
+        y=torch.tensor(seed % 2), lig_fname=f'lig_{seed}', rec_fname=f'rec_{seed}',
+        edge_layout='generate_edges')     # inter block then intra block, each row-major: see graph.runs_layout
 
 
 def synthetic_batch(cfg_id, batch_size, first_graph=0, **graph_kwargs):

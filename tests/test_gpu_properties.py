@@ -653,3 +653,45 @@ def test_public_submethods_compose_to_the_fused_layer(flags):
         outs.append([t.detach().cpu().numpy() for t in (h_out, x_out, m, h.grad, x.grad)])
     for a, b, name in zip(outs[0], outs[1], ('h', 'x', 'm', 'g_h', 'g_x')):
         assert rel_err(a, b) < 2e-5, name
+
+
+def test_prepare_by_merging_sorted_runs_equals_the_sort():
+    """pvs_graph_prepare_runs (batches tagged edge_layout == 'generate_edges': two row-sorted runs per graph,
+    merged by counting) gives array for array what the radix-sort path gives - on ragged batches, with and
+    without the by-column lists - and a list that breaks the promised layout raises instead of mis-sorting."""
+    from pointvs_amd.graph import Batch, prepare_graph, runs_layout
+    from pointvs_amd.synthetic import synthetic_graph
+    sizes = [(300, 20, 6.0), (57, 5, 5.0), (800, 30, 7.0), (33, 32, 9.0), (120, 1, 4.0)]
+    items = [synthetic_graph(700 + k, n_nodes=n, n_lig=nl, edge_radius=r) for k, (n, nl, r) in enumerate(sizes)]
+    batch = Batch.from_data_list(items).to('cuda')
+    assert batch.edge_layout == 'generate_edges'
+    layout = runs_layout(batch)
+    n = int(batch.x.shape[0])
+    for need_backward in (True, False):
+        a = prepare_graph(batch.edge_index, batch.edge_attr, n, need_backward=need_backward, layout=layout)
+        b = prepare_graph(batch.edge_index, batch.edge_attr, n, need_backward=need_backward)
+        a.check_status(); b.check_status()
+        for name in ('rowptr', 'row', 'col', 'etype', 'perm', 'inv_deg') + (('colptr', 'cedge') if need_backward else ()):
+            assert torch.equal(a.t[name], b.t[name]), name
+    # the model-level path picks the merge up from the tag and gives the same numbers as the sort
+    model, _ = make_model(seed=2, num_layers=2)
+    y_runs, g_runs = gpu_run(model, batch)
+    os.environ['PVS_PREPARE_RUNS'] = '0'
+    try:
+        plain = Batch.from_data_list(items)
+        y_sort, g_sort = gpu_run(model, plain)
+    finally:
+        os.environ.pop('PVS_PREPARE_RUNS')
+    assert y_runs.tobytes() == y_sort.tobytes()
+    for name in g_runs:
+        if g_runs[name] is not None:
+            assert g_runs[name].tobytes() == g_sort[name].tobytes(), name
+    # a broken promise: edges of one graph shuffled
+    bad = Batch.from_data_list(items).to('cuda')
+    e0 = bad.graph_edge_counts[0]
+    perm = torch.randperm(e0, generator=torch.Generator().manual_seed(0)).cuda()
+    bad.edge_index[:, :e0] = bad.edge_index[:, :e0][:, perm]
+    bad.edge_attr[:e0] = bad.edge_attr[:e0][perm]
+    pg = prepare_graph(bad.edge_index, bad.edge_attr, n, layout=runs_layout(bad))
+    with pytest.raises(ValueError, match='generate_edges'):
+        pg.check_status()
