@@ -1156,6 +1156,17 @@ __device__ __forceinline__ void wgrad_parts64(const unsigned short* __restrict__
     }
 }
 
+// timing-only ablations (tools/ab.py variants; never built into the shipped library)
+#ifdef PVS_ABL_T_NOBAR
+#define TEAM_SYNC() ((void)0)
+#else
+#define TEAM_SYNC() __syncthreads()
+#endif
+#ifdef PVS_ABL_T_NOWGRAD
+#define TEAM_WGRAD(...) ((void)0)
+#else
+#define TEAM_WGRAD(...) wgrad_parts64(__VA_ARGS__)
+#endif
 template <bool ERES, bool EATT>
 __global__ void __launch_bounds__(256, 1)
 k_edge_bwd_team_parts(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks,
@@ -1329,7 +1340,7 @@ k_edge_bwd_team_parts(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEd
             load16_tab(io.gM + (size_t)i * H + co, hh, gMi);
             rows_of(nxt);
             const Idx nn = idx_of(it + 2);
-            __syncthreads();                                                     // (1) PA complete
+            TEAM_SYNC();                                                     // (1) PA complete
             // ---- z2 = W2 a1 + b2 (own output block) ----
             float dz2[16], m[16];
             float m_new[ERES ? 16 : 1], mp[ERES ? 16 : 1];
@@ -1377,7 +1388,7 @@ k_edge_bwd_team_parts(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEd
                 pdot += __shfl_xor(pdot, 32, 64);
                 if (hh == 0) { pdA[cb * kTile + j] = pl; pdB[cb * kTile + j] = pdot; }
             }
-            __syncthreads();                                                     // (2) PB, pd complete
+            TEAM_SYNC();                                                     // (2) PB, pd complete
             float g_l = 0.f, aval = 1.f;
             if constexpr (EATT) {
                 const float logit = sum_pd(pdA) + bac;
@@ -1418,9 +1429,9 @@ k_edge_bwd_team_parts(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEd
                     dq[r] = pvs_silu_grad(zc, sg);
                 }
                 const float ps = dot16_tab(wc2t + co, hh, q);
-                __syncthreads();                                                 // (3a) pdA reads of (2) done
+                TEAM_SYNC();                                                 // (3a) pdA reads of (2) done
                 if (hh == 0) pdA[cb * kTile + j] = ps;
-                __syncthreads();                                                 // (3) pdA complete
+                TEAM_SYNC();                                                 // (3) pdA complete
                 float s = sum_pd(pdA);
                 float dact = 1.f;
                 if (flags & PVS_TANH) { s = pvs_tanh(s); dact = 1.f - s * s; }
@@ -1437,12 +1448,12 @@ k_edge_bwd_team_parts(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEd
                 }
                 split_bf16x3(g_zc, own);
                 write_parts64(PC, j, hh, cb, own);
-                __syncthreads();                                                 // (4) PC = g_zc complete
+                TEAM_SYNC();                                                 // (4) PC = g_zc complete
                 read_parts64(PC, lane, pb, oth);
                 chain_block_parts<true>(Wc1i, lane, cb, cb, own, gm);            // g_m += Wc1^T g_zc
                 chain_block_parts<true>(Wc1i, lane, cb, pb, oth, gm);
                 // ---- Wc1 weight gradient (row block cb) ----
-                wgrad_parts64(PC, PB, lane, cb, gWc1);
+                TEAM_WGRAD(PC, PB, lane, cb, gWc1);
             }
             // ---- edge residual, g_z2 ----
             float g_z2[16];
@@ -1475,9 +1486,9 @@ k_edge_bwd_team_parts(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEd
                 }
             }
             split_bf16x3(g_z2, own);
-            __syncthreads();                                                     // (5) PC / PB reads done
+            TEAM_SYNC();                                                     // (5) PC / PB reads done
             write_parts64(PC, j, hh, cb, own);
-            __syncthreads();                                                     // (6) PC = g_z2 complete
+            TEAM_SYNC();                                                     // (6) PC = g_z2 complete
             // ---- g_a1 = W2^T g_z2 (own block); g_z1 = g_a1 * SiLU'(z1) ----
             f32x16 ga1;
 #pragma unroll
@@ -1494,8 +1505,8 @@ k_edge_bwd_team_parts(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEd
             const float prho = dot16_tab(wrhot + co, hh, g_z1);
             if (hh == 0) pdA[cb * kTile + j] = prho;
             // ---- W2 weight gradient (row block cb) ----
-            wgrad_parts64(PC, PA, lane, cb, gW2);
-            __syncthreads();                                                     // (7) pdA complete; PB free
+            TEAM_WGRAD(PC, PA, lane, cb, gW2);
+            TEAM_SYNC();                                                     // (7) pdA complete; PB free
             const float g_rho = sum_pd(pdA);
             const float k1 = s_coord * nrm * vm;
             const float gd0 = fmaf(k1, gT0, 2.f * d0 * g_rho);
@@ -1508,7 +1519,7 @@ k_edge_bwd_team_parts(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEd
                         make_float4(gd0, gd1, gd2, pvs_pack_rho_type(rho, ty));
             }
             xwrite_block<HB>(T1, j, hh, cb, g_z1);
-            __syncthreads();                                                     // (8) T1 = g_z1, tx complete
+            TEAM_SYNC();                                                     // (8) T1 = g_z1, tx complete
             // own 128-byte half-rows of g_z1 to HBM + row-side sums of the own channel block
             {
                 float4 v[4], dx[4];
@@ -1537,9 +1548,12 @@ k_edge_bwd_team_parts(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEd
                     const int pos = __builtin_ctz(bm);
                     bm &= bm - 1u;
                     cur_row = __builtin_amdgcn_readfirstlane(rowbuf[pos]);
+#ifdef PVS_ABL_T_NOBAR
+                    cur_row = min(max(cur_row, 0), g.n_nodes - 1);     // (racy read in this timing-only build)
+#endif
                 }
             }
-            __syncthreads();                                                     // (9) tile buffers free
+            TEAM_SYNC();                                                     // (9) tile buffers free
             cur = nxt;
             nxt = nn;
         }
@@ -1622,12 +1636,9 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
         const bool all_bf16 = !(bf && bf[0] == '0');
         if (H == 32 && all_bf16 && !eres_on && !(b32 && b32[0] == '0'))
             return pvs_launch_edge_bwd_bf16(s, H, g, w, flags, att_act, io, e_lo, e_hi, n_slabs);
-#ifdef PVS_BWD_BF16_H64      // (see edge_bwd_bf16.hip: measured slower than the team kernel, not built by default)
+        // H = 64: one wave per 16-edge tile (edge_bwd_h64.hip); PVS_BWD64=0: the round-1 team kernel below
         if (H == 64 && all_bf16 && !(b64 && b64[0] == '0'))
-            return pvs_launch_edge_bwd_bf16(s, H, g, w, flags, att_act, io, e_lo, e_hi, n_slabs);
-#else
-        (void)b64;
-#endif
+            return pvs_launch_edge_bwd_h64(s, g, w, flags, att_act, io, e_lo, e_hi, n_slabs);
     }
     const int nt = bf16x3 ? 512 : kThreads, nw = nt / 64;
     // resident blocks per launch: H=32 fp32: 2 x 256 threads per CU; bf16x3: 1 x 512; H=64: 1 x 256
