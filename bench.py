@@ -529,7 +529,7 @@ def main():
             dom_bytes = algorithmic_bytes_edge_bwd(n_nodes, n_edges, h)
             dom_flops = (12.0 * h * h + 4 * h) * n_edges     # 2 recompute + 2 dgrad + 2 wgrad products
             dom_symbol = (('k_edge_bwd_bf16' if os.environ.get('PVS_BWD32') != '0' else 'k_edge_bwd_mfma') if h == 32
-                          else 'k_edge_bwd_team_parts')
+                          else ('k_edge_bwd_h64' if os.environ.get('PVS_BWD64') != '0' else 'k_edge_bwd_team_parts'))
             dom_name = (f'{dom_symbol} (H={h} edge backward, one launch per layer)')
             step_bytes = layers * algorithmic_bytes_per_layer(n_nodes, n_edges, h)
         else:            # forward only: the edge forward

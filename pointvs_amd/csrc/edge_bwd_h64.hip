@@ -215,18 +215,34 @@ __device__ __forceinline__ float sum_groups(float s) {
     return s;
 }
 
-// node rows of one tile, gathered one tile ahead
+// node rows and per-row / per-edge scalars of one tile, fetched one tile ahead. EVERYTHING the first half of a
+// tile reads from HBM is in here: a load issued at the top of the tile would sit in front of the wait for this
+// struct's registers (the loop-carried wait is vmcnt(0): one in-order counter), exposing its whole latency.
 struct Gather16 {
     float P[16], Q[16];
     float xi0, xi1, xi2, xj0, xj1, xj2;
+    float gT0, gT1, gT2;      // gxagg row (coordinate update)
+    float aval, softd;        // attention value of the edge, softmax row term
 };
 
-__device__ __forceinline__ void gather16(const float* __restrict__ PQ, const float* __restrict__ x, const TileIdx& t,
-                                         int gr, Gather16& G) {
-    load_y(PQ + (size_t)t.i * 2 * kH, gr, G.P);
-    load_y(PQ + (size_t)t.jn * 2 * kH + kH, gr, G.Q);
+template <bool EATT>
+__device__ __forceinline__ void gather16(const PvsEdgeBwdIO& io, const TileIdx& t, int gr, bool upd, bool softmax,
+                                         Gather16& G) {
+    load_y(io.PQ + (size_t)t.i * 2 * kH, gr, G.P);
+    load_y(io.PQ + (size_t)t.jn * 2 * kH + kH, gr, G.Q);
+    const float* x = io.x;
     G.xi0 = x[3 * t.i]; G.xi1 = x[3 * t.i + 1]; G.xi2 = x[3 * t.i + 2];
     G.xj0 = x[3 * t.jn]; G.xj1 = x[3 * t.jn + 1]; G.xj2 = x[3 * t.jn + 2];
+    // UNCONDITIONAL loads from a pointer chosen by the (uniform) condition - the consumer selects: a load under
+    // a branch reaches its consumer through a phi, and the register copies that implement the phi wait for the
+    // load where it was issued (s_waitcnt vmcnt(0) right behind the prefetch: the whole latency, every tile)
+    const float* gx = upd ? io.gxagg : io.x;          // (x is [N,3] like gxagg)
+    G.gT0 = gx[3 * t.i]; G.gT1 = gx[3 * t.i + 1]; G.gT2 = gx[3 * t.i + 2];
+    G.aval = 1.f; G.softd = 0.f;
+    if constexpr (EATT) {
+        G.aval = io.att[t.ee];
+        G.softd = *(softmax ? io.softD + t.i : io.att + t.ee);
+    }
 }
 
 // Row (segment) reduction of the 16-edge g_z1 tile: reduce_rows_tile (edge_mfma_common.h) with 16 rows -
@@ -373,26 +389,39 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
         TileIdx I = load_tile_idx(g, w.n_attr, e_begin, e_begin, e_end, n);
         TileIdx In = load_tile_idx(g, w.n_attr, e_begin + kT16, e_begin, e_end, n);
         Gather16 G;
-        if (e_begin < e_end) gather16(io.PQ, io.x, I, gr, G);
-#ifdef PVS_H64_UNROLL2
-#pragma unroll 2
+        if (e_begin < e_end) gather16<EATT>(io, I, gr, upd, flags & PVS_SOFTMAX_ATT, G);
+        // The tile's HBM stores (g_z1 rows, gd records, finished rows of gPQ / gx_row) are issued at the START of
+        // the next tile, after that tile's first loads: vmcnt counts loads and stores in one in-order queue, so
+        // a wait for a load issued after a store also waits for the store's acknowledgement from HBM, and with
+        // one wave per SIMD nothing else runs meanwhile (s_waitcnt was 26 % of the wave's cycles). The g_z1
+        // tile, tx and rowbuf stay in LDS until then (their slot - the m image - is next written mid-tile).
+        int pend_e0 = -1;
+        unsigned pend_bmask = 0u;
+        auto store_phase = [&]() {
+            if (gr == 0 && pend_e0 + n < e_end)       // per edge: grad wrt (x_row - x_col), rho and class: 16 B
+                pvs_store_nt(io.gd + (size_t)(pend_e0 + n) * 4, *reinterpret_cast<const float4*>(tx + n * 4));
+#ifndef PVS_ABL_H_NOSEG
+            const int pe0 = pend_e0;
+            reduce_rows16(T1, tx, rowbuf, pend_bmask, lane, acc, accx, cur_row, flush,
+                          [&](int rl, int q, const float4& v) {
+                              if (pe0 + rl < e_end)   // streamed once: non-temporal
+                                  pvs_store_nt(io.gz1 + (size_t)(pe0 + rl) * H + 4 * q, v);
+                          });
 #endif
+            pvs_wave_lds_sync();
+        };
         for (int e0 = e_begin; e0 < e_end; e0 += kT16) {
             const int e = I.e, ee = I.ee, i = I.i, ty = I.ty;
             const bool valid = I.valid;
             const float vm = valid ? 1.f : 0.f;
             const unsigned bmask = (unsigned)__ballot(valid && gr == 0 && i != I.prev_row) & 0xffffu;
-            // ---- this tile's small late operands (the 16-register ones are fetched where the pressure allows) ----
+            // (the 16-register row operands are fetched mid-tile, where the pressure allows)
             float gMi[16];
-            float gT0 = 0.f, gT1 = 0.f, gT2 = 0.f;
-            if (upd) { gT0 = io.gxagg[3 * i]; gT1 = io.gxagg[3 * i + 1]; gT2 = io.gxagg[3 * i + 2]; }
-            float aval = 1.f, softd = 0.f;
-            if constexpr (EATT) {
-                aval = io.att[ee];
-                if (flags & PVS_SOFTMAX_ATT) softd = io.softD[i];
-            }
+            const float gT0 = upd ? G.gT0 : 0.f, gT1 = upd ? G.gT1 : 0.f, gT2 = upd ? G.gT2 : 0.f;
+            const float aval = G.aval, softd = G.softd;      // (softd is only read under PVS_SOFTMAX_ATT)
             float mp[ERES ? 16 : 1];
             if constexpr (ERES) load_y(io.m_prev + (size_t)ee * H, gr, mp);
+            if (pend_e0 >= 0) store_phase();           // the previous tile's stores, behind this tile's loads
 
             const float d0 = G.xi0 - G.xj0, d1 = G.xi1 - G.xj1, d2 = G.xi2 - G.xj2;
             const float rho = d0 * d0 + d1 * d1 + d2 * d2;
@@ -489,11 +518,6 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             } else {
                 load_y(io.gM + (size_t)i * H, gr, gMi);
             }
-            // ---- software pipeline: the node rows of tile t+1 and the indices of tile t+2 are fetched from here
-            // on (the register peak - the coordinate branch - is over; ~4k cycles of work remain to cover them) ----
-            Gather16 Gn;
-            gather16(io.PQ, io.x, In, gr, Gn);
-            const TileIdx Inn = load_tile_idx(g, w.n_attr, e0 + 2 * kT16, e_begin, e_end, n);
             {   // external, aggregated-message and attention terms
                 if (io.g_m_out) {
                     float init[16];
@@ -525,6 +549,12 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                     for (int r = 0; r < 16; ++r) gm[r >> 2][r & 3] = fmaf(vm, gMi[r], gm[r >> 2][r & 3]);
                 }
             }
+            // ---- software pipeline: the node rows of tile t+1 and the indices of tile t+2 are fetched from here
+            // on: the register peak - the coordinate branch - is over, ~4k cycles of work remain to cover them, and the
+            // wait for gM_i above did not have to count (or, after the branch merge, drain) these loads ----
+            Gather16 Gn;
+            gather16<EATT>(io, In, gr, upd, flags & PVS_SOFTMAX_ATT, Gn);
+            const TileIdx Inn = load_tile_idx(g, w.n_attr, e0 + 2 * kT16, e_begin, e_end, n);
             // ---- edge residual; g_z2 = g_m_new * SiLU'(z2) ----
             float g_z2[16];
 #pragma unroll
@@ -579,28 +609,22 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             const float gd1 = fmaf(k1, gT1, 2.f * d1 * g_rho);
             const float gd2 = fmaf(k1, gT2, 2.f * d2 * g_rho);
             pvs_wave_lds_sync();          // every read of the m image (its slot becomes the g_z1 tile) is done
-            // per edge: grad wrt (x_row - x_col) and rho, 16 B, for the node gather kernel
+            // per edge: grad wrt (x_row - x_col) and rho (+ class), 16 B, for the node gather kernel
             if (gr == 0) {
-                *reinterpret_cast<float4*>(tx + n * 4) = make_float4(gd0, gd1, gd2, 0.f);
+                *reinterpret_cast<float4*>(tx + n * 4) = make_float4(gd0, gd1, gd2, pvs_pack_rho_type(rho, ty));
                 rowbuf[n] = i;
-                if (valid)
-                    pvs_store_nt(io.gd + (size_t)e * 4, make_float4(gd0, gd1, gd2, pvs_pack_rho_type(rho, ty)));
             }
-            // ---- g_z1 edge-major, then whole rows to HBM + the row-side sums from the same reads ----
+            // ---- g_z1 edge-major: whole rows go to HBM, and the row-side sums come from the same reads, in the
+            // deferred store phase ----
             store_y(T1 + n * kTS16, gr, g_z1);
-            pvs_wave_lds_sync();
-#ifndef PVS_ABL_H_NOSEG
-            reduce_rows16(T1, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
-                          [&](int rl, int q, const float4& v) {
-                              if (e0 + rl < e_end)   // streamed once: non-temporal
-                                  pvs_store_nt(io.gz1 + (size_t)(e0 + rl) * H + 4 * q, v);
-                          });
-#endif
+            pend_e0 = e0;
+            pend_bmask = bmask;
             I = In;
             In = Inn;
             G = Gn;
             pvs_wave_lds_sync();
         }
+        if (pend_e0 >= 0) store_phase();
         flush(cur_row);
     }
 
@@ -683,6 +707,11 @@ int pvs_launch_edge_bwd_h64(hipStream_t s, const PvsGraph& g, const PvsEdgeW& w,
     }
     *n_slabs = blocks;
     PvsProfScope prof(s, PVS_PROF_EDGE_BWD);
+#ifdef PVS_ABL_H_HOT      // timing only: every gather hits 8 hot rows (load_tile_idx)
+    PvsEdgeW w_hot = w;
+    w_hot.n_attr |= 0x100;
+#define w w_hot
+#endif
     const PvsSlabLayout L = pvs_slab_layout(kH);
     size_t lds = (size_t)kSharedBytes64 + (size_t)nw * kWaveBytes64;
     if (lds < (size_t)L.total * 4) lds = (size_t)L.total * 4;
@@ -698,6 +727,9 @@ int pvs_launch_edge_bwd_h64(hipStream_t s, const PvsGraph& g, const PvsEdgeW& w,
     else if (eatt) PVS_BWD_H64_LAUNCH(false, true);
     else PVS_BWD_H64_LAUNCH(false, false);
 #undef PVS_BWD_H64_LAUNCH
+#ifdef PVS_ABL_H_HOT
+#undef w
+#endif
     PVS_CHECK_LAUNCH();
     return 0;
 }
