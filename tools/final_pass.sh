@@ -18,7 +18,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg5 -- python
 find $out -name '*kernel_trace.csv' -delete
 tools/measure_traffic.sh ${tag}_cfg2 > $out/traffic_cfg2.log 2>&1
 tools/measure_traffic.sh ${tag}_cfg5 --config cfg5 --steps 5 --graph 0 > $out/traffic_cfg5.log 2>&1
+tools/measure_traffic.sh ${tag}_cfg3 --config cfg3 > $out/traffic_cfg3.log 2>&1
 tools/pmc_sq.sh ${tag} > $out/pmc_sq.log 2>&1
 python3 tools/pmc_summary.py gpurun_out/pmc_${tag} k_edge_bwd k_edge_fwd k_node_gather > $out/pmc_sq_summary.txt 2>&1
-find gpurun_out/pmc_${tag} gpurun_out/traffic_${tag}_cfg2 gpurun_out/traffic_${tag}_cfg5 -name '*.csv' -size +1M -delete
+tools/pmc_sq.sh ${tag}_cfg3 --config cfg3 > $out/pmc_sq_cfg3.log 2>&1
+python3 tools/pmc_summary.py gpurun_out/pmc_${tag}_cfg3 k_edge_bwd k_edge_fwd k_node_gather > $out/pmc_sq_cfg3_summary.txt 2>&1
+find gpurun_out/pmc_${tag} gpurun_out/pmc_${tag}_cfg3 gpurun_out/traffic_${tag}_cfg2 gpurun_out/traffic_${tag}_cfg5 gpurun_out/traffic_${tag}_cfg3 -name '*.csv' -size +1M -delete
 for f in $out/bench_*.json $out/prof_cfg*.json; do echo "$f: $(cut -c1-260 $f | grep -o '"value": [0-9.]*')"; done
