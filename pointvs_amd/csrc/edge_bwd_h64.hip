@@ -707,11 +707,6 @@ int pvs_launch_edge_bwd_h64(hipStream_t s, const PvsGraph& g, const PvsEdgeW& w,
     }
     *n_slabs = blocks;
     PvsProfScope prof(s, PVS_PROF_EDGE_BWD);
-#ifdef PVS_ABL_H_HOT      // timing only: every gather hits 8 hot rows (load_tile_idx)
-    PvsEdgeW w_hot = w;
-    w_hot.n_attr |= 0x100;
-#define w w_hot
-#endif
     const PvsSlabLayout L = pvs_slab_layout(kH);
     size_t lds = (size_t)kSharedBytes64 + (size_t)nw * kWaveBytes64;
     if (lds < (size_t)L.total * 4) lds = (size_t)L.total * 4;
@@ -727,9 +722,6 @@ int pvs_launch_edge_bwd_h64(hipStream_t s, const PvsGraph& g, const PvsEdgeW& w,
     else if (eatt) PVS_BWD_H64_LAUNCH(false, true);
     else PVS_BWD_H64_LAUNCH(false, false);
 #undef PVS_BWD_H64_LAUNCH
-#ifdef PVS_ABL_H_HOT
-#undef w
-#endif
     PVS_CHECK_LAUNCH();
     return 0;
 }
