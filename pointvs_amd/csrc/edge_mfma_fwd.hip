@@ -36,8 +36,9 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
     float* wc2t = bc1t + H;
     float* wat = wc2t + H;
     float* wrhot = wat + H;
-    float* attrt = wrhot + H;                            // [PVS_MAX_EDGE_ATTR][H]
-    float* wave_base = attrt + PVS_MAX_EDGE_ATTR * H;    // per wave: tile[32][TS], tx[32][4], rowbuf[32]
+    float* attrt = wrhot + H;                            // [max(n_attr, 1)][H]
+    const int attr_rows = w.n_attr > 1 ? w.n_attr : 1;
+    float* wave_base = attrt + attr_rows * H;            // per wave: tile[32][TS], tx[32][4], rowbuf[32]
     constexpr int kWaveFloats = kTile * TS + kTile * 4 + kTile;
 
     const bool upd = flags & PVS_UPDATE_COORDS;
@@ -61,7 +62,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
         wc2t[c] = upd ? w.wc2[c] : 0.f;
         wat[c] = eatt ? w.wa[c] : 0.f;
         wrhot[c] = w.w1[c * w.ld1 + w.off_rho];
-        for (int t = 0; t < PVS_MAX_EDGE_ATTR; ++t)
+        for (int t = 0; t < attr_rows; ++t)
             attrt[t * H + c] = t < w.n_attr ? w.w1[c * w.ld1 + w.off_rho + 1 + t] : 0.f;
     }
     __syncthreads();
@@ -301,12 +302,15 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     const char* bf64 = getenv("PVS_EGNN_BF16X3_H64");
     // default: fp32 products as bf16x3 (PVS_EGNN_BF16X3=0: fp32 MFMAs; PVS_EGNN_BF16X3_H64=0: only for H = 64)
     const bool bf16x3 = !(bf && bf[0] == '0') && (H == 32 || !(bf64 && bf64[0] == '0'));
-    // H = 64 bf16x3: 48 KB of weight operands, so one 512-thread workgroup per CU (8 waves)
-    const int nw = (HB == 2 && bf16x3) ? 8 : kWaves;
+    // H = 64 bf16x3: 48 KB of weight operands, so one workgroup per CU: 768 threads = three waves per SIMD
+    // (164-168 registers, no spills; forward kernel -5 % against two waves per SIMD) where the edge-class table
+    // leaves room in the 160 KB of LDS (up to 3 classes: 512 bytes to spare), 512 threads otherwise
+    const int attr_rows = w.n_attr > 1 ? w.n_attr : 1;
+    const int nw = (HB == 2 && bf16x3) ? (attr_rows <= 3 ? 12 : 8) : kWaves;
     int blocks, n_chunks;
-    pick_grid(g.n_edges, &blocks, &n_chunks, nw, nw == 8 ? 256 : 1024);
+    pick_grid(g.n_edges, &blocks, &n_chunks, nw, nw >= 8 ? 256 : 1024);
     const size_t words = (bf16x3 ? (size_t)2 * HB * HB * 6 * 64 * 4 : (size_t)2 * H * H) +
-                         (5 + PVS_MAX_EDGE_ATTR) * H +
+                         (5 + attr_rows) * H +
                          (size_t)nw * (kTile * (H + 4) + kTile * 4 + kTile);
     const size_t lds = words * sizeof(float);
     const bool soft = (flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT);
@@ -320,7 +324,8 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
         if (soft) PVS_FWD_LAUNCH(HBV, B3, NTV, true);  \
         else PVS_FWD_LAUNCH(HBV, B3, NTV, false);      \
     } while (0)
-    if (HB == 2 && bf16x3) PVS_FWD_PICK(2, true, 512);
+    if (HB == 2 && bf16x3 && nw == 12) PVS_FWD_PICK(2, true, 768);
+    else if (HB == 2 && bf16x3) PVS_FWD_PICK(2, true, 512);
     else if (HB == 1 && bf16x3) PVS_FWD_PICK(1, true, kThreads);
     else if (HB == 1) PVS_FWD_PICK(1, false, kThreads);
     else PVS_FWD_PICK(2, false, kThreads);
