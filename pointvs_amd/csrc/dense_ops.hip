@@ -580,7 +580,19 @@ int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx,
                       int swc, int swk, const float* b, const float* x2, int ldx2, const float* W2,
                       int swc2, int swk2, int N, int K, int K2, int C, bool accumulate, int epi,
                       const float* aux_in, int ld_in, float* aux_out, int ld_out) {
-    PVS_REQUIRE(C >= 1 && C <= kThreads, "linear: n_out %d unsupported (1..256)", C);
+    PVS_REQUIRE(C >= 1, "linear: n_out %d unsupported", C);
+    if (C > kThreads) {
+        // more output channels than one pass holds (one per thread): chunks of the output dimension (the input
+        // gradient of a layer whose input is wider than 256: edge_mlp.0 at hidden size 128 on the decomposed path)
+        PVS_REQUIRE(epi == 0 && !x2, "linear: n_out %d > %d needs the plain form", C, kThreads);
+        for (int c0 = 0; c0 < C; c0 += kThreads) {
+            const int rc = pvs_launch_linear(s, y + c0, ldy, x, ldx, W + (size_t)c0 * swc, swc, swk, b ? b + c0 : nullptr,
+                                             nullptr, 0, nullptr, 0, 0, N, K, 0, C - c0 < kThreads ? C - c0 : kThreads,
+                                             accumulate, 0, nullptr, 0, nullptr, 0);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     PVS_REQUIRE(epi == 0 || pvs_linear_epilogue_supported(ldy, ldx, x2 ? ldx2 : 0, K, K2, C, y, x, x2),
                 "linear: the epilogue needs the MFMA path");
     if (N <= 0) return 0;
@@ -642,7 +654,19 @@ int pvs_launch_reduce_slabs2(hipStream_t s, float* out_a, const float* slabs_a, 
 int pvs_launch_tsgemm_tn(hipStream_t s, float* out, int ldo, const float* A, int lda, const float* B,
                          int ldb, int N, int C, int K, float* slabs, bool accumulate) {
     const int CK = C * K;
-    PVS_REQUIRE(CK <= 32 * kThreads, "tsgemm: %d x %d outputs unsupported", C, K);
+    PVS_REQUIRE(C <= 32 * kThreads, "tsgemm: %d x %d outputs unsupported", C, K);
+    if (CK > 32 * kThreads) {
+        // wider than one pass holds (32 outputs per thread): column chunks of the right operand, each a
+        // product of its own (hidden sizes above 64 on the decomposed layer path; A is re-read per chunk)
+        const int kc = (32 * kThreads / C) & ~3;
+        PVS_REQUIRE(kc >= 4, "tsgemm: %d x %d outputs unsupported", C, K);
+        for (int k0 = 0; k0 < K; k0 += kc) {
+            const int rc = pvs_launch_tsgemm_tn(s, out + k0, ldo, A, lda, B + k0, ldb, N, C, K - k0 < kc ? K - k0 : kc,
+                                                slabs, accumulate);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     const int blocks = pvs_reduce_blocks(N);
     const int rpb = rows_per_block_for(N, blocks);
     if (C % 32 == 0 && K % 32 == 0 && C <= 64 && K <= 64) {

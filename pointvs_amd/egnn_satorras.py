@@ -214,8 +214,10 @@ class EGNNLayer(nn.Module):
         if skip_coords:
             desc = (desc[0], desc[1], desc[2] & ~_lib.UPDATE_COORDS, desc[3])
         if self.hidden_nf > max(self._KERNEL_WIDTHS):
-            raise NotImplementedError(f'hidden size {self.hidden_nf} > {max(self._KERNEL_WIDTHS)} is '
-                                      f'not built in libpvs_egnn.so')
+            # wider than the fused kernels are built for: the layer as the composition of its public
+            # sub-methods (dense products and segment reductions through the C ABI, per-edge glue as torch
+            # ops on the HIP tensors), in CSR-sorted edge order
+            return self._decomposed_call(pg, h, coord, m_prev_sorted, skip_coords)
         if self.hidden_nf not in self._KERNEL_WIDTHS:
             h_out, x_out, m_sorted, att, natt = self._padded_call(pg, h, coord, m_prev_sorted, need_m, desc[2])
         else:
@@ -233,6 +235,52 @@ class EGNNLayer(nn.Module):
         else:
             self._coords_src = (lambda: x_out.detach()) if self.use_coords else self._coords_src
         return h_out, x_out, m_sorted
+
+    _MAX_DECOMPOSED_WIDTH = 128       # pvs_linear_* stages the whole [C, K] weight in LDS: edge_mlp.0 is [k, 2k+1+A]
+
+    def _decomposed_call(self, pg, h, coord, m_prev_sorted, skip_coords):
+        """EGNNLayer.forward (egnn_satorras.py:189-206) for hidden sizes above the fused kernels' 64 channels:
+        coord2radial -> edge_model -> edge residual -> coord_model -> node_model on the prepared graph's sorted
+        edge list. Not fused (the [E, H] intermediates live in HBM and autograd keeps them), so it runs at a
+        fraction of the fused layers' rate; same values as the reference (oracle-checked at k = 96, 128)."""
+        if self.hidden_nf > self._MAX_DECOMPOSED_WIDTH:
+            raise NotImplementedError(f'hidden size {self.hidden_nf} > {self._MAX_DECOMPOSED_WIDTH} is not '
+                                      f'built in libpvs_egnn.so')
+        e = pg.n_edges
+        row, col = pg.t['row'][:e].long(), pg.t['col'][:e].long()
+        edge_index = torch.stack([row, col])
+        edge_attr = None
+        if self.edges_in_d:
+            edge_attr = torch.nn.functional.one_hot(pg.t['etype'][:e].long(), self.edges_in_d).to(h.dtype)
+        radial, coord_diff = self.coord2radial(edge_index, coord)
+        m = self.edge_model(h[row], h[col], radial, edge_attr)
+        if self.edge_residual and m_prev_sorted is not None:
+            if self.rezero:
+                m = m_prev_sorted + self.edge_gate_parameter * m
+            elif self.gated_residual:
+                gate = torch.relu(self.edge_gate_parameter)
+                m = gate * m + (1 - gate) * m_prev_sorted
+            else:
+                m = m + m_prev_sorted
+        self._att_src = self._natt_src = None
+        if skip_coords:
+            x_out = coord
+            self._coords_src = lambda h=h.detach(), coord=coord.detach(), mp=(
+                None if m_prev_sorted is None else m_prev_sorted.detach()): self._decomposed_coords(pg, h, coord, mp)
+        else:
+            x_out = self.coord_model(coord, edge_index, coord_diff, m)
+        h_out, _ = self.node_model(h, edge_index, m)
+        if self._att_src is not None:      # node_model recorded the gates in sorted order
+            att_sorted = self._att_src
+            self._att_src = lambda: PF.rows_to_input_order(att_sorted(), pg)
+        return h_out, x_out, m
+
+    def _decomposed_coords(self, pg, h, coord, mp):
+        with torch.no_grad():
+            att, natt = self._att_src, self._natt_src
+            x = self._decomposed_call(pg, h, coord, mp, skip_coords=False)[1]
+            self._att_src, self._natt_src = att, natt
+            return x
 
     def forward(self, h, edge_index, coord, edge_attr=None, edge_messages=None):
         """Same contract as the reference: returns (h, coord, edge_attr, edge_feat), edge_feat in
@@ -259,7 +307,13 @@ class EGNNLayer(nn.Module):
     def _mlp(seq, x):
         for mod in seq:
             if isinstance(mod, nn.Linear):
-                x = PF.linear(x, mod.weight, mod.bias)
+                if min(mod.in_features, mod.out_features) > 64 or mod.out_features > 64:
+                    # a plain GEMM wider than the MFMA linear kernels are built for (hidden sizes above 64):
+                    # the library GEMM (hipBLASLt through torch) instead of the generic one-row-per-lane kernel
+                    _lib.require_hip(x)
+                    x = torch.nn.functional.linear(x, mod.weight, mod.bias)
+                else:
+                    x = PF.linear(x, mod.weight, mod.bias)
             elif isinstance(mod, GraphNorm):      # no batch vector: one graph
                 _lib.require_hip(x)
                 out = x - x.mean(dim=0, keepdim=True) * mod.mean_scale

@@ -103,6 +103,32 @@ def test_ragged_graphs_match_oracle(name, flags):
             assert rel_err(gr, g_ref[pname].numpy()) < TOL, pname
 
 
+@pytest.mark.parametrize('k', [96, 128])
+@pytest.mark.parametrize('flags', ['default', 'att_res'])
+def test_wide_layers_run_decomposed_and_match_oracle(k, flags):
+    """Hidden sizes above the fused kernels' 64 channels (the reference accepts any --channels) run as the
+    composition of the layer's public sub-methods on the prepared graph (EGNNLayer._decomposed_call): same
+    logits and gradients as the oracle, attention values and coordinates still available."""
+    changes = dict(k=k, num_layers=2) if flags == 'default' else dict(
+        k=k, num_layers=2, edge_attention=True, node_attention=True, residual=True, normalize=True, tanh=True,
+        edge_residual=True, graphnorm=True)
+    model, kw = make_model(seed=3, **changes)
+    g = random_graph(300, 6000, seed=21, n_graphs=3)
+    y, grads = gpu_run(model, g)
+    y_ref, _, g_ref = oracle_run(model, kw, g, dtype=torch.float64)
+    assert rel_err(y, y_ref.numpy()) < TOL
+    for pname, gr in grads.items():
+        if gr is None:
+            assert g_ref[pname] is None, pname
+        else:
+            assert rel_err(gr, g_ref[pname].numpy()) < TOL, pname
+    if flags == 'att_res':
+        n_edges = int(g.edge_index.shape[1])
+        for layer in list(model.layers)[1:]:      # (the last one evaluates its dead coordinate update on demand)
+            assert layer.att_val.shape == (n_edges, 1) and layer.node_att_val.shape == (300, 1)
+            assert layer.intermediate_coords.shape == (300, 3)
+
+
 def test_star_graph_rows_longer_than_a_chunk():
     """One destination with 20,000 incoming edges (a row far longer than a wave's chunk) plus the
     reverse edges: exercises multi-tile rows, chunk alignment and the column gather."""
