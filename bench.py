@@ -341,6 +341,10 @@ def main():
                     help='let the model skip the last layer\'s coordinate update, whose result nothing reads '
                          '(the library default); the bench evaluates it by default, like the reference does')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--model-flags', default='',
+                    help='NOT a BASELINE configuration: extra model keywords on top of --config, e.g. '
+                         '"edge_residual=True,tanh=True" (profiles of kernel instantiations no BASELINE config uses); '
+                         'the workload string names them')
     ap.add_argument('--infer', action='store_true',
                     help='forward-only (torch.no_grad) throughput: the virtual-screening shape of '
                          'BASELINE config 5; not the headline metric')
@@ -395,6 +399,10 @@ def main():
     if args.config == 'cfg5':
         return screening_bench(args, rank, world, dev)
     cfg = CONFIGS[args.config]
+    if args.model_flags:
+        import ast
+        extra = {k.strip(): ast.literal_eval(v.strip()) for k, v in (kv.split('=', 1) for kv in args.model_flags.split(','))}
+        cfg = dict(cfg, model=dict(cfg['model'], **extra))
     lib = _lib.lib()
     pgraph.CACHE_ENABLED = False        # every step prepares its batch, as a fresh batch would
 
@@ -528,7 +536,8 @@ def main():
             dom_ms, dom_n = bwd_ms, bwd_n
             dom_bytes = algorithmic_bytes_edge_bwd(n_nodes, n_edges, h)
             dom_flops = (12.0 * h * h + 4 * h) * n_edges     # 2 recompute + 2 dgrad + 2 wgrad products
-            dom_symbol = (('k_edge_bwd_bf16' if os.environ.get('PVS_BWD32') != '0' else 'k_edge_bwd_mfma') if h == 32
+            dom_symbol = (('k_edge_bwd_bf16' if os.environ.get('PVS_BWD32') != '0' and not cfg['model'].get('edge_residual')
+                           else 'k_edge_bwd_mfma') if h == 32
                           else ('k_edge_bwd_h64' if os.environ.get('PVS_BWD64') != '0' else 'k_edge_bwd_team_parts'))
             dom_name = (f'{dom_symbol} (H={h} edge backward, one launch per layer)')
             step_bytes = layers * algorithmic_bytes_per_layer(n_nodes, n_edges, h)
@@ -554,7 +563,9 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 3),
             'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{args.config}: {layers}-layer EGNN, channels={h}, '
+            'config': {'workload': (f'NOT A BASELINE CONFIGURATION ({args.config} + --model-flags {args.model_flags}): '
+                                    if args.model_flags else '') +
+                                   f'{args.config}: {layers}-layer EGNN, channels={h}, '
                                    f'edge_radius={cfg["graph"]["edge_radius"]}A, '
                                    f'{args.batch} graphs/GPU x {cfg["graph"]["n_nodes"]} atoms, '
                                    f'N={n_nodes} nodes E={n_edges} edges per rank, '

@@ -1629,12 +1629,15 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     const bool bf16x3 = !(bf && bf[0] == '0') && H == 32;
     {   // defaults: the all-bf16 one-wave-per-tile kernels of edge_bwd_bf16.hip.
         // PVS_BWD32=0: H = 32 with fp32 weight-gradient MFMAs (k_edge_bwd_mfma).
-        // (H = 32 with edge residual needs ~100 more registers than two waves per SIMD have: round-1 kernel)
+        // (H = 32 with edge residual AND edge attention needs ~100 more registers than two waves per SIMD have -
+        //  137 spilled - and runs no faster than the round-1 kernel, which keeps that combination; edge residual
+        //  alone spills 29 and is 24 % faster per launch than the round-1 kernel: profiles/r02_variants_edge_residual.txt)
         const char* b32 = getenv("PVS_BWD32");
         const char* b64 = getenv("PVS_BWD64");
         const bool eres_on = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
         const bool all_bf16 = !(bf && bf[0] == '0');
-        if (H == 32 && all_bf16 && !eres_on && !(b32 && b32[0] == '0'))
+        const bool eres_att = eres_on && (flags & PVS_EDGE_ATTENTION);
+        if (H == 32 && all_bf16 && !eres_att && !(b32 && b32[0] == '0'))
             return pvs_launch_edge_bwd_bf16(s, H, g, w, flags, att_act, io, e_lo, e_hi, n_slabs);
         // H = 64: one wave per 16-edge tile (edge_bwd_h64.hip); PVS_BWD64=0: the round-1 team kernel below
         if (H == 64 && all_bf16 && !(b64 && b64[0] == '0'))
