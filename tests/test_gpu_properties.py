@@ -635,11 +635,13 @@ def test_backward_on_a_forward_only_graph_fails_loudly():
 
 @pytest.mark.parametrize('changes', [dict(), dict(edge_attention=True, node_attention=True, residual=True),
                                      dict(k=64, edge_attention=True), dict(edge_residual=True, tanh=True),
-                                     dict(k=64, edge_residual=True, edge_attention=True, tanh=True)])
+                                     dict(k=64, edge_residual=True, edge_attention=True, tanh=True),
+                                     dict(edge_residual=True, edge_attention=True)])
 def test_bitwise_reproducible_at_baseline_size(changes):
     """No atomics and no unordered LDS hand-offs anywhere: four runs of the same cfg2-shaped batch give
-    identical bits in the outputs and in every gradient (every kernel family: H = 32 all-bf16 backward,
-    H = 32 with edge residual, the H = 64 one-wave-per-16-edge-tile backward with and without edge residual). A race in a kernel shows up here as run-to-run
+    identical bits in the outputs and in every gradient (every kernel family: H = 32 all-bf16 backward with and
+    without edge residual, the round-1 H = 32 kernel that keeps edge residual + edge attention, the H = 64
+    one-wave-per-16-edge-tile backward with and without edge residual). A race in a kernel shows up here as run-to-run
     differences long before it breaks a tolerance."""
     from pointvs_amd.synthetic import CONFIGS, synthetic_batch
     cfg = CONFIGS['cfg2']
