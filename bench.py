@@ -457,7 +457,7 @@ def main():
         y_pred = model(batch).reshape(-1)
         if prefetch:   # the next batch's CSR/CSC build (here: the same tensors) runs on a side
             # stream under this batch's backward, as a data loader's look-ahead would arrange it
-            pgraph.prefetch_graph(batch.edge_index, batch.edge_attr, n_nodes)
+            pgraph.prefetch_graph(batch.edge_index, batch.edge_attr, n_nodes, layout=pgraph.runs_layout(batch))
         loss = model.get_loss(y_true, y_pred)
         model.optimiser.zero_grad()
         loss.backward()

@@ -211,7 +211,7 @@ def _graph_key(edge_index, edge_attr, n_nodes):
             None if edge_attr is None else (edge_attr.data_ptr(), edge_attr._version), n_nodes)
 
 
-def prefetch_graph(edge_index, edge_attr, n_nodes):
+def prefetch_graph(edge_index, edge_attr, n_nodes, layout=None):
     """Start `prepare_graph` for an upcoming batch on a side stream (e.g. while the current batch
     is in its backward pass: the sorts are memory/latency-bound, the edge kernels ALU-bound). The
     next `prepared_for` call with the same tensors picks the result up and orders the consumer
@@ -222,7 +222,7 @@ def prefetch_graph(edge_index, edge_attr, n_nodes):
         side = _PREFETCH_STREAM[dev] = torch.cuda.Stream(dev)
     side.wait_stream(torch.cuda.current_stream(dev))   # inputs may have been produced just now
     with torch.cuda.stream(side):
-        pg = prepare_graph(edge_index, edge_attr, n_nodes, need_backward=True)
+        pg = prepare_graph(edge_index, edge_attr, n_nodes, need_backward=True, layout=layout)
         done = torch.cuda.Event()
         done.record(side)
     _PREFETCH[dev] = (_graph_key(edge_index, edge_attr, n_nodes), pg, done, edge_index, edge_attr)
@@ -237,7 +237,8 @@ def _take_prefetched(edge_index, edge_attr, n_nodes):
     _, pg, done, _, _ = hit
     torch.cuda.current_stream(edge_index.device).wait_event(done)
     for t in pg.t.values():    # the side stream allocated these: tell the allocator who uses them now
-        t.record_stream(torch.cuda.current_stream(edge_index.device))
+        if torch.is_tensor(t):
+            t.record_stream(torch.cuda.current_stream(edge_index.device))
     return pg
 
 
