@@ -691,6 +691,36 @@ def test_public_submethods_compose_to_the_fused_layer(flags):
         assert rel_err(a, b) < 2e-5, name
 
 
+def test_prefetched_graph_is_picked_up_by_the_next_forward():
+    """graph.prefetch_graph (the next batch's CSR/CSC build on a side stream, a data loader's look-ahead) hands
+    the same arrays to the next prepared_for call with those tensors - for plain and for generate_edges-tagged
+    batches - and the model's numbers do not change."""
+    from pointvs_amd import graph as pgraph
+    from pointvs_amd.graph import Batch
+    from pointvs_amd.synthetic import synthetic_graph
+    items = [synthetic_graph(900 + k, n_nodes=n, n_lig=10, edge_radius=6.0) for k, n in enumerate((200, 350))]
+    batch = Batch.from_data_list(items).to('cuda')
+    n = int(batch.x.shape[0])
+    model, _ = make_model(seed=4, num_layers=2)
+    y_plain, g_plain = gpu_run(model, batch)
+    was = pgraph.CACHE_ENABLED
+    pgraph.CACHE_ENABLED = False
+    try:
+        for layout in (None, pgraph.runs_layout(batch)):
+            ref = pgraph.prepare_graph(batch.edge_index, batch.edge_attr, n, need_backward=True, layout=layout)
+            pgraph.prefetch_graph(batch.edge_index, batch.edge_attr, n, layout=layout)
+            got = pgraph.prepared_for(batch.edge_index, batch.edge_attr, n, layout=layout)
+            torch.cuda.synchronize()
+            for name in ('rowptr', 'row', 'col', 'etype', 'perm', 'colptr', 'cedge', 'inv_deg'):
+                assert torch.equal(ref.t[name], got.t[name]), name
+        pgraph.prefetch_graph(batch.edge_index, batch.edge_attr, n, layout=pgraph.runs_layout(batch))
+        model.zero_grad()
+        y = model(batch).reshape(-1)
+        assert y.detach().cpu().numpy().tobytes() == y_plain.tobytes()
+    finally:
+        pgraph.CACHE_ENABLED = was
+
+
 def test_prepare_by_merging_sorted_runs_equals_the_sort():
     """pvs_graph_prepare_runs (batches tagged edge_layout == 'generate_edges': two row-sorted runs per graph,
     merged by counting) gives array for array what the radix-sort path gives - on ragged batches, with and
