@@ -191,6 +191,11 @@ __global__ void k_extract_runs(const int64_t* __restrict__ ei, const int64_t* __
     int bad = 0;
     if (r < 0 || r >= N || c < 0 || c >= N) { bad |= 1; r = 0; c = 0; }
     if (r < node_ptr[g] || r >= node_ptr[g + 1] || c < node_ptr[g] || c >= node_ptr[g + 1]) bad |= 4;
+    // the tables themselves: they must cover exactly [0, E) and [0, N) (an edge list edited after collation with
+    // stale per-graph counts would otherwise be placed outside its rows' slots); monotone segments follow from
+    // the per-edge range checks above, because every edge is tested against the segment the walk assigns it
+    if (e < edge_ptr[g] || e >= edge_ptr[g + 1]) bad |= 4;
+    if (e == 0 && (edge_ptr[0] != 0 || edge_ptr[n_graphs] != E || node_ptr[0] != 0 || node_ptr[n_graphs] != N)) bad |= 4;
     if (e > edge_ptr[g] && ei[e - 1] > r) {          // a descent inside the graph: the second run starts here
         const int old = atomicMin(&split[g], e);
         if (old != edge_ptr[g + 1]) bad |= 4;          // more than one descent: not two sorted runs

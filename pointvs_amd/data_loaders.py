@@ -32,10 +32,12 @@ class RankWeightedSampler:
     All ranks draw the same `num_samples` indices (torch.multinomial on a CPU generator seeded with
     seed + epoch) and rank r keeps positions r, r + world, ...; `len()` is the same on every rank
     (the draw is padded by wrapping to a multiple of world), so ranks run the same number of steps -
-    a requirement of the gradient all-reduce. weights=None: a seeded permutation (uniform, without
-    replacement) instead."""
+    a requirement of the gradient all-reduce. weights=None (regression sets, single-class sets): the
+    reference then builds its DataLoader with sampler=None and shuffle=False (data_loaders.py:176-178,
+    512-520), i.e. iterates in index order every epoch; so does this: the identity sequence, strided
+    over the ranks. shuffle=True draws a seeded permutation instead (not a reference behaviour)."""
 
-    def __init__(self, weights, num_samples=None, rank=0, world=1, seed=0):
+    def __init__(self, weights, num_samples=None, rank=0, world=1, seed=0, shuffle=False):
         self.weights = None if weights is None else torch.as_tensor(weights, dtype=torch.double)
         if num_samples is None:
             if weights is None:
@@ -43,6 +45,7 @@ class RankWeightedSampler:
             num_samples = len(self.weights)
         self.num_samples, self.rank, self.world, self.seed = int(num_samples), int(rank), int(world), int(seed)
         self.epoch = 0
+        self.shuffle = bool(shuffle)
 
     def set_epoch(self, epoch):
         self.epoch = int(epoch)
@@ -50,6 +53,8 @@ class RankWeightedSampler:
     def global_draw(self):
         gen = torch.Generator().manual_seed(self.seed + self.epoch)
         if self.weights is None:
+            if not self.shuffle:
+                return torch.arange(self.num_samples)
             return torch.randperm(self.num_samples, generator=gen)
         return torch.multinomial(self.weights, self.num_samples, True, generator=gen)
 

@@ -121,6 +121,13 @@ class GradAllReducer:
             raise RuntimeError('the set of parameters with gradients changed between steps (on at '
                                'least one rank; every rank raises this together)')
 
+    def reset(self):
+        """Forget the agreed layout: the next call learns (and cross-checks) it again. For a change of
+        the set of parameters that receive gradients which every rank makes at the same step, e.g.
+        MultitaskSatorrasEGNN switching from its pose head to its affinity head."""
+        self.check()
+        self._live = self._bucket = None
+
     def __call__(self, weight=1.0):
         if not _active(self.group):
             return
@@ -223,6 +230,19 @@ class OverlappedGradAllReducer:
     def check(self):
         """Drains the pending (one call late) mismatch check."""
         self._flat_fallback.check()
+
+    def reset(self):
+        """Forget the bucket plan (see GradAllReducer.reset): the next step runs the flat exchange again,
+        learns which parameters receive gradients now and re-plans the buckets. Call it on every rank at
+        the same step (PointNeuralNetworkBase.set_task does when the task changes); an exchange must
+        not be in flight."""
+        for b in self._buckets or ():
+            if b.handle is not None:
+                b.handle.wait()
+                b.handle = None
+            b.ready = 0
+        self._flat_fallback.reset()
+        self._buckets, self._bucket_of = None, {}
 
 
 def shard_range(n_items, rank, world):

@@ -130,16 +130,32 @@ def runs_layout(graph, device=None):
     None. Cached on the batch object (one small host-to-device copy per batch)."""
     if getattr(graph, 'edge_layout', None) != 'generate_edges' or os.environ.get('PVS_PREPARE_RUNS') == '0':
         return None
+    n_edges = int(graph.edge_index.size(1))
     cached = getattr(graph, '_runs_layout', None)
-    if cached is not None and (device is None or cached[0].device == torch.device(device)):
-        return cached
+    if (cached is not None and cached[2] == (n_edges, graph.edge_index.data_ptr())
+            and (device is None or cached[0].device == torch.device(device))):
+        return cached[:2]
     counts, ptr = getattr(graph, 'graph_edge_counts', None), getattr(graph, 'ptr', None)
     if counts is None or ptr is None:
         return None
+    # The device pass verifies the edge list AGAINST these two tables; the tables themselves are host data
+    # and are checked here (free): an edge list filtered or extended after collation no longer matches its
+    # stale per-graph counts, and the placement would then write outside the rows' slots. Such a batch
+    # takes the general sort path.
+    nodes = getattr(graph, 'graph_node_counts', None)
+    if nodes is None:
+        if ptr.is_cuda:          # only a device copy of the node table: not verifiable without a sync
+            return None
+        nodes = (ptr[1:] - ptr[:-1]).tolist()
+    n_nodes = int(graph.x.size(0)) if torch.is_tensor(getattr(graph, 'x', None)) else sum(nodes)
+    if (not counts or len(nodes) != len(counts) or sum(counts) != n_edges or min(counts) < 0
+            or sum(nodes) != n_nodes or min(nodes) < 0):
+        return None
     dev = graph.edge_index.device if device is None else device
     edge_ptr = torch.tensor([0] + list(counts), dtype=torch.int64).cumsum(0).to(dtype=torch.int32)
-    layout = (ptr.to(device=dev, dtype=torch.int32).contiguous(), edge_ptr.to(dev, non_blocking=True))
-    graph._runs_layout = layout
+    node_ptr = torch.tensor([0] + list(nodes), dtype=torch.int64).cumsum(0).to(dtype=torch.int32)
+    layout = (node_ptr.to(dev, non_blocking=True), edge_ptr.to(dev, non_blocking=True))
+    graph._runs_layout = layout + ((n_edges, graph.edge_index.data_ptr()),)
     return layout
 
 
@@ -182,7 +198,7 @@ def prepare_graph(edge_index, edge_attr, n_nodes, need_backward=None, layout=Non
     outputs = (_lib.ptr(t['rowptr']), _lib.ptr(t['row']), _lib.ptr(t['col']), _lib.ptr(t.get('etype')),
                _lib.ptr(t['perm']), _lib.ptr(t.get('colptr')), _lib.ptr(t.get('cedge')), _lib.ptr(t['inv_deg']),
                _lib.ptr(t['status']))
-    if layout is not None and n_edges > 0:
+    if layout is not None and n_edges > 0 and int(layout[0].numel()) == int(layout[1].numel()) >= 2:
         node_ptr, edge_ptr = layout
         n_graphs = int(node_ptr.numel()) - 1
         ws_bytes = lib.pvs_graph_prepare_runs_workspace_bytes(n_nodes, n_edges, n_graphs)

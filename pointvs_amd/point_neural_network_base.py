@@ -25,6 +25,14 @@ from .global_objects import DEVICE
 from .optim import FusedClipAdam
 
 
+def _rank_world():
+    """(rank, world) of the default process group; (0, 1) for a single process."""
+    dist = torch.distributed
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 class PointNeuralNetworkBase(nn.Module):
     """Base (abstract) class of the point-cloud networks."""
 
@@ -177,23 +185,36 @@ class PointNeuralNetworkBase(nn.Module):
         batches, as the reference's write_predictions does (pointvs_amd/predictions.py).
         Returns True like the reference (top-1 / Pearson model selection is analysis code outside
         the path)."""
-        from .predictions import PredictionsWriter
+        from .predictions import PredictionsWriter, merge_rank_files, rank_part
         predictions_file = Path(predictions_file or self.predictions_file)
         predictions_file = (predictions_file.parent /
                             f'{self.model_task_for_fnames}_{predictions_file.name}').expanduser()
+        rank, world = _rank_world()
+        # one process per GPU: every rank scores its own contiguous share of the set (point_vs.py
+        # make_loader) into its OWN part file; rank 0 joins the parts in rank order after a barrier
+        part = predictions_file if world == 1 else rank_part(predictions_file, rank)
         self.eval()
         self.val_iter = 0
-        with PredictionsWriter(predictions_file, self.model_task, flush_every=self.log_interval) as writer:
+        with PredictionsWriter(part, self.model_task, flush_every=self.log_interval) as writer:
             for self.batch, graph in enumerate(data_loader):
                 self.val_iter += 1
                 y_pred, y_true, ligands, receptors = self.unpack_input_data_and_predict(graph)
                 if self.model_task == 'classification':
                     y_pred = torch.sigmoid(y_pred)
                 writer.submit(y_pred, y_true, receptors, ligands)
+        if world > 1:
+            torch.distributed.barrier()         # every part is complete and closed
+            if rank == 0:
+                merge_rank_files(predictions_file, world)
+            torch.distributed.barrier()         # nobody reads the file before it is whole
         self.last_predictions_file = predictions_file
         return True
 
     def save(self, save_path=None):
+        """Checkpoint in the reference's format (:501-517). Data parallel: weights and optimiser state
+        are identical on every rank, so rank 0 alone writes (ranks writing one path at once corrupt it)."""
+        if _rank_world()[0] != 0:
+            return
         epoch = self.a_epoch if 'regression' in self.model_task else self.p_epoch
         if save_path is None:
             save_path = (self.save_path / 'checkpoints' /
@@ -259,7 +280,13 @@ class PointNeuralNetworkBase(nn.Module):
         if task not in ('classification', 'regression', 'multi_regression'):
             raise ValueError('Argument for set_task must be one of classification, regression or '
                              'multi_regression')
+        changed = getattr(self, 'model_task', task) != task
         self.model_task = task
+        sync = getattr(self, 'grad_sync', None)
+        if changed and hasattr(sync, 'reset'):
+            # another head receives gradients from now on (MultitaskSatorrasEGNN: pose / affinity): the
+            # exchange must learn its bucket layout again, identically on every rank
+            sync.reset()
         if 'regression' in task:
             self.model_task_for_fnames = 'affinity'
             self.model_task_string = 'Mean squared error'

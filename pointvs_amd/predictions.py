@@ -48,6 +48,27 @@ def format_lines(task, y_pred, y_true, receptors, ligands):
             for i in range(n)]
 
 
+def rank_part(path, rank):
+    """Part file of one rank of a data-parallel validation run (joined by merge_rank_files)."""
+    path = Path(path)
+    return path.with_name(f'{path.name}.rank{rank}')
+
+
+def merge_rank_files(path, world):
+    """Joins the ranks' part files in rank order into `path` (ranks hold contiguous shares of the set, so
+    this is the order one process would have written) and removes them. Called by rank 0 between two
+    barriers; a rank with an empty share has written no part."""
+    path = Path(path)
+    tmp = path.with_name(path.name + '.joining')
+    with open(tmp, 'wb') as out:
+        for r in range(world):
+            part = rank_part(path, r)
+            if part.is_file():
+                out.write(part.read_bytes())
+                part.unlink()
+    tmp.replace(path)
+
+
 class PredictionsWriter:
     """with PredictionsWriter(path, task) as w:  w.submit(y_pred_device, y_true, receptors, ligands)"""
 

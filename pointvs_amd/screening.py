@@ -246,7 +246,14 @@ class ReceptorScreen:
         torch.cuda.current_stream(dev).wait_stream(stream)
         return self
 
+    def stale(self):
+        """True when the weights the cached receptor-receptor sums came from have changed since
+        (load_weights(), an optimiser step): a captured step has those sums baked in."""
+        return self.reuse and self._fingerprint != self._weights_fingerprint()
+
     def replay(self, lig_poses):
+        if self.stale():           # host-only comparison of version counters
+            raise RuntimeError('ReceptorScreen: the model\'s weights changed after capture(); build a new screen')
         self.check()
         self._static_in.copy_(lig_poses)
         self._graph.replay()
@@ -309,6 +316,10 @@ class ScreeningSweep:
 
     def _bucket(self, n_lig, lig_feats, example_poses):
         screen = self.buckets.get(n_lig)
+        if screen is not None and screen.stale():
+            # the model was trained on or reloaded since this bucket was captured: its cached receptor
+            # sums (baked into the captured step) are out of date - build and capture it again
+            screen = None
         if screen is None:
             feats = torch.cat([lig_feats.to(self.rec_feats.device), self.rec_feats], 0)
             screen = ReceptorScreen(self.model, self.rec_pos, feats, n_lig, self.b, self.edge_radius, self.intra_radius)

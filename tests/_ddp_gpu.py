@@ -41,7 +41,7 @@ def rank_main(rank, world, port, out_dir):
         names = [n for n, _ in model.named_parameters()]
         reducer = OverlappedGradAllReducer(params)
         model.grad_sync = None
-        sampler = RankWeightedSampler(None, N_GRAPHS, rank, world, seed=SEED)
+        sampler = RankWeightedSampler(None, N_GRAPHS, rank, world, seed=SEED, shuffle=True)
         loader = GraphLoader(dataset(), batch_size=PER_RANK, sampler=sampler, device='cuda')
         rec = {}
         step = 0

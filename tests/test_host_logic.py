@@ -350,3 +350,119 @@ def test_rank_sampler_shards_one_seeded_draw():
     data = [synthetic_graph(s, n_nodes=40, n_lig=4, edge_radius=5.0) for s in range(13)]
     batches = list(GraphLoader(data, batch_size=2, sampler=ranks[0]))
     assert [b.num_graphs for b in batches] == [2, 2, 1] and len(GraphLoader(data, 2, ranks[0])) == 3
+
+
+class _TwoHeadToy:
+    """Built lazily (needs the package on sys.path inside the spawned ranks): a two-headed model on the
+    REAL harness (PointNeuralNetworkBase.train_model / val / save / set_task) with CPU tensors."""
+
+    @staticmethod
+    def make(save_path, silent):
+        from torch import nn
+        from pointvs_amd.point_neural_network_base import PointNeuralNetworkBase
+
+        class Toy(PointNeuralNetworkBase):
+            def build_net(self, **kw):
+                self.head_pose = nn.Linear(4, 1)
+                self.head_affinity = nn.Linear(4, 1)
+                return nn.Sequential(nn.Linear(3, 4), nn.SiLU())
+
+            def unpack_input_data_and_predict(self, item):
+                x, y, names = item
+                body = self.layers(x)
+                head = self.head_pose if self.model_task == 'classification' else self.head_affinity
+                return head(body).reshape(-1), y, names, ['rec'] * len(names)
+
+        torch.manual_seed(0)
+        return Toy(save_path, 1e-2, 1e-4, silent=silent, model_task='classification')
+
+
+def _harness_worker(rank, world, port, tmp, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, str(ROOT))
+        from pointvs_amd.distributed import OverlappedGradAllReducer, shard_range
+        model = _TwoHeadToy.make(Path(tmp) / 'run', silent=rank != 0)
+        model.grad_sync = OverlappedGradAllReducer(list(model.parameters()))
+        model.log_interval = 2
+        gen = torch.Generator().manual_seed(7)
+        xs, ys = torch.randn(22, 3, generator=gen), (torch.arange(22) % 2).float()
+        names = [f'lig{i:02d}' for i in range(22)]
+
+        def loader(lo, hi, step=3):
+            return [(xs[k:min(k + step, hi)], ys[k:min(k + step, hi)], names[k:min(k + step, hi)])
+                    for k in range(lo, hi, step)]
+        lo, hi = shard_range(22, rank, world)
+        train = loader(rank * 6, rank * 6 + 6)          # three steps of two... equal step count on both ranks
+        model.set_task('classification')
+        model.train_model(train, epochs=2, epoch_end_validation_set=loader(lo, hi))
+        model.val(loader(lo, hi))
+        model.set_task('regression')                      # the other head: the exchange must re-plan
+        model.train_model(train, epochs=1, epoch_end_validation_set=loader(lo, hi))
+        model.val(loader(lo, hi))
+        model.grad_sync.check()
+        out[rank] = {n: p.detach().clone() for n, p in model.named_parameters()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_harness_writes_whole_files_and_switches_heads_gloo_world2(tmp_path):
+    """ADVICE r2 (high + medium): under data parallelism every rank validates its own share - the
+    predictions file must come out complete and in data-set order (per-rank parts joined by rank 0),
+    checkpoints are written by rank 0 only, and `--model_task both` (pose head, then affinity head)
+    must not trip the gradient exchange when the set of parameters with gradients changes."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_harness_worker, args=(2, port, str(tmp_path), out), nprocs=2, join=True)
+    for n in out[0]:                                         # replicas stayed in lockstep through both phases
+        assert torch.equal(out[0][n], out[1][n]), n
+    run = tmp_path / 'run'
+    files = sorted(p.name for p in run.iterdir() if p.suffix == '.txt')
+    assert files == ['affinity_predictions.txt', 'affinity_predictions_epoch_1.txt', 'pose_predictions.txt',
+                     'pose_predictions_epoch_1.txt', 'pose_predictions_epoch_2.txt'], files
+    assert not list(run.glob('*.rank*')) and not list(run.glob('*.joining'))
+    for f in files:
+        lines = (run / f).read_text().splitlines()
+        assert [ln.split()[-1] for ln in lines] == [f'lig{i:02d}' for i in range(22)], f
+    ckpts = sorted(p.name for p in (run / 'checkpoints').iterdir())
+    assert ckpts == ['affinity_ckpt_epoch_1.pt', 'pose_ckpt_epoch_1.pt', 'pose_ckpt_epoch_2.pt']
+    for c in ckpts:
+        torch.load(run / 'checkpoints' / c, map_location='cpu', weights_only=False)     # whole, readable
+
+
+def test_rank_sampler_without_weights_iterates_in_index_order():
+    """weights=None is the reference's sampler=None, shuffle=False (data_loaders.py:176-178,
+    512-520): index order every epoch, strided over ranks, padded by wrapping."""
+    from pointvs_amd.data_loaders import RankWeightedSampler
+    ranks = [RankWeightedSampler(None, 7, r, 2, seed=3) for r in range(2)]
+    for epoch in (0, 1):
+        for s in ranks:
+            s.set_epoch(epoch)
+        assert list(ranks[0]) == [0, 2, 4, 6] and list(ranks[1]) == [1, 3, 5, 0]
+    assert list(RankWeightedSampler(None, 5)) == [0, 1, 2, 3, 4]
+    shuffled = RankWeightedSampler(None, 50, seed=3, shuffle=True)
+    assert sorted(shuffled) == list(range(50)) and list(shuffled) != list(range(50))
+
+
+def test_runs_layout_refuses_tables_that_do_not_match_the_edge_list():
+    """ADVICE r2 (medium): an edge list edited after collation no longer matches its per-graph counts;
+    the merge-of-runs preparation trusts those tables, so such a batch must take the sort path."""
+    from pointvs_amd.graph import Batch, runs_layout
+    from pointvs_amd.synthetic import synthetic_graph
+    items = [synthetic_graph(s, n_nodes=40, n_lig=4, edge_radius=5.0) for s in range(3)]
+    batch = Batch.from_data_list(items)
+    node_ptr, edge_ptr = runs_layout(batch)
+    assert node_ptr.tolist() == [0, 40, 80, 120] and int(edge_ptr[-1]) == batch.edge_index.size(1)
+    keep = torch.ones(batch.edge_index.size(1), dtype=torch.bool)
+    keep[5] = False
+    batch.edge_index = batch.edge_index[:, keep]            # filtered after collation: counts are stale
+    batch.edge_attr = batch.edge_attr[keep]
+    assert runs_layout(batch) is None
+    batch2 = Batch.from_data_list(items)
+    batch2.x = batch2.x[:-1]                                 # node table no longer covers the nodes
+    assert runs_layout(batch2) is None
