@@ -31,11 +31,41 @@ import faulthandler  # noqa: E402
 import numpy as np  # noqa: E402
 
 faulthandler.enable()
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+# torch is imported by main() AFTER the self-launch decision: the launcher parent of a multi-rank run never
+# maps libamdhip64 / libtorch_hip, let alone initialises HIP (a process that has must not start ranks)
+torch = None
+dist = None
+
+
+def _import_torch():
+    global torch, dist
+    import torch as _torch
+    import torch.distributed as _dist
+    torch, dist = _torch, _dist
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3   # fp32 vector = fp32 MFMA peak
+
+
+# what "dtype": "f32" means on this path: inputs, outputs, every accumulation and all
+# elementwise work are fp32; the per-edge matrix products run on the bf16 matrix pipe with each fp32 operand
+# split exactly into three bf16 parts and six partial products accumulated in fp32 (error O(2^-25 |a||b|),
+# below fp32 rounding; parity at 1e-5 relative against the fp64 oracle at BASELINE size is part of the GPU suite)
+ARITHMETIC = ('fp32 I/O, accumulation and elementwise work; per-edge matrix products as 6-term bf16x3 splits of '
+              'the fp32 operands on the bf16 matrix pipe with fp32 accumulation (no fp32 MFMA, no reduced-precision '
+              'storage); node-level products likewise')
+
+
+def scaling_note(args, world, strong):
+    """How this line relates to BASELINE config 4 (batch 256 over 8 GPUs)."""
+    if world == 1:
+        return None
+    if strong:
+        return (f'strong scaling: global batch {args.global_batch} fixed, {args.batch} graphs per GPU at '
+                f'{world} GPUs (BASELINE config 4 = --global-batch 256)')
+    return (f'weak scaling: {args.batch} graphs per GPU, global batch {world * args.batch}; the strong-scaling '
+            f'form of BASELINE config 4 is `--global-batch 256` ({256 // world} graphs per GPU at {world} GPUs), '
+            f'and at 8 GPUs the two coincide (8 x 32 = 256)')
 
 
 def algorithmic_bytes_per_layer(n, e, h):
@@ -98,18 +128,42 @@ def measured_traffic(config, kernel):
     return None, None
 
 
+def visible_gpu_count(topology='/sys/class/kfd/kfd/topology/nodes'):
+    """GPUs this process's children would see, WITHOUT loading or initialising the HIP runtime: the KFD
+    topology lists one node per agent, GPUs are the nodes with SIMDs; HIP_/ROCR_/CUDA_VISIBLE_DEVICES
+    narrow that list. None when the topology is not readable (no driver in this container)."""
+    nodes = sorted(Path(topology).glob('*/properties'),
+                   key=lambda p: int(p.parent.name))
+    if not nodes:
+        return None
+    count = 0
+    for props in nodes:
+        try:
+            fields = dict(line.split()[:2] for line in props.read_text().splitlines() if len(line.split()) >= 2)
+        except OSError:
+            continue
+        count += int(fields.get('simd_count', '0')) > 0
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        listed = os.environ.get(var)
+        if listed is not None:
+            count = min(count, len([x for x in listed.split(',') if x.strip()]))
+    return count
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) without a launcher: start N fresh ranks of this script under
-    torch.distributed.run and exit with their status. Runs BEFORE anything touches the GPU (a process
-    that has initialised HIP must never be replaced or forked into ranks)."""
+    torch.distributed.run and exit with their status. Runs BEFORE torch is imported: the parent neither
+    maps nor initialises HIP (a process that has initialised it must never be replaced or forked into
+    ranks), and it counts the GPUs from the KFD topology in sysfs."""
     import socket
     import subprocess
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
     env = dict(os.environ)
-    if torch.cuda.device_count() < args.gpus and 'PVS_BENCH_BACKEND' not in env:
-        raise SystemExit(f'--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible; set '
+    n_visible = visible_gpu_count()
+    if n_visible is not None and n_visible < args.gpus and 'PVS_BENCH_BACKEND' not in env:
+        raise SystemExit(f'--gpus {args.gpus} but only {n_visible} GPU(s) visible; set '
                          f'PVS_BENCH_BACKEND=gloo for a dry run of the multi-rank path with ranks sharing devices')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
            '--master-addr', '127.0.0.1', '--master-port', str(port), str(Path(__file__).resolve())] + sys.argv[1:]
@@ -245,16 +299,16 @@ def screening_bench(args, rank, world, dev):
     pred_file = out_dir / f'screen_predictions_rank{rank}.txt'
 
     sweep.run([('warm', lig_feats, warm)])           # builds the bucket, captures the step
-    if world > 1:
+    if getattr(args, 'distributed', world > 1):
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     scores = sweep.run([('lig0', lig_feats, timed)], predictions_file=pred_file)['lig0']
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if getattr(args, 'distributed', world > 1):
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if getattr(args, 'distributed', world > 1):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -318,7 +372,7 @@ def screening_bench(args, rank, world, dev):
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_screening(cfg, lig, rec, feats)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if getattr(args, 'distributed', world > 1):
         dist.barrier()
         dist.destroy_process_group()
 
@@ -356,6 +410,10 @@ def main():
                     help='hand every step a HOST batch (as the reference\'s DataLoader does) and count the '
                          'host-to-device copy in the step: the PCIe-inclusive rate noted in DESIGN.md, never '
                          'the headline value (inputs resident in HBM)')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='with --gpus 1: create a process group of ONE rank and run every collective of the '
+                         'multi-rank path anyway (hooks, bucketed all-reduce, barriers, max-over-ranks): an '
+                         'RCCL smoke on a one-GPU box; not a measured configuration')
     ap.add_argument('--graph', type=int, default=None,
                     help='1: capture the whole step in a hipGraph and time replays (default: 1 for cfg5, the '
                          'configuration BASELINE names; 0 for the training configurations)')
@@ -372,6 +430,7 @@ def main():
 
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(self_launch(args))
+    _import_torch()
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -385,7 +444,14 @@ def main():
     dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
-    if world > 1:
+    distributed = world > 1 or args.force_dist
+    args.distributed = distributed
+    if distributed:
+        if world == 1:      # --force-dist: a group of one, rendezvous on the loopback
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
@@ -427,13 +493,13 @@ def main():
     torch.manual_seed(0)
     model = SartorrasEGNN(Path('/tmp/pvs_bench'), 2e-3, 1e-4, silent=True, **cfg['model']).train()
     params = list(model.parameters())
-    use_graph = bool(args.graph) and world == 1 and not args.build_graph and not args.host_inputs
+    use_graph = bool(args.graph) and not distributed and not args.build_graph and not args.host_inputs
     if use_graph:   # same Adam, step counter kept on the device so the step can be captured
         model.optimiser = torch.optim.Adam(params, lr=2e-3, weight_decay=1e-4, capturable=True)
     # exchange of the late layers' gradients starts from backward hooks, the rest after the backward
     elif os.environ.get('PVS_BENCH_TORCH_ADAM'):   # A/B: torch's multi-tensor Adam + clip_grad_value_
         model.optimiser = torch.optim.Adam(params, lr=2e-3, weight_decay=1e-4)
-    reducer = OverlappedGradAllReducer(params) if world > 1 else None
+    reducer = OverlappedGradAllReducer(params, exchange_when_alone=True) if distributed else None
 
     # measured on MI355X: no gain (8.9 ms with and without; the sorts contend with the edge
     # kernels), so off by default
@@ -492,13 +558,13 @@ def main():
         lib.pvs_profile_reset()
         lib.pvs_profile_enable(0 if use_graph else 1)
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if distributed:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = step()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if distributed:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         lib.pvs_profile_enable(0)
@@ -510,7 +576,7 @@ def main():
                 eager_step()
             torch.cuda.synchronize(dev)
             lib.pvs_profile_enable(0)
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -574,6 +640,8 @@ def main():
                                       'Adam lr 2e-3 wd 1e-4 clip 1.0') + ', random init',
                        'graphs_per_gpu': args.batch, 'global_batch': world * args.batch,
                        'parallelism': f'dp{world}', 'final_loss': round(final_loss, 6),
+                       'arithmetic': ARITHMETIC,
+                       'scaling_note': scaling_note(args, world, strong),
                        'last_layer_coord_update': 'skipped (dead)' if args.skip_dead_coords else 'evaluated',
                        'launch': 'hipGraph replay of the whole step' if use_graph else 'eager',
                        'inputs': (f'host ({args.host_inputs}) batch copied to the device inside every step'
@@ -609,7 +677,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

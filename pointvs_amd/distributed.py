@@ -21,8 +21,10 @@ import torch
 import torch.distributed as dist
 
 
-def _active(group):
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+def _active(group, alone=False):
+    """A process group exists and has someone to exchange with. alone=True: also a group of ONE rank runs
+    its collectives (an RCCL smoke on a one-GPU box walks the very code of the multi-rank path)."""
+    return dist.is_available() and dist.is_initialized() and (alone or dist.get_world_size(group) > 1)
 
 
 class _Bucket:
@@ -75,9 +77,10 @@ class GradAllReducer:
 
     reducer = GradAllReducer(params); ...; loss.backward(); reducer(weight=n_local_graphs)"""
 
-    def __init__(self, params, process_group=None):
+    def __init__(self, params, process_group=None, exchange_when_alone=False):
         self.params = list(params)
         self.group = process_group
+        self.alone = bool(exchange_when_alone)
         self._live = None
         self._bucket = None
         self._pending = None
@@ -129,7 +132,7 @@ class GradAllReducer:
         self._live = self._bucket = None
 
     def __call__(self, weight=1.0):
-        if not _active(self.group):
+        if not _active(self.group, self.alone):
             return
         live = [i for i, p in enumerate(self.params) if p.grad is not None]
         if self._live is None:
@@ -157,10 +160,11 @@ class OverlappedGradAllReducer:
     Use: reducer = OverlappedGradAllReducer(params); ...; loss.backward(); reducer(weight=n_local)
     `weight` of the overlapped buckets is the one given to the PREVIOUS call or set_weight()."""
 
-    def __init__(self, params, n_buckets=2, process_group=None):
+    def __init__(self, params, n_buckets=2, process_group=None, exchange_when_alone=False):
         self.params = list(params)
         self.group = process_group
-        self._flat_fallback = GradAllReducer(self.params, process_group)
+        self.alone = bool(exchange_when_alone)
+        self._flat_fallback = GradAllReducer(self.params, process_group, exchange_when_alone)
         self._buckets = None
         self._bucket_of = {}
         self.n_buckets = max(1, int(n_buckets))
@@ -206,7 +210,7 @@ class OverlappedGradAllReducer:
         self._bucket_of = {i: b for b in self._buckets for i in b.idx}
 
     def __call__(self, weight=None):
-        if not _active(self.group):
+        if not _active(self.group, self.alone):
             return
         if weight is not None:
             self._weight = float(weight)

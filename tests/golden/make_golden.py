@@ -329,6 +329,14 @@ def main():
     run_case('c4_k32_softmax_edgeres_g4', g4, SartorrasEGNN,
              var(k=32, edge_attention=True, softmax_attention=True, edge_residual=True, residual=True,
                  num_layers=3))
+    # C6: MultitaskSatorrasEGNN's per-layer attention placement (egnn_multitask.py:99-123): the edge gate
+    # only in the LAST layer, the node gate only in the FIRST; and the mirrored placement
+    run_case('c6_multitask_att_placement_g5', g5, MultitaskSatorrasEGNN,
+             var(k=32, num_layers=3, edge_attention=True, node_attention=True, residual=True,
+                 edge_attention_final_only=True, node_attention_first_only=True), with_adam=True)
+    run_case('c6_multitask_att_placement_mirrored_g4', g4, MultitaskSatorrasEGNN,
+             var(k=64, num_layers=3, edge_attention=True, node_attention=True,
+                 edge_attention_first_only=True, node_attention_final_only=True), task='regression')
 
 
 if __name__ == '__main__':

@@ -4,12 +4,14 @@ file the validation loop writes, pinned on a file written by the reference's own
 import argparse
 import importlib
 import json
+import sys
 from pathlib import Path
 
 import numpy as np
 import torch
 
 GOLDEN = Path(__file__).resolve().parent / 'golden'
+ROOT = Path(__file__).resolve().parent.parent
 
 
 def test_cli_flags_match_the_reference_parser():
@@ -78,3 +80,24 @@ def test_prediction_line_formats_without_labels_and_multi_target():
     assert format_lines('multi_regression', [[1, 2, 3]], None, ['r'], ['l']) == ['1.000 2.000 3.000 | r l']
     got = format_lines('multi_regression', [[1, 2, 3], [4, 5, 6]], [[-1, 7, -1], [8, -1, -1]], ['ra', 'rb'], ['la', 'lb'])
     assert got == ['7.000 | 2.000 ra la | pkd', '8.000 | 4.000 rb lb | pki']
+
+
+def test_bench_launcher_parent_never_loads_torch_and_counts_gpus_from_sysfs(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` starts its ranks from a parent that has not even
+    imported torch (so it cannot have initialised HIP); the GPU count comes from the KFD topology."""
+    import subprocess
+    code = ("import sys, bench; assert 'torch' not in sys.modules, 'torch imported by the launcher'; "
+            "assert not any('libamdhip64' in l for l in open('/proc/self/maps')); print(bench.visible_gpu_count())")
+    out = subprocess.run([sys.executable, '-c', code], cwd=str(ROOT), capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    import bench
+    for node, simd in enumerate((0, 0, 1024, 1024, 1024)):           # two CPU agents, three GPUs
+        d = tmp_path / str(node)
+        d.mkdir()
+        (d / 'properties').write_text(f'cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nmem_banks_count 1\n')
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpu_count(tmp_path) == 3
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,2')
+    assert bench.visible_gpu_count(tmp_path) == 2
+    assert bench.visible_gpu_count(tmp_path / 'absent') is None

@@ -67,3 +67,85 @@ def test_two_ranks_sharing_one_gpu_train_in_lockstep(tmp_path):
     for n, p in model.named_parameters():
         if p.grad is not None:
             assert rel_err(r0[f's0/reduced/{n}'], p.grad.cpu().numpy()) < 1e-5, n
+
+
+def _run_ranks(target, n, tmp_path, timeout=900):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('forkserver')       # server started in conftest before the GPU was touched
+    procs = [ctx.Process(target=target, args=(r, n, port, str(tmp_path))) for r in range(n)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=timeout)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
+def test_config4_two_ranks_on_baseline_graphs_match_the_fp64_oracle(tmp_path):
+    """BASELINE config 4 (config 2 data parallel) at config-2 GRAPH size, on the product path: two ranks share
+    cuda:0 over gloo, the global batch of 8 graphs (2000 atoms, r = 10 A) is split 4 + 4. The exchanged
+    gradient - step 0 through the flat exchange, step 1 through the hook-driven overlapped buckets - must be
+    the gradient of the mean loss over the GLOBAL batch = the mean of the eight per-graph fp64 ORACLE
+    gradients evaluated at that step's weights (bound: SURVEY 8c, as tests/test_gpu_baseline_parity.py)."""
+    from oracle import egnn_oracle as orc
+    from pointvs_amd.graph import Batch
+    from pointvs_amd.synthetic import CONFIGS
+    _run_ranks(W.rank_main_cfg4, 2, tmp_path)
+    r0, r1 = (np.load(tmp_path / f'rank{r}.npz') for r in range(2))
+    names = sorted(k[len('final/'):] for k in r0.files if k.startswith('final/'))
+    cfg = CONFIGS['cfg2']
+    ocfg = dict(cfg['model'], _class='SartorrasEGNN')
+    graphs = [Batch.from_data_list([g]) for g in W.cfg4_graphs()]
+    assert not bool(r0['s0/overlapped']) and bool(r0['s1/overlapped']) and bool(r1['s1/overlapped'])
+    for step in range(W.CFG4_STEPS):
+        sd = {n: r0[f's{step}/weights/{n}'] for n in names}
+        for n in names:                       # replicas in lockstep
+            assert np.array_equal(r0[f's{step}/weights/{n}'], r1[f's{step}/weights/{n}']), (step, n)
+        mean64, mean32 = {}, {}
+        for g in graphs:
+            y_true = g.y.float().reshape(-1)
+            for dtype, acc in ((torch.float64, mean64), (torch.float32, mean32)):
+                _, _, grads = orc.forward_backward(sd, ocfg, g.x, g.pos, g.edge_index, g.edge_attr, g.batch,
+                                                   y_true, dtype=dtype)
+                for k, v in grads.items():
+                    if v is not None:
+                        acc[k] = acc.get(k, 0.0) + v.numpy().astype(np.float64) / len(graphs)
+        for n in names:
+            got0, got1 = r0[f's{step}/reduced/{n}'], r1[f's{step}/reduced/{n}']
+            if n not in mean64:               # the last layer's coord_mlp: None before and after the exchange
+                assert got0.size == 0 and got1.size == 0, n
+                continue
+            assert np.array_equal(got0, got1), (step, n)
+            bound = max(1e-5, 2.0 * rel_err(mean32[n], mean64[n]))
+            assert rel_err(got0, mean64[n]) <= bound, (step, n, rel_err(got0, mean64[n]), bound)
+    for n in names:
+        assert np.array_equal(r0[f'final/{n}'], r1[f'final/{n}']), n
+
+
+def _run_one(target, out_path, timeout=600):
+    ctx = mp.get_context('forkserver')
+    p = ctx.Process(target=target, args=(str(out_path),))
+    p.start()
+    p.join(timeout=timeout)
+    assert p.exitcode == 0, p.exitcode
+
+
+def test_rccl_all_reduce_on_a_process_group_of_one(tmp_path):
+    """The 'nccl' backend (RCCL) has never run on a multi-GPU node in this project (no such node was leased):
+    at least load it and run the gradient exchange's collective on device memory with world_size 1."""
+    import json
+    _run_one(W.rccl_single_rank_reducer, tmp_path / 'reducer.json')
+    rec = json.loads((tmp_path / 'reducer.json').read_text())
+    assert rec == dict(backend='nccl', same=True, exchanged=True), rec
+
+
+def test_bench_multi_rank_path_runs_on_rccl_with_one_rank(tmp_path):
+    """bench.py's multi-rank code (init_process_group('nccl', device_id=...), hook-driven bucketed all-reduce,
+    barriers around the timed region, max-over-ranks of the time) executed end to end on RCCL."""
+    import json
+    _run_one(W.rccl_single_rank_bench, tmp_path / 'bench.txt')
+    line = [ln for ln in (tmp_path / 'bench.txt').read_text().splitlines() if ln.startswith('{')][-1]
+    rec = json.loads(line)
+    assert rec['n_gpus'] == 1 and rec['value'] > 0 and rec['config']['launch'] == 'eager'
+    assert 'bf16x3' in rec['config']['arithmetic']
