@@ -1,0 +1,534 @@
+// Edge backward for H = 32 with every product as a THREE-term fp16 product on the matrix cores ("f16x2",
+// edge_mfma_common.h), one wave per 32-edge tile, two waves per SIMD. Round 3's successor of
+// k_edge_bwd_bf16 (edge_bwd_bf16.hip: six bf16 terms per product, three parts per operand).
+//
+// What changes against the bf16x3 kernel, per 32-edge tile:
+//   * an operand is split into two fp16 parts with 2 VALU instructions per value (v_fma_mixlo/hi_f16: the
+//     power-of-two tile scale rides in the same instruction) instead of three bf16 parts with 5.5;
+//   * a chain product (W2 a1, Wc1 m, Wc1^T g_zc, W2^T g_z2) is 6 MFMAs instead of 12;
+//   * two parts per tensor are 4 KB of image per wave instead of 6 KB, which frees the LDS for a THIRD image
+//     slot: the gradient tensors (g_zc, g_z2) go to LDS as row-major [edge][channel] images like the
+//     activations, and BOTH operands of the two weight-gradient products over the edge index come back
+//     through the transposing read (ds_read_b64_tr_b16). The transposition on the matrix core (part x
+//     identity, 6 MFMAs + 24 v_perm per gradient tensor, latency-serialised: DESIGN.md §5) is gone;
+//   * a weight-gradient product is 6 MFMAs (+ 4 for the bias column) instead of 18 (+ 6).
+// 44 MFMAs per tile instead of 96. The price: every operand carries a tile scale (a wave-wide maximum, 8
+// v_max3 + 4 DPP steps per operand) and every accumulator is descaled where it is consumed; the
+// weight-gradient products of a tile go through a temporary accumulator, because their scale changes from
+// tile to tile (16 FMAs each).
+//
+// Reference semantics: autograd of EGNNLayer.edge_model / coord_model / node_model's aggregation,
+// /root/reference/point_vs/models/geometric/egnn_satorras.py:123-206 (SURVEY.md §8a "Backward spec").
+#include "edge_mfma_common.h"
+
+namespace {
+
+constexpr int kH = 32;
+constexpr int kPartShorts = 32 * kH;              // one fp16 part image of a [32 edges][32 channels] tensor
+constexpr int kImg2 = 2 * kPartShorts;            // hi + lo
+
+template <bool TRANSPOSE>
+__device__ __forceinline__ f16x8 frag_f16(const unsigned short* __restrict__ part, int lane, int s) {
+    return __builtin_bit_cast(f16x8, img_fragment_bits<1, TRANSPOSE>(part, lane, 0, 0, s));
+}
+
+// acc += (W s_w) (v s_v)  (TRANSPOSE: W^T), v given as its two fp16 parts (B operand, X layout); three terms,
+// the smallest first
+template <bool TRANSPOSE>
+__device__ __forceinline__ void chain_f16(const unsigned short* __restrict__ img, int lane, const F16Parts& b,
+                                          f32x16& acc) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const f16x8 ah = frag_f16<TRANSPOSE>(img, lane, s);
+        const f16x8 al = frag_f16<TRANSPOSE>(img + kH * kH, lane, s);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.hi[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.lo[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi[s], acc, 0, 0, 0);
+    }
+}
+
+// one fp16 part of a [32 edges][32 channels] tensor, X layout -> swizzled row-major image
+__device__ __forceinline__ void write_part_f16(unsigned short* __restrict__ part, int j, int hh, const f16x8 (&p)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const uint4 u = __builtin_bit_cast(uint4, p[s]);
+        // registers 8s..8s+3 hold channels 16s + 4hh + (0..3), registers 8s+4..8s+7 channels 16s + 8 + 4hh + (0..3)
+        *reinterpret_cast<uint2*>(part + img_off<1>(j, 16 * s + 4 * hh)) = make_uint2(u.x, u.y);
+        *reinterpret_cast<uint2*>(part + img_off<1>(j, 16 * s + 8 + 4 * hh)) = make_uint2(u.z, u.w);
+    }
+}
+
+__device__ __forceinline__ void write_image_f16(unsigned short* __restrict__ img, int j, int hh, const F16Parts& b) {
+    write_part_f16(img, j, hh, b.hi);
+    write_part_f16(img + kPartShorts, j, hh, b.lo);
+}
+
+// gW (D layout [c = ch(r,hh)][k = j]) += inv_w * sum over the tile's edges of G'[e][c] * Act'[e][k], and
+// gB[.][col] += inv_b * sum over the tile's edges of G'[e][.]  (the bias gradient belonging to G, as a product
+// with a B operand that is all ones in column `col`: the matrix core does the sum over the edges).
+// G' and Act' are the scaled fp16 images of the gradient and activation tensors; both operands are read
+// transposed (k = edge index). inv_w = 1 / (s_G s_Act), inv_b = 1 / s_G.
+__device__ __forceinline__ void wgrad_tile_f16(const unsigned short* __restrict__ g_img,
+                                               const unsigned short* __restrict__ act_img,
+                                               const unsigned* __restrict__ ones, int lane, float inv_w, float inv_b,
+                                               f32x16& gW, f32x16& gB) {
+    f32x16 t, tb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { t[r] = 0.f; tb[r] = 0.f; }
+    const f16x8 one = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ones + lane * 4));
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const f16x8 gh = frag_f16<true>(g_img, lane, s);
+        const f16x8 gl = frag_f16<true>(g_img + kPartShorts, lane, s);
+        const f16x8 ah = frag_f16<true>(act_img, lane, s);
+        const f16x8 al = frag_f16<true>(act_img + kPartShorts, lane, s);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, ah, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, al, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, ah, t, 0, 0, 0);
+        tb = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, one, tb, 0, 0, 0);
+        tb = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, one, tb, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        gW[r] = fmaf(t[r], inv_w, gW[r]);
+        gB[r] = fmaf(tb[r], inv_b, gB[r]);
+    }
+}
+
+struct F16Cfg {
+    static constexpr int kThreadsPerBlock = 512;                          // two waves per SIMD
+    static constexpr int kWavesPerBlock = kThreadsPerBlock / 64;
+    static constexpr int kTS = kH + 4;                                    // g_z1 tile row stride (floats)
+    // per wave: a1 image, m image, gradient image (4 KB each), SiLU'(z1) (4 KB)
+    static constexpr int kWaveBytes = 3 * kImg2 * 2 + 16 * 64 * 4;
+    // shared: W2 and Wc1 images (hi + lo), tables, two ones columns, 4 words of weight maxima
+    static constexpr int kSharedBytes = 2 * kImg2 * 2 + (5 + PVS_MAX_EDGE_ATTR) * kH * 4 + 2 * 64 * 16 + 16;
+    static_assert(kTile * kTS * 4 + kTile * 16 + kTile * 4 <= 2 * kImg2 * 2, "g_z1 tile + tx + rowbuf must fit the m + gradient images");
+};
+
+template <bool ERES, bool EATT>
+__global__ void __launch_bounds__(F16Cfg::kThreadsPerBlock, 2)
+k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks, int e_lo, int e_hi) {
+    using Cfg = F16Cfg;
+    constexpr int H = kH, NT = Cfg::kThreadsPerBlock, NW = Cfg::kWavesPerBlock;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* W2i = reinterpret_cast<unsigned short*>(smem);         // hi, lo: [H][H] fp16 each
+    unsigned short* Wc1i = W2i + kImg2;
+    float* b2t = smem + kImg2;                                             // (2 images x kImg2 shorts = kImg2 floats)
+    float* bc1t = b2t + H;
+    float* wc2t = bc1t + H;
+    float* wat = wc2t + H;
+    float* wrhot = wat + H;
+    float* attrt = wrhot + H;                                  // [PVS_MAX_EDGE_ATTR][H]
+    unsigned* ones0 = reinterpret_cast<unsigned*>(attrt + PVS_MAX_EDGE_ATTR * H);   // [64 lanes][4]: fp16 ones, column 0 (g_bc1)
+    unsigned* ones1 = ones0 + 64 * 4;               // ... column 1 (g_b2)
+    unsigned* wmax = ones1 + 64 * 4;                // [0]: max |W2|, [1]: max |Wc1| (fp32 bits)
+    char* wave_base = reinterpret_cast<char*>(wmax + 4);
+
+    const bool upd = (flags & PVS_UPDATE_COORDS) && io.gxagg != nullptr;
+
+    if (threadIdx.x < 4) wmax[threadIdx.x] = 0u;
+    __syncthreads();
+    pvs_block_absmax(w.w2, H * H, wmax);
+    if (upd) pvs_block_absmax(w.wc1, H * H, wmax + 1);
+    __syncthreads();
+    float inv_sw2, inv_swc1;
+    const float sw2 = pvs_f16_scale(wmax[0], &inv_sw2);
+    const float swc1 = pvs_f16_scale(wmax[1], &inv_swc1);
+    stage_weights_img_f16<1>(W2i, w.w2, sw2);
+    if (upd) stage_weights_img_f16<1>(Wc1i, w.wc1, swc1);
+    for (int c = threadIdx.x; c < H; c += NT) {
+        b2t[c] = w.b2[c];
+        bc1t[c] = upd ? w.bc1[c] : 0.f;
+        wc2t[c] = upd ? w.wc2[c] : 0.f;
+        wat[c] = EATT ? w.wa[c] : 0.f;
+        wrhot[c] = w.w1[c * w.ld1 + w.off_rho];
+        for (int t = 0; t < PVS_MAX_EDGE_ATTR; ++t)
+            attrt[t * H + c] = t < w.n_attr ? w.w1[c * w.ld1 + w.off_rho + 1 + t] : 0.f;
+    }
+    for (int i = threadIdx.x; i < 64 * 4; i += NT) {
+        const int col = (i >> 2) & 31;
+        ones0[i] = col == 0 ? 0x3c003c00u : 0u;      // fp16 1.0 pairs
+        ones1[i] = col == 1 ? 0x3c003c00u : 0u;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    unsigned short* A1I = reinterpret_cast<unsigned short*>(wave_base + wv * Cfg::kWaveBytes);
+    unsigned short* MI = A1I + kImg2;
+    unsigned short* GI = MI + kImg2;
+    float* d1b = reinterpret_cast<float*>(GI + kImg2);         // SiLU'(z1), X layout, lane-private
+    // once the m and gradient images are dead (after the W2 weight gradient) their slots hold the g_z1 tile
+    float* T1 = reinterpret_cast<float*>(MI);
+    float* tx = T1 + kTile * Cfg::kTS;
+    int* rowbuf = reinterpret_cast<int*>(tx + kTile * 4);
+
+    const float bac = EATT ? w.ba[0] : 0.f;
+    float gate_raw = 0.f, gate = 1.f;
+    if (ERES && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
+        gate_raw = w.edge_gate[0];
+        gate = (flags & PVS_GATED_RESIDUAL) ? fmaxf(gate_raw, 0.f) : gate_raw;
+    }
+    const float res_a = (flags & (PVS_REZERO | PVS_GATED_RESIDUAL)) ? gate : 1.f;
+    const float res_b = (flags & PVS_GATED_RESIDUAL) ? 1.f - gate : 1.f;
+
+    // ---- accumulators that live for the whole kernel ----
+    f32x16 gW2, gWc1;                          // D layout: [c = ch(r,hh)][k = j]
+    f32x16 gB;                                 // column 0: g_bc1, column 1: g_b2 (rows = channels, D layout)
+    float g_wc2x[16];                          // X layout (channel in the register, edges on lanes)
+    float g_wax[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { gB[r] = 0.f; g_wc2x[r] = 0.f; gW2[r] = 0.f; gWc1[r] = 0.f; g_wax[r] = 0.f; }
+    float g_ba = 0.f, g_gate = 0.f;
+
+    const int total_waves = gridDim.x * NW;
+    for (int chunk = pvs_xcd_block(blockIdx.x, gridDim.x) * NW + wv; chunk < n_chunks; chunk += total_waves) {
+        const int e_begin = chunk_begin(g, chunk, n_chunks, e_lo, e_hi);
+        const int e_end = chunk_begin(g, chunk + 1, n_chunks, e_lo, e_hi);
+        int cur_row = -1;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accx = acc;   // open row: lane = (row slot, quad)
+        constexpr int QPR = H / 4;
+        const int quad = lane % QPR, rsub = lane / QPR;
+        auto flush = [&](int row_id) {
+            if (row_id >= 0) {
+                const float4 tot = sum_row_slots<1>(acc);
+                if (rsub == 0) *reinterpret_cast<float4*>(io.gPQ + (size_t)row_id * 2 * H + 4 * quad) = tot;
+                const float4 tx4 = sum_row_slots<1>(accx);
+                if (lane == 0) {
+                    io.gx_row[3 * row_id] = tx4.x;
+                    io.gx_row[3 * row_id + 1] = tx4.y;
+                    io.gx_row[3 * row_id + 2] = tx4.z;
+                }
+            }
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            accx = acc;
+        };
+        TileIdx I = load_tile_idx(g, w.n_attr, e_begin, e_begin, e_end, j);
+        for (int e0 = e_begin; e0 < e_end; e0 += kTile) {
+            const int e_next = (e0 + kTile < e_end) ? e0 + kTile : e0;
+            const TileIdx In = load_tile_idx(g, w.n_attr, e_next, e_begin, e_end, j);
+            const int e = I.e, ee = I.ee, i = I.i, ty = I.ty;
+            const bool valid = I.valid;
+            const float vm = valid ? 1.f : 0.f;
+            const unsigned bmask = (unsigned)__ballot(valid && hh == 0 && i != I.prev_row);
+            float d0, d1, d2, rho;
+            F16Parts pb;                      // parts of the tensor being pushed through a product
+            float inv_sa1, inv_sm = 1.f;      // 1 / tile scale of the a1 and m images
+
+            // ---- recompute: z1, a1 = SiLU(z1), SiLU'(z1); a1 image; z2 = W2 a1 + b2 ----
+            float z2[16];
+            {
+                TileGather<1> G;
+                gather_tile<1>(io.PQ, io.x, I, hh, G);
+                d0 = G.d0; d1 = G.d1; d2 = G.d2;
+                rho = d0 * d0 + d1 * d1 + d2 * d2;
+                float a1[1][16];
+                assemble_z1<1>(G, attrt, wrhot, ty, hh, rho, a1);
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    float dd[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float z = a1[0][4 * gq + q];
+                        const float sg = pvs_sigmoid(z);
+                        const float av = z * sg;
+                        dd[q] = fmaf(av, 1.0f - sg, sg);       // SiLU'(z) = s + z s (1 - s)
+                        a1[0][4 * gq + q] = av;
+                    }
+                    *reinterpret_cast<float4*>(d1b + (gq * 64 + lane) * 4) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+                }
+                const float sa1 = pvs_tile_scale(a1[0], &inv_sa1);
+                split_f16x2(a1[0], sa1, pb);
+                write_image_f16(A1I, j, hh, pb);
+                f32x16 acc2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+                chain_f16<false>(W2i, lane, pb, acc2);
+                float bias[1][16];
+                load_tab<1>(b2t, hh, bias);
+                const float k2 = inv_sa1 * inv_sw2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z2[r] = fmaf(acc2[r], k2, bias[0][r]);
+            }
+            float dz2[16], m[1][16];          // SiLU'(z2) and the message
+            float m_new[ERES ? 16 : 1], mp[1][16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sg = pvs_sigmoid(z2[r]);
+                m[0][r] = z2[r] * sg;
+                dz2[r] = fmaf(m[0][r], 1.0f - sg, sg);
+                if constexpr (ERES) m_new[r] = m[0][r];
+            }
+            if constexpr (ERES) {
+                load_x<1>(io.m_prev + (size_t)ee * H, hh, mp);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m[0][r] = fmaf(res_a, m_new[r], res_b * mp[0][r]);
+            }
+
+            // ---- gradient wrt m: the coordinate branch's term comes from the matrix core first; the external,
+            // aggregated-message and attention terms are added AFTER it (g_m is then not live across the
+            // coordinate branch) ----
+            float gm[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gm[r] = 0.f;
+            float gMi[1][16];
+            auto load_row_terms = [&]() { load_x<1>(io.gM + (size_t)i * H, hh, gMi); };
+            auto add_row_terms = [&]() {
+                if (io.g_m_out) {
+                    float init[1][16];
+                    load_x<1>(io.g_m_out + (size_t)ee * H, hh, init);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gm[r] = fmaf(init[0][r], vm, gm[r]);
+                }
+                if constexpr (EATT) {
+                    float wax[1][16];
+                    load_tab<1>(wat, hh, wax);
+                    float logit = 0.f, dot = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        logit = fmaf(wax[0][r], m[0][r], logit);
+                        dot = fmaf(m[0][r], gMi[0][r], dot);
+                    }
+                    logit += __shfl_xor(logit, 32, 64);
+                    dot += __shfl_xor(dot, 32, 64);
+                    logit += bac;
+                    const float aval = io.att[ee];
+                    const float g_l = (flags & PVS_SOFTMAX_ATT) ? aval * (dot - io.softD[i]) * vm   // softD = M_i . g_M_i
+                                                                : pvs_att_act_grad(att_act, logit, aval) * dot * vm;
+                    if (hh == 0) g_ba += g_l;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        gm[r] += (aval * vm) * gMi[0][r] + g_l * wax[0][r];
+                        g_wax[r] = fmaf(g_l, m[0][r], g_wax[r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gm[r] = fmaf(vm, gMi[0][r], gm[r]);
+                }
+            };
+            float s_coord = 0.f, nrm = 1.f;
+            float gT0 = 0.f, gT1 = 0.f, gT2 = 0.f;
+            if (upd) {
+                gT0 = io.gxagg[3 * i]; gT1 = io.gxagg[3 * i + 1]; gT2 = io.gxagg[3 * i + 2];
+                const float sm = pvs_tile_scale(m[0], &inv_sm);
+                split_f16x2(m[0], sm, pb);
+                write_image_f16(MI, j, hh, pb);
+                f32x16 accc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accc[r] = 0.f;
+                chain_f16<false>(Wc1i, lane, pb, accc);               // (Wc1 m) s_m s_wc1
+                float bias2[1][16], wc2x[1][16];
+                load_tab<1>(bc1t, hh, bias2);
+                load_tab<1>(wc2t, hh, wc2x);
+                const float kc = inv_sm * inv_swc1;
+                float q[16], dq[16];
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float zc = fmaf(accc[r], kc, bias2[0][r]);   // zc = Wc1 m + bc1
+                    const float sg = pvs_sigmoid(zc);
+                    q[r] = zc * sg;
+                    dq[r] = fmaf(q[r], 1.0f - sg, sg);
+                    s = fmaf(wc2x[0][r], q[r], s);
+                }
+                s += __shfl_xor(s, 32, 64);
+                float dact = 1.f;
+                if (flags & PVS_TANH) { s = pvs_tanh(s); dact = 1.f - s * s; }
+                if (flags & PVS_NORMALIZE) nrm = 1.f / (sqrtf(rho) + 1e-8f);
+                s_coord = s;
+                const float g_s = (d0 * gT0 + d1 * gT1 + d2 * gT2) * nrm * dact * vm;
+                float g_zc[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    g_zc[r] = g_s * wc2x[0][r] * dq[r];
+                    g_wc2x[r] = fmaf(g_s, q[r], g_wc2x[r]);
+                }
+                float inv_sg;
+                const float sg_ = pvs_tile_scale(g_zc, &inv_sg);
+                split_f16x2(g_zc, sg_, pb);
+                write_image_f16(GI, j, hh, pb);
+                f32x16 accg;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accg[r] = 0.f;
+                chain_f16<true>(Wc1i, lane, pb, accg);                // (Wc1^T g_zc) s_g s_wc1
+                const float kg = inv_sg * inv_swc1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gm[r] = accg[r] * kg;
+                pvs_wave_lds_sync();                                  // the m and g_zc images are complete
+                wgrad_tile_f16(GI, MI, ones0, lane, inv_sg * inv_sm, inv_sg, gWc1, gB);   // gWc1 += g_zc (x) m ; g_bc1 += sum_e g_zc
+                load_row_terms();
+            } else {
+                load_row_terms();
+            }
+            add_row_terms();
+            // ---- edge residual; g_z2 = g_m_new * SiLU'(z2) ----
+            float g_z2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float gmv = gm[r];
+                float gnew = gmv;
+                if constexpr (ERES) {
+                    if (flags & PVS_REZERO) {
+                        gnew = gate * gmv;
+                        g_gate = fmaf(gmv, m_new[r], g_gate);
+                        mp[0][r] = gmv;
+                    } else if (flags & PVS_GATED_RESIDUAL) {
+                        gnew = gate * gmv;
+                        if (gate_raw > 0.f) g_gate = fmaf(gmv, m_new[r] - mp[0][r], g_gate);
+                        mp[0][r] = (1.f - gate) * gmv;
+                    } else {
+                        mp[0][r] = gmv;
+                    }
+                }
+                g_z2[r] = gnew * dz2[r];
+            }
+            if constexpr (ERES) {
+                if (valid) store_x<1>(io.g_m_prev + (size_t)e * H, hh, mp);
+            }
+            // ---- g_a1 = W2^T g_z2 ; gW2 += g_z2 (x) a1 ; g_b2 += sum_e g_z2 ; g_z1 = g_a1 * SiLU'(z1) ----
+            float inv_sg2;
+            const float sg2 = pvs_tile_scale(g_z2, &inv_sg2);
+            split_f16x2(g_z2, sg2, pb);
+            pvs_wave_lds_sync();                                      // the g_zc image has been read
+            write_image_f16(GI, j, hh, pb);
+            f32x16 ga1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ga1[r] = 0.f;
+            chain_f16<true>(W2i, lane, pb, ga1);
+            pvs_wave_lds_sync();                                      // the a1 and g_z2 images are complete
+            wgrad_tile_f16(GI, A1I, ones1, lane, inv_sg2 * inv_sa1, inv_sg2, gW2, gB);
+            float g_z1[1][16];
+            const float k1g = inv_sg2 * inv_sw2;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 dd = *reinterpret_cast<const float4*>(d1b + (gq * 64 + lane) * 4);
+                g_z1[0][4 * gq] = ga1[4 * gq] * (dd.x * k1g);
+                g_z1[0][4 * gq + 1] = ga1[4 * gq + 1] * (dd.y * k1g);
+                g_z1[0][4 * gq + 2] = ga1[4 * gq + 2] * (dd.z * k1g);
+                g_z1[0][4 * gq + 3] = ga1[4 * gq + 3] * (dd.w * k1g);
+            }
+            const float g_rho = dot_tab<1>(wrhot, hh, g_z1);
+            const float k1 = s_coord * nrm * vm;
+            const float gd0 = fmaf(k1, gT0, 2.f * d0 * g_rho);
+            const float gd1 = fmaf(k1, gT1, 2.f * d1 * g_rho);
+            const float gd2 = fmaf(k1, gT2, 2.f * d2 * g_rho);
+            pvs_wave_lds_sync();          // every read of the m / gradient images (their slots become the g_z1 tile) is done
+            // per edge: grad wrt (x_row - x_col) and rho, 16 B, for the node gather kernel
+            if (hh == 0) {
+                *reinterpret_cast<float4*>(tx + j * 4) = make_float4(gd0, gd1, gd2, 0.f);
+                rowbuf[j] = i;
+                if (valid)
+                    pvs_store_nt(io.gd + (size_t)e * 4, make_float4(gd0, gd1, gd2, pvs_pack_rho_type(rho, ty)));
+            }
+            // ---- g_z1 edge-major, then whole rows to HBM + the row-side sums from the same reads ----
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *reinterpret_cast<float4*>(T1 + j * Cfg::kTS + 8 * gq + 4 * hh) =
+                    make_float4(g_z1[0][4 * gq], g_z1[0][4 * gq + 1], g_z1[0][4 * gq + 2], g_z1[0][4 * gq + 3]);
+            pvs_wave_lds_sync();
+            reduce_rows_tile<1>(T1, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
+                                [&](int rl, int q, const float4& v) {
+                                    if (e0 + rl < e_end)   // streamed once: non-temporal
+                                        pvs_store_nt(io.gz1 + (size_t)(e0 + rl) * H + 4 * q, v);
+                                });
+            I = In;
+            pvs_wave_lds_sync();
+        }
+        flush(cur_row);
+    }
+
+    // ---- block reduction into one slab, fixed order ----
+    const PvsSlabLayout L = pvs_slab_layout(H);
+    __syncthreads();
+    float* slab = smem;
+    for (int i = threadIdx.x; i < L.total; i += NT) slab[i] = 0.f;
+    __syncthreads();
+    // X-layout vectors: sum over the 32 edge lanes of each half
+    auto lanes32 = [](float v) {
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g_wc2x[r] = lanes32(g_wc2x[r]);
+    if constexpr (EATT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g_wax[r] = lanes32(g_wax[r]);
+    }
+    g_ba += __shfl_xor(g_ba, 32, 64);          // only hh == 0 lanes accumulated
+    g_ba = lanes32(g_ba);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) g_gate += __shfl_xor(g_gate, o, 64);
+    for (int turn = 0; turn < NW; ++turn) {
+        if (wv == turn) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = xch(r, hh), k = j;
+                slab[L.w2 + c * H + k] += gW2[r];
+                slab[L.wc1 + c * H + k] += gWc1[r];
+            }
+            if (j == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = xch(r, hh);
+                    slab[L.wc2 + c] += g_wc2x[r];
+                    if constexpr (EATT) slab[L.wa + c] += g_wax[r];
+                }
+            }
+            if (j <= 1) {      // bias gradients: column 0 of gB is g_bc1, column 1 is g_b2
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[(j == 0 ? L.bc1 : L.b2) + xch(r, hh)] += gB[r];
+            }
+            if (lane == 0) { slab[L.ba] += g_ba; slab[L.gate] += g_gate; }
+        }
+        __syncthreads();
+    }
+    float* dst = io.slabs + (size_t)blockIdx.x * L.total;
+    for (int i = threadIdx.x; i < L.total; i += NT) dst[i] = slab[i];
+}
+
+}  // namespace
+
+// Same contract as pvs_launch_edge_bwd_mfma (edge_mfma.hip). H = 32 only.
+int pvs_launch_edge_bwd_f16(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags, int att_act,
+                            const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs) {
+    PVS_REQUIRE(w.n_attr <= 3, "MFMA edge backward supports up to 3 edge classes (got %d)", w.n_attr);
+    PVS_REQUIRE(H == 32, "f16x2 edge backward is built for H = 32 (got %d)", H);
+    *n_slabs = 0;
+    if (e_hi <= e_lo) return 0;
+    using Cfg = F16Cfg;
+    constexpr int nw = Cfg::kWavesPerBlock;
+    int blocks, n_chunks;
+    {
+        const int E = e_hi - e_lo;
+        long long b = ((long long)E + (long long)nw * 512 - 1) / ((long long)nw * 512);   // fill the chip first
+        if (b < 1) b = 1;
+        if (b > 256) b = 256;                      // one workgroup per CU (LDS)
+        const long long waves = b * nw;
+        long long per_wave = ((long long)E + waves * 4096 - 1) / (waves * 4096);
+        if (per_wave < 1) per_wave = 1;
+        blocks = (int)b;
+        n_chunks = (int)(waves * per_wave);
+    }
+    *n_slabs = blocks;
+    PvsProfScope prof(s, PVS_PROF_EDGE_BWD);
+    const PvsSlabLayout L = pvs_slab_layout(kH);
+    size_t lds = (size_t)Cfg::kSharedBytes + (size_t)nw * Cfg::kWaveBytes;
+    if (lds < (size_t)L.total * 4) lds = (size_t)L.total * 4;
+    const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
+    const bool eatt = flags & PVS_EDGE_ATTENTION;
+#define PVS_BWD_F16_LAUNCH(ER, EA)                                                                          \
+    do {                                                                                                   \
+        if (set_lds(k_edge_bwd_f16<ER, EA>, lds)) return -2;                                               \
+        k_edge_bwd_f16<ER, EA><<<blocks, Cfg::kThreadsPerBlock, lds, s>>>(g, w, flags, att_act, io, n_chunks, \
+                                                                          e_lo, e_hi);                   \
+    } while (0)
+    if (eres && eatt) PVS_BWD_F16_LAUNCH(true, true);
+    else if (eres) PVS_BWD_F16_LAUNCH(true, false);
+    else if (eatt) PVS_BWD_F16_LAUNCH(false, true);
+    else PVS_BWD_F16_LAUNCH(false, false);
+#undef PVS_BWD_F16_LAUNCH
+    PVS_CHECK_LAUNCH();
+    return 0;
+}

@@ -80,6 +80,10 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
 // same contract as pvs_launch_edge_bwd_mfma
 int pvs_launch_edge_bwd_bf16(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags, int att_act,
                              const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs);
+// H = 32 backward with every product as three fp16 terms (f16x2 split with tile scales), both weight-gradient
+// operands through transposing LDS reads (edge_bwd_f16.hip, round 3); same contract
+int pvs_launch_edge_bwd_f16(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags, int att_act,
+                            const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs);
 // H = 64 backward, one wave per 16-edge tile with 16x16x32 chain products (edge_bwd_h64.hip); same contract
 int pvs_launch_edge_bwd_h64(hipStream_t s, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags, int att_act,
                             const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs);

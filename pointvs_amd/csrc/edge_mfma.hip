@@ -1637,6 +1637,11 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
         const bool eres_on = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
         const bool all_bf16 = !(bf && bf[0] == '0');
         const bool eres_att = eres_on && (flags & PVS_EDGE_ATTENTION);
+        // round 3: H = 32 as three-term fp16 products (edge_bwd_f16.hip), every flag combination;
+        // PVS_BWD32=bf16: the round-2 six-term bf16 kernel (which hands edge residual + attention to round 1's)
+        const bool want_bf16 = b32 && b32[0] == 'b';
+        if (H == 32 && all_bf16 && !want_bf16 && !(b32 && b32[0] == '0'))
+            return pvs_launch_edge_bwd_f16(s, H, g, w, flags, att_act, io, e_lo, e_hi, n_slabs);
         if (H == 32 && all_bf16 && !eres_att && !(b32 && b32[0] == '0'))
             return pvs_launch_edge_bwd_bf16(s, H, g, w, flags, att_act, io, e_lo, e_hi, n_slabs);
         // H = 64: one wave per 16-edge tile (edge_bwd_h64.hip); PVS_BWD64=0: the round-1 team kernel below

@@ -380,8 +380,8 @@ __device__ __forceinline__ void stage_weights_img(unsigned short* img, const flo
 // A-operand fragment (8 bf16 in the k order of the X layout) of block (bo, bi), k-step s, of one part
 // image: TRANSPOSE = false: rows of W (W v); true: columns of W (W^T v) through the transposing read.
 template <int HB, bool TRANSPOSE>
-__device__ __forceinline__ bf16x8 img_fragment(const unsigned short* __restrict__ part, int lane, int bo,
-                                               int bi, int s) {
+__device__ __forceinline__ uint4 img_fragment_bits(const unsigned short* __restrict__ part, int lane, int bo,
+                                                   int bi, int s) {
     const int hh = lane >> 5;
     uint2 a, b;
     if constexpr (!TRANSPOSE) {
@@ -399,7 +399,13 @@ __device__ __forceinline__ bf16x8 img_fragment(const unsigned short* __restrict_
         a = __builtin_bit_cast(uint2, ta);
         b = __builtin_bit_cast(uint2, tb);
     }
-    return __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+
+template <int HB, bool TRANSPOSE>
+__device__ __forceinline__ bf16x8 img_fragment(const unsigned short* __restrict__ part, int lane, int bo,
+                                               int bi, int s) {
+    return __builtin_bit_cast(bf16x8, img_fragment_bits<HB, TRANSPOSE>(part, lane, bo, bi, s));
 }
 
 // acc += W v (TRANSPOSE: W^T v) for H = 32 with the weights as one image per part
@@ -457,6 +463,173 @@ __device__ __forceinline__ void mfma_chain_bf16x3_blocks(const unsigned* __restr
             }
         }
     }
+}
+
+
+// ---- fp32 products as 3 fp16 MFMA terms ("f16x2", round 3) ------------------------------------------
+// x*s = hi + lo with hi = fp16(x*s) (round to nearest) and lo = fp16(x*s - hi): 22 significant bits in two
+// parts instead of 24 in three, and  a*b = (hi*hi + hi*lo + lo*hi) / (s_a s_b) + O(2^-22 |a||b|)  with the
+// three terms summed in ONE fp32 accumulator of v_mfma_f32_32x32x16_f16 (same cycles as the bf16 form): half
+// the MFMAs of bf16x3 and 2 VALU instructions per split value instead of 5.5 - v_fma_mixlo/hi_f16 evaluates
+// x*s (and x*s - hi) in fp32 and rounds to fp16 into one half of a register, scaling included.
+// fp16 has 5 exponent bits, so every operand is scaled by a power of two s chosen from the maximum of the
+// TILE it belongs to (activations reach 1e3, gradients 1e-9: neither fits fp16 unscaled): s * max in
+// [2^13, 2^14). Then hi never overflows and the representation error of an element is
+// max(2^-22 |x s|, 2^-25) - the second term (fp16 subnormal spacing) is 2^-38 of the tile maximum, so small
+// elements of a tile keep more absolute accuracy than fp32 rounding of the sums they enter. Power-of-two
+// scales are exact; products are divided by s_a s_b where the accumulator is consumed (folded into the FMA
+// that adds the bias / multiplies by the activation derivative).
+// Emulated against fp64 on random tiles with 2^+-6 dynamic range inside a tile (tools/f16x2_numerics.py):
+// max error 2e-7 of sum|a||b|, between a sequential fp32 FMA chain (3e-7) and bf16x3 (1.5e-7).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct F16Parts { f16x8 hi[2], lo[2]; };
+
+// maximum over the wave of a per-lane u32 (all 64 lanes active), wave-uniform result
+__device__ __forceinline__ unsigned pvs_wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
+    v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+    v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true));    // row_half_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true));    // row_mirror
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+// power-of-two scale for values whose largest magnitude has the fp32 bit pattern `max_bits`:
+// s * max in [2^13, 2^14);  *inv = 1 / s. All-zero / denormal input: s = 2^124.
+__device__ __forceinline__ float pvs_f16_scale(unsigned max_bits, float* inv) {
+    int e = (int)((max_bits >> 23) & 0xffu);
+    e = e < 16 ? 16 : e;
+    *inv = __uint_as_float((unsigned)(e - 13) << 23);
+    return __uint_as_float((unsigned)(267 - e) << 23);
+}
+
+__device__ __forceinline__ float pvs_absmax16(const float (&v)[16]) {
+    float m = fmaxf(fabsf(v[0]), fabsf(v[1]));
+#pragma unroll
+    for (int t = 2; t < 16; t += 2) m = fmaxf(fmaxf(m, fabsf(v[t])), fabsf(v[t + 1]));
+    return m;
+}
+
+// scale of one 32-edge tile operand held in X layout (16 values per lane, whole wave)
+__device__ __forceinline__ float pvs_tile_scale(const float (&v)[16], float* inv) {
+    return pvs_f16_scale(pvs_wave_max_u32(__float_as_uint(pvs_absmax16(v))), inv);
+}
+
+// fp16 pair (x0*s, x1*s) rounded to nearest, low half = x0
+__device__ __forceinline__ unsigned pvs_f16_hi2(float x0, float x1, float s) {
+    unsigned h;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+    return h;
+}
+// fp16 pair (x0*s - hi.lo, x1*s - hi.hi): the residuals (exact in fp32) rounded to fp16
+__device__ __forceinline__ unsigned pvs_f16_lo2(float x0, float x1, float s, unsigned h) {
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
+    return l;
+}
+
+__device__ __forceinline__ void split_f16x2(const float (&v)[16], float s, F16Parts& out) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        uint4 ph, pl;
+        unsigned* h = reinterpret_cast<unsigned*>(&ph);
+        unsigned* l = reinterpret_cast<unsigned*>(&pl);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float x0 = v[8 * ks + 2 * q], x1 = v[8 * ks + 2 * q + 1];
+            h[q] = pvs_f16_hi2(x0, x1, s);
+            l[q] = pvs_f16_lo2(x0, x1, s, h[q]);
+        }
+        out.hi[ks] = __builtin_bit_cast(f16x8, ph);
+        out.lo[ks] = __builtin_bit_cast(f16x8, pl);
+    }
+}
+
+// W [H][H] (row-major) * s as two swizzled row-major fp16 images (hi at img, lo at img + H*H), the layout of
+// stage_weights_img: rows through ds_read_b64 for W v, columns through ds_read_b64_tr_b16 for W^T v.
+template <int HB>
+__device__ __forceinline__ void stage_weights_img_f16(unsigned short* img, const float* __restrict__ W, float s) {
+    constexpr int H = 32 * HB;
+    unsigned* hi = reinterpret_cast<unsigned*>(img);
+    unsigned* lo = reinterpret_cast<unsigned*>(img + H * H);
+    for (int i = threadIdx.x; i < H * H / 2; i += blockDim.x) {
+        const int r = (2 * i) / H, c = (2 * i) % H;
+        const float x0 = W[r * H + c], x1 = W[r * H + c + 1];
+        const unsigned h = pvs_f16_hi2(x0, x1, s);
+        const int o = img_off<HB>(r, c) >> 1;
+        hi[o] = h;
+        lo[o] = pvs_f16_lo2(x0, x1, s, h);
+    }
+}
+
+// A-operand order for the forward kernels (one ds_read_b128 per fragment): the 32x32 block W[row0 + .][col0 + .]
+// of a matrix with row stride ld, times s, as dst[((part*2 + ks)*64 + l)*4 .. +3] (uint words) = 8 fp16 of
+// W[l&31][ch(8ks + j', l>>5)], part in {hi, lo}: 4 KB per block.
+__device__ __forceinline__ void stage_weights_f16x2(unsigned* dst, const float* __restrict__ W, float s, int ld,
+                                                    int row0, int col0) {
+    W += (size_t)row0 * ld + col0;
+    for (int i = threadIdx.x; i < 2 * 64 * 4; i += blockDim.x) {
+        const int q = i & 3, l = (i >> 2) & 63, ks = i >> 8;
+        const int o = l & 31, hh = l >> 5;
+        const float x0 = W[o * ld + xch(8 * ks + 2 * q, hh)], x1 = W[o * ld + xch(8 * ks + 2 * q + 1, hh)];
+        const unsigned h = pvs_f16_hi2(x0, x1, s);
+        dst[((0 * 2 + ks) * 64 + l) * 4 + q] = h;
+        dst[((1 * 2 + ks) * 64 + l) * 4 + q] = pvs_f16_lo2(x0, x1, s, h);
+    }
+}
+
+template <int HB>
+__device__ __forceinline__ void stage_weights_f16x2_blocks(unsigned* dst, const float* __restrict__ W, float s) {
+#pragma unroll
+    for (int bo = 0; bo < HB; ++bo)
+#pragma unroll
+        for (int bi = 0; bi < HB; ++bi)
+            stage_weights_f16x2(dst + (bo * HB + bi) * (4 * 64 * 4), W, s, 32 * HB, 32 * bo, 32 * bi);
+}
+
+// acc[bo] += sum_bi (W s_w)[bo][bi] (v s_v)[bi]: v (X layout, fp32) is split here with the tile scale s_v
+template <int HB>
+__device__ __forceinline__ void mfma_chain_f16x2_blocks(const unsigned* __restrict__ Wb, int lane,
+                                                        const float (&v)[HB][16], float s_v, f32x16 (&acc)[HB]) {
+#pragma unroll
+    for (int bi = 0; bi < HB; ++bi) {
+        F16Parts b;
+        split_f16x2(v[bi], s_v, b);
+#pragma unroll
+        for (int bo = 0; bo < HB; ++bo) {
+            const unsigned* Wblk = Wb + (bo * HB + bi) * (4 * 64 * 4);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(Wblk + ((0 * 2 + ks) * 64 + lane) * 4));
+                const f16x8 al = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(Wblk + ((1 * 2 + ks) * 64 + lane) * 4));
+                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.hi[ks], acc[bo], 0, 0, 0);
+                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.lo[ks], acc[bo], 0, 0, 0);
+                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi[ks], acc[bo], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// tile scale of an H = 32*HB channel operand (all blocks share one scale)
+template <int HB>
+__device__ __forceinline__ float pvs_tile_scale_blocks(const float (&v)[HB][16], float* inv) {
+    float m = pvs_absmax16(v[0]);
+#pragma unroll
+    for (int b = 1; b < HB; ++b) m = fmaxf(m, pvs_absmax16(v[b]));
+    return pvs_f16_scale(pvs_wave_max_u32(__float_as_uint(m)), inv);
+}
+
+// largest |W[i]| of an n-element array as fp32 bits, over the whole workgroup (slot: one LDS word, zeroed
+// by the caller before a barrier; call from every thread, read *slot after the next barrier)
+__device__ __forceinline__ void pvs_block_absmax(const float* __restrict__ W, int n, unsigned* slot) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(W[i]));
+    const unsigned wm = pvs_wave_max_u32(__float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, wm);
 }
 
 template <typename K>

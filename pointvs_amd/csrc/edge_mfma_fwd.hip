@@ -18,8 +18,10 @@
 
 namespace {
 
-template <int HB, bool BF16X3, int NT = kThreads, bool SOFT = false>
-__global__ void __launch_bounds__(NT)
+// F16X2 (round 3): the two chain products as three-term fp16 products with tile scales (edge_mfma_common.h)
+// instead of six-term bf16 products: half the MFMAs, 2 instead of 5.5 VALU instructions per split value.
+template <int HB, bool BF16X3, int NT = kThreads, bool SOFT = false, bool F16X2 = false>
+__global__ void __launch_bounds__(NT, (F16X2 && HB == 1) ? 4 : (F16X2 && NT == 768) ? 3 : 1)
 k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdIO io, int n_chunks,
                 int e_lo, int e_hi) {
     constexpr int H = 32 * HB;
@@ -27,8 +29,9 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
     if (g.n_edges_dev) e_hi = min(e_hi, *g.n_edges_dev);   // edge count only known on the device
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NW = NT / 64;
-    constexpr int kBlkWords = 6 * 64 * 4;                 // one 32x32 block as bf16x3: 6 KB
-    constexpr int kWeightWords = BF16X3 ? 2 * HB * HB * kBlkWords : 2 * H * H;
+    static_assert(!(BF16X3 && F16X2), "one split scheme at a time");
+    constexpr int kBlkWords = F16X2 ? 4 * 64 * 4 : 6 * 64 * 4;      // one 32x32 block as f16x2: 4 KB, bf16x3: 6 KB
+    constexpr int kWeightWords = (BF16X3 || F16X2) ? 2 * HB * HB * kBlkWords + (F16X2 ? 4 : 0) : 2 * H * H;
     float* W2s = smem;
     float* Wc1s = W2s + H * H;
     float* b2t = smem + kWeightWords;
@@ -49,7 +52,19 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
     // BF16X3: each 32x32 block takes 3 parts x 2 k-steps x 64 lanes x 16 B = 6 KB
     unsigned* W2b = reinterpret_cast<unsigned*>(W2s);
     unsigned* Wc1b = W2b + HB * HB * kBlkWords;
-    if constexpr (BF16X3) {
+    float inv_sw2 = 1.f, inv_swc1 = 1.f;
+    if constexpr (F16X2) {
+        unsigned* wmax = Wc1b + HB * HB * kBlkWords;     // [0]: max |W2|, [1]: max |Wc1| (fp32 bits)
+        if (threadIdx.x < 4) wmax[threadIdx.x] = 0u;
+        __syncthreads();
+        pvs_block_absmax(w.w2, H * H, wmax);
+        if (upd) pvs_block_absmax(w.wc1, H * H, wmax + 1);
+        __syncthreads();
+        const float sw2 = pvs_f16_scale(wmax[0], &inv_sw2);
+        const float swc1 = pvs_f16_scale(wmax[1], &inv_swc1);
+        stage_weights_f16x2_blocks<HB>(W2b, w.w2, sw2);
+        if (upd) stage_weights_f16x2_blocks<HB>(Wc1b, w.wc1, swc1);
+    } else if constexpr (BF16X3) {
         stage_weights_bf16x3_blocks<HB>(W2b, w.w2);
         if (upd) stage_weights_bf16x3_blocks<HB>(Wc1b, w.wc1);
     } else {
@@ -150,17 +165,33 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
             {
                 f32x16 acc2[HB];
                 float bias[HB][16];
-                load_tab<HB>(b2t, hh, bias);
+                if constexpr (!F16X2) load_tab<HB>(b2t, hh, bias);
+                if constexpr (F16X2) {
+                    float inv_s;
+                    const float s_a = pvs_tile_scale_blocks<HB>(a1, &inv_s);
 #pragma unroll
-                for (int b = 0; b < HB; ++b)
+                    for (int b = 0; b < HB; ++b)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc2[b][r] = bias[b][r];
-                if constexpr (BF16X3) mfma_chain_bf16x3_blocks<HB>(W2b, lane, a1, acc2);
-                else mfma_chain<HB>(W2s, lane, a1, acc2, flags & kAblNoMfma);
+                        for (int r = 0; r < 16; ++r) acc2[b][r] = 0.f;
+                    mfma_chain_f16x2_blocks<HB>(W2b, lane, a1, s_a, acc2);
+                    load_tab<HB>(b2t, hh, bias);      // (after the chain: not live across it)
+                    const float k2 = inv_s * inv_sw2;
 #pragma unroll
-                for (int b = 0; b < HB; ++b)
+                    for (int b = 0; b < HB; ++b)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m[b][r] = pvs_silu(acc2[b][r]);
+                        for (int r = 0; r < 16; ++r) m[b][r] = pvs_silu(fmaf(acc2[b][r], k2, bias[b][r]));
+                } else {
+#pragma unroll
+                    for (int b = 0; b < HB; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc2[b][r] = bias[b][r];
+                    if constexpr (BF16X3) mfma_chain_bf16x3_blocks<HB>(W2b, lane, a1, acc2);
+                    else mfma_chain<HB>(W2s, lane, a1, acc2, flags & kAblNoMfma);
+#pragma unroll
+                    for (int b = 0; b < HB; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) m[b][r] = pvs_silu(acc2[b][r]);
+                }
             }
             if (eres) {
 #pragma unroll
@@ -190,18 +221,34 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
             if (upd) {
                 f32x16 accc[HB];
                 float bias[HB][16];
-                load_tab<HB>(bc1t, hh, bias);
-#pragma unroll
-                for (int b = 0; b < HB; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) accc[b][r] = bias[b][r];
-                if constexpr (BF16X3) mfma_chain_bf16x3_blocks<HB>(Wc1b, lane, m, accc);
-                else mfma_chain<HB>(Wc1s, lane, m, accc, flags & kAblNoMfma);
+                if constexpr (!F16X2) load_tab<HB>(bc1t, hh, bias);
                 float q[HB][16];
+                if constexpr (F16X2) {
+                    float inv_s;
+                    const float s_m = pvs_tile_scale_blocks<HB>(m, &inv_s);
 #pragma unroll
-                for (int b = 0; b < HB; ++b)
+                    for (int b = 0; b < HB; ++b)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) q[b][r] = pvs_silu(accc[b][r]);
+                        for (int r = 0; r < 16; ++r) accc[b][r] = 0.f;
+                    mfma_chain_f16x2_blocks<HB>(Wc1b, lane, m, s_m, accc);
+                    load_tab<HB>(bc1t, hh, bias);
+                    const float kc = inv_s * inv_swc1;
+#pragma unroll
+                    for (int b = 0; b < HB; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) q[b][r] = pvs_silu(fmaf(accc[b][r], kc, bias[b][r]));
+                } else {
+#pragma unroll
+                    for (int b = 0; b < HB; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) accc[b][r] = bias[b][r];
+                    if constexpr (BF16X3) mfma_chain_bf16x3_blocks<HB>(Wc1b, lane, m, accc);
+                    else mfma_chain<HB>(Wc1s, lane, m, accc, flags & kAblNoMfma);
+#pragma unroll
+                    for (int b = 0; b < HB; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) q[b][r] = pvs_silu(accc[b][r]);
+                }
                 s = dot_tab<HB>(wc2t, hh, q);
                 if (flags & PVS_TANH) s = pvs_tanh(s);
                 if (flags & PVS_NORMALIZE) s = s / (sqrtf(rho) + 1e-8f);
@@ -302,6 +349,10 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     const char* bf64 = getenv("PVS_EGNN_BF16X3_H64");
     // default: fp32 products as bf16x3 (PVS_EGNN_BF16X3=0: fp32 MFMAs; PVS_EGNN_BF16X3_H64=0: only for H = 64)
     const bool bf16x3 = !(bf && bf[0] == '0') && (H == 32 || !(bf64 && bf64[0] == '0'));
+    // round 3: the chain products as three-term fp16 products with tile scales (default);
+    // PVS_EGNN_F16X2=0 keeps the six-term bf16 products
+    const char* f16e = getenv("PVS_EGNN_F16X2");
+    const bool f16x2 = bf16x3 && !(f16e && f16e[0] == '0');
     // H = 64 bf16x3: 48 KB of weight operands, so one workgroup per CU: 768 threads = three waves per SIMD
     // (164-168 registers, no spills; forward kernel -5 % against two waves per SIMD) where the edge-class table
     // leaves room in the 160 KB of LDS (up to 3 classes: 512 bytes to spare), 512 threads otherwise
@@ -309,26 +360,35 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     const int nw = (HB == 2 && bf16x3) ? (attr_rows <= 3 ? 12 : 8) : kWaves;
     int blocks, n_chunks;
     pick_grid(g.n_edges, &blocks, &n_chunks, nw, nw >= 8 ? 256 : 1024);
-    const size_t words = (bf16x3 ? (size_t)2 * HB * HB * 6 * 64 * 4 : (size_t)2 * H * H) +
+    const size_t words = (f16x2 ? (size_t)2 * HB * HB * 4 * 64 * 4 + 4 : bf16x3 ? (size_t)2 * HB * HB * 6 * 64 * 4 : (size_t)2 * H * H) +
                          (5 + attr_rows) * H +
                          (size_t)nw * (kTile * (H + 4) + kTile * 4 + kTile);
     const size_t lds = words * sizeof(float);
     const bool soft = (flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT);
-#define PVS_FWD_LAUNCH(HBV, B3, NTV, SF)                                                             \
+#define PVS_FWD_LAUNCH(HBV, B3, NTV, SF, F16)                                                        \
     do {                                                                                            \
-        if (set_lds(k_edge_fwd_mfma<HBV, B3, NTV, SF>, lds)) return -2;                             \
-        k_edge_fwd_mfma<HBV, B3, NTV, SF><<<blocks, NTV, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges); \
+        if (set_lds(k_edge_fwd_mfma<HBV, B3, NTV, SF, F16>, lds)) return -2;                        \
+        k_edge_fwd_mfma<HBV, B3, NTV, SF, F16><<<blocks, NTV, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges); \
     } while (0)
-#define PVS_FWD_PICK(HBV, B3, NTV)                      \
-    do {                                               \
-        if (soft) PVS_FWD_LAUNCH(HBV, B3, NTV, true);  \
-        else PVS_FWD_LAUNCH(HBV, B3, NTV, false);      \
+#define PVS_FWD_PICK(HBV, B3, NTV)                             \
+    do {                                                      \
+        if (soft) PVS_FWD_LAUNCH(HBV, B3, NTV, true, false);  \
+        else PVS_FWD_LAUNCH(HBV, B3, NTV, false, false);      \
     } while (0)
-    if (HB == 2 && bf16x3 && nw == 12) PVS_FWD_PICK(2, true, 768);
+#define PVS_FWD_PICK16(HBV, NTV)                                \
+    do {                                                       \
+        if (soft) PVS_FWD_LAUNCH(HBV, false, NTV, true, true); \
+        else PVS_FWD_LAUNCH(HBV, false, NTV, false, true);     \
+    } while (0)
+    if (HB == 2 && f16x2 && nw == 12) PVS_FWD_PICK16(2, 768);
+    else if (HB == 2 && f16x2) PVS_FWD_PICK16(2, 512);
+    else if (HB == 1 && f16x2) PVS_FWD_PICK16(1, kThreads);
+    else if (HB == 2 && bf16x3 && nw == 12) PVS_FWD_PICK(2, true, 768);
     else if (HB == 2 && bf16x3) PVS_FWD_PICK(2, true, 512);
     else if (HB == 1 && bf16x3) PVS_FWD_PICK(1, true, kThreads);
     else if (HB == 1) PVS_FWD_PICK(1, false, kThreads);
     else PVS_FWD_PICK(2, false, kThreads);
+#undef PVS_FWD_PICK16
 #undef PVS_FWD_PICK
 #undef PVS_FWD_LAUNCH
     PVS_CHECK_LAUNCH();
