@@ -73,6 +73,13 @@ typedef struct PvsGraph {
      * by pvs_graph_filter_ligand_edges); n_edges is then the capacity of the edge arrays. Only
      * pvs_egnn_layer_edge_sums / _fwd_partial accept such a graph. */
     const int32_t* n_edges_dev;
+    /* Optional DEVICE int32 [n_graphs + 1]: first sorted edge of every graph of the batch (graphs are
+     * contiguous node ranges, so contiguous edge ranges of the CSR), last entry = E; NULL / 0 when unknown.
+     * Speed and values of the reference are unaffected by it; the fp16-split edge backward uses it to end its
+     * 32-edge tiles at graph boundaries, because one tile shares one power-of-two scale and two graphs'
+     * gradients can differ by many orders of magnitude ("f16x2"). */
+    const int32_t* graph_eptr;
+    int32_t n_graphs;
 } PvsGraph;
 
 /* Parameters of one EGNNLayer, torch nn.Linear layout W[out][in] (state_dict keys in comments). */

@@ -27,7 +27,8 @@ class PvsGraph(C.Structure):
     _fields_ = [('n_nodes', C.c_int32), ('n_edges', C.c_int32), ('rowptr', C.c_void_p),
                 ('row', C.c_void_p), ('col', C.c_void_p), ('etype', C.c_void_p),
                 ('perm', C.c_void_p), ('colptr', C.c_void_p), ('cedge', C.c_void_p),
-                ('inv_deg', C.c_void_p), ('n_edges_dev', C.c_void_p)]
+                ('inv_deg', C.c_void_p), ('n_edges_dev', C.c_void_p), ('graph_eptr', C.c_void_p),
+                ('n_graphs', C.c_int32)]
 
 
 class PvsLayerParams(C.Structure):

@@ -204,10 +204,29 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             acc = make_float4(0.f, 0.f, 0.f, 0.f);
             accx = acc;
         };
-        TileIdx I = load_tile_idx(g, w.n_attr, e_begin, e_begin, e_end, j);
-        for (int e0 = e_begin; e0 < e_end; e0 += kTile) {
-            const int e_next = (e0 + kTile < e_end) ? e0 + kTile : e0;
-            const TileIdx In = load_tile_idx(g, w.n_attr, e_next, e_begin, e_end, j);
+        // A tile shares ONE power-of-two scale per operand, and two graphs' gradients can differ by many orders of
+        // magnitude (a saturated loss), so a tile ends where a graph ends (PvsGraph.graph_eptr, when the caller knows
+        // the batch's graphs): gb = the first graph boundary behind the current tile's start.
+        int gk = 0, gb = e_hi;
+        if (g.graph_eptr) {
+            int lo = 0, hi = g.n_graphs;                // last k with graph_eptr[k] <= e_begin
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (g.graph_eptr[mid] <= e_begin) lo = mid; else hi = mid;
+            }
+            gk = lo + 1;
+            gb = g.graph_eptr[gk];
+        }
+        auto tile_end = [&](int start, int bound) { return min(min(start + kTile, e_end), bound > start ? bound : e_end); };
+        int t_end = tile_end(e_begin, gb);
+        TileIdx I = load_tile_idx(g, w.n_attr, e_begin, e_begin, t_end, j);
+        for (int e0 = e_begin; e0 < e_end;) {
+            const int e_this_end = t_end;
+            // the next tile: starts where this one ends; past a graph boundary the next boundary applies
+            if (g.graph_eptr) while (gk < g.n_graphs && gb <= e_this_end) { ++gk; gb = g.graph_eptr[gk]; }   // (empty graphs repeat a boundary)
+            const int e_next = e_this_end < e_end ? e_this_end : e0;
+            const int n_end = e_this_end < e_end ? tile_end(e_this_end, gb) : e_this_end;
+            const TileIdx In = load_tile_idx(g, w.n_attr, e_next, e_begin, n_end, j);
             const int e = I.e, ee = I.ee, i = I.i, ty = I.ty;
             const bool valid = I.valid;
             const float vm = valid ? 1.f : 0.f;
@@ -429,10 +448,12 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             pvs_wave_lds_sync();
             reduce_rows_tile<1>(T1, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
                                 [&](int rl, int q, const float4& v) {
-                                    if (e0 + rl < e_end)   // streamed once: non-temporal
+                                    if (e0 + rl < e_this_end)   // streamed once: non-temporal
                                         pvs_store_nt(io.gz1 + (size_t)(e0 + rl) * H + 4 * q, v);
                                 });
             I = In;
+            e0 = e_this_end;
+            t_end = n_end;
             pvs_wave_lds_sync();
         }
         flush(cur_row);

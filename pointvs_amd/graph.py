@@ -88,6 +88,18 @@ class PreparedGraph:
     def perm(self):
         return self.t['perm']
 
+    def set_graph_ptr(self, node_ptr):
+        """node_ptr: device int tensor [B + 1] of the batch's node offsets (PyG `ptr`). Records where each
+        graph's edges start in the sorted list (PvsGraph.graph_eptr): the fp16-split edge backward ends its
+        tiles there. One small device gather, no host sync; optional (a batch of one graph needs none)."""
+        if node_ptr is None or node_ptr.numel() <= 2 or self.c.graph_eptr:
+            return
+        idx = node_ptr.to(device=self.t['rowptr'].device, dtype=torch.long)
+        eptr = self.t['rowptr'].index_select(0, idx).contiguous()
+        self.t['graph_eptr'] = eptr
+        self.c.graph_eptr = _lib.ptr(eptr)
+        self.c.n_graphs = int(eptr.numel()) - 1
+
     def poll_status(self):
         """Asynchronous validation: the first call queues a D2H copy of the status word, later
         calls (or check_status) raise once it has landed. Never blocks the stream."""

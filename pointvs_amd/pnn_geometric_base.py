@@ -46,6 +46,7 @@ class PNNGeometricBase(PointNeuralNetworkBase):
         if pg is None:
             pg = prepared_for(edges, edge_attributes, n_nodes, layout=runs_layout(graph, feats.device))
         pg.poll_status()
+        pg.set_graph_ptr(graph_ptr)
         feats, _, _ = self.embed_prepared(pg, feats, coords, need_coords=False)
         return feats, pg, graph_ptr, n_graphs
 

@@ -770,3 +770,59 @@ def test_results_do_not_depend_on_stale_memory(family):
     rec = soak.soak_family(family, soak.FAMILIES[family], repeats=3, n_graphs=2, log=lambda *_: None)
     assert rec['tensors_hashed'] > 10
     assert not rec['tensors_with_more_than_one_hash'], rec
+
+
+@pytest.mark.parametrize('hid,flags', [(32, dict()), (32, dict(edge_attention=True, tanh=True)),
+                                       (32, dict(edge_residual=True, normalize=True)),
+                                       (64, dict()), (64, dict(edge_attention=True, node_attention=True))])
+def test_upstream_gradients_spanning_many_binades(hid, flags):
+    """The fp16-split products carry one power-of-two scale per operand and 32-edge tile (edge_mfma_common.h,
+    "f16x2"). Here the graphs of one batch receive upstream gradients of 1, 1e-18, 1e+12 and 1e-24 (a saturated BCE
+    loss does that: sigmoid'(37) ~ 1e-16): every graph's input gradients must be as accurate RELATIVE TO THAT
+    GRAPH'S OWN magnitude as fp32 allows - the scales follow the tiles down and up, and no tile mixes two graphs
+    (PvsGraph.graph_eptr) - and the weight gradients, sums over all graphs dominated by the largest, relative to
+    theirs. Oracle: autograd on the fp64 layer."""
+    from oracle import egnn_oracle as orc
+    from pointvs_amd.egnn_satorras import EGNNLayer
+    from pointvs_amd.graph import Batch
+    from pointvs_amd.synthetic import synthetic_graph
+    torch.manual_seed(3)
+    layer = EGNNLayer(hid, hid, hid, edges_in_d=3, **flags).cuda()
+    items = [synthetic_graph(700 + k, n_nodes=260, n_lig=12, edge_radius=6.0) for k in range(4)]
+    g = Batch.from_data_list(items)
+    n = g.x.shape[0]
+    scales = torch.tensor([1.0, 1e-18, 1e12, 1e-24], dtype=torch.float64)[g.batch]
+    rng = np.random.default_rng(2)
+    h0 = torch.from_numpy(rng.normal(size=(n, hid)).astype(np.float32))
+    wh = torch.from_numpy(rng.normal(size=(n, hid))) * scales[:, None]
+    wx = torch.from_numpy(rng.normal(size=(n, 3))) * scales[:, None]
+
+    from pointvs_amd.graph import prepared_for
+    h = h0.cuda().requires_grad_(True)
+    x = g.pos.cuda().requires_grad_(True)
+    pg = prepared_for(g.edge_index.cuda(), g.edge_attr.cuda(), n)
+    pg.set_graph_ptr(g.ptr.cuda())          # as the models do: tiles of the fp16-split backward end at graph ends
+    h1, x1, _ = layer.forward_prepared(pg, h, x)
+    ((h1 * wh.float().cuda()).sum() + (x1 * wx.float().cuda()).sum()).backward()
+
+    sd = {'L.' + k: v.detach().cpu().double().requires_grad_(True) for k, v in layer.state_dict().items()}
+    kw = dict(orc.BUILD_NET_DEFAULTS, residual=True, normalize=False, tanh=False, graphnorm=False)
+    kw.update(flags)
+    kw['edge_attention_here'] = kw['edge_attention']
+    kw['node_attention_here'] = kw['node_attention']
+    hr = h0.double().requires_grad_(True)
+    xr = g.pos.double().requires_grad_(True)
+    h2, x2, _, _, _ = orc.egnn_layer(sd, 'L.', kw, hr, g.edge_index, xr, g.edge_attr, None)
+    ((h2 * wh.float().double()).sum() + (x2 * wx.float().double()).sum()).backward()
+
+    def graph_rel(a, b):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        return float(np.abs(a - b).max() / np.abs(b).max())
+    for gid in range(4):
+        rows = (g.batch == gid).numpy()
+        assert graph_rel(h.grad.cpu().numpy()[rows], hr.grad.numpy()[rows]) < 2e-5, ('g_h', gid)
+        assert graph_rel(x.grad.cpu().numpy()[rows], xr.grad.numpy()[rows]) < 2e-5, ('g_x', gid)
+    for name, p in layer.named_parameters():
+        ref = sd['L.' + name].grad.numpy()
+        assert np.isfinite(p.grad.cpu().numpy()).all(), name
+        assert graph_rel(p.grad.cpu().numpy(), ref) < 2e-5, name
