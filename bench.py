@@ -48,12 +48,15 @@ FP32_PEAK_TFLOPS = 157.3   # fp32 vector = fp32 MFMA peak
 
 
 # what "dtype": "f32" means on this path: inputs, outputs, every accumulation and all
-# elementwise work are fp32; the per-edge matrix products run on the bf16 matrix pipe with each fp32 operand
-# split exactly into three bf16 parts and six partial products accumulated in fp32 (error O(2^-25 |a||b|),
-# below fp32 rounding; parity at 1e-5 relative against the fp64 oracle at BASELINE size is part of the GPU suite)
-ARITHMETIC = ('fp32 I/O, accumulation and elementwise work; per-edge matrix products as 6-term bf16x3 splits of '
-              'the fp32 operands on the bf16 matrix pipe with fp32 accumulation (no fp32 MFMA, no reduced-precision '
-              'storage); node-level products likewise')
+# elementwise work are fp32; the matrix products run on the 16-bit matrix pipes with each fp32 operand split into
+# exact parts - three bf16 parts and six partial products (error O(2^-25 |a||b|)), or, round 3, two fp16 parts
+# under a per-tile power-of-two scale and three partial products (O(2^-22 |a||b|), between bf16x3 and a sequential
+# fp32 FMA chain: tools/f16x2_numerics.py) - accumulated in fp32; parity at 1e-5 relative against the fp64 oracle
+# at BASELINE size is part of the GPU suite
+ARITHMETIC = ('fp32 I/O, accumulation and elementwise work; per-edge matrix products on the matrix cores with fp32 '
+              'accumulation and fp32-exact operand splits (no fp32 MFMA, no reduced-precision storage): H=32 forward and '
+              'backward and H=64 forward as 3-term fp16 splits (two fp16 parts per operand, 22 bits, one power-of-two '
+              'scale per 32-edge tile), H=64 backward and the node-level products as 6-term bf16x3 splits')
 
 
 def scaling_note(args, world, strong):
@@ -602,8 +605,10 @@ def main():
             dom_ms, dom_n = bwd_ms, bwd_n
             dom_bytes = algorithmic_bytes_edge_bwd(n_nodes, n_edges, h)
             dom_flops = (12.0 * h * h + 4 * h) * n_edges     # 2 recompute + 2 dgrad + 2 wgrad products
-            dom_symbol = (('k_edge_bwd_bf16' if os.environ.get('PVS_BWD32') != '0' and not cfg['model'].get('edge_residual')
-                           else 'k_edge_bwd_mfma') if h == 32
+            b32 = os.environ.get('PVS_BWD32', '')
+            eres_att = cfg['model'].get('edge_residual') and cfg['model'].get('edge_attention')
+            dom_symbol = (('k_edge_bwd_mfma' if b32[:1] == '0' or (b32[:1] == 'b' and eres_att) else
+                           'k_edge_bwd_bf16' if b32[:1] == 'b' else 'k_edge_bwd_f16') if h == 32
                           else ('k_edge_bwd_h64' if os.environ.get('PVS_BWD64') != '0' else 'k_edge_bwd_team_parts'))
             dom_name = (f'{dom_symbol} (H={h} edge backward, one launch per layer)')
             step_bytes = layers * algorithmic_bytes_per_layer(n_nodes, n_edges, h)

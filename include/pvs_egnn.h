@@ -191,6 +191,19 @@ int pvs_radius_graph_fill(const uint8_t* bp, const int32_t* graph_ptr, int32_t n
 int pvs_graph_min_label_step(const int32_t* rowptr, const int32_t* col, int32_t n_nodes, int32_t* labels,
                              int32_t* changed, pvs_stream_t stream);
 
+/* Edge dropout of SartorrasEGNN.get_embeddings (egnn_satorras.py:320-323: torch_geometric's
+ * dropout_adj(edges, edge_attr, p, force_undirected=True, training)): of every pair only the copy with
+ * row <= col is drawn (kept with probability 1 - p), the survivors' reverses are appended, attributes repeated.
+ * Philox4x32-10 keyed on (seed, step), counter = edge id: reproducible, not bit-matched to torch's generator.
+ * _mark: pos [E + 1] = exclusive scan of the keep flags (pos[E] = number of survivors K, read it on the host);
+ * _fill: out_index int64 [2][2K], out_attr int64 [2K][A]. */
+size_t pvs_dropout_adj_workspace_bytes(int32_t n_edges);
+int pvs_dropout_adj_mark(const int64_t* edge_index, int32_t n_edges, float p, uint64_t seed, uint64_t step,
+                         int32_t* pos, void* workspace, size_t workspace_bytes, pvs_stream_t stream);
+int pvs_dropout_adj_fill(const int64_t* edge_index, const int64_t* edge_attr, int32_t n_edge_attr,
+                         int32_t n_edges, const int32_t* pos, int32_t n_kept, int64_t* out_index,
+                         int64_t* out_attr, pvs_stream_t stream);
+
 /* dst[perm[e], :] = src[e, :]  (sorted -> input edge order), width floats per row.
  * Gives EGNNLayer.forward's 4th return value `edge_feat` and `att_val` in the reference's order. */
 int pvs_rows_to_input_order(const float* src, float* dst, const int32_t* perm, int32_t n_edges,

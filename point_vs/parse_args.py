@@ -124,8 +124,6 @@ def unsupported_in_use(args):
     bad = []
     if args.double:
         bad.append('--double (the HIP kernels are fp32)')
-    if args.dropout and args.dropout > 0:
-        bad.append('--dropout > 0 (dropout_adj, SURVEY.md §8a Q7)')
     if args.model == 'lucid':
         bad.append('model lucid (outside the hot path)')
     if args.include_strain_info:

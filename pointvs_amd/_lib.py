@@ -57,6 +57,11 @@ _PROTOTYPES = {
                               [C.c_void_p] * 10 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     'pvs_graph_min_label_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                            C.c_void_p]),
+    'pvs_dropout_adj_workspace_bytes': (C.c_size_t, [C.c_int32]),
+    'pvs_dropout_adj_mark': (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    'pvs_dropout_adj_fill': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     'pvs_rows_to_input_order': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                           C.c_void_p]),
     'pvs_rows_to_sorted_order': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,

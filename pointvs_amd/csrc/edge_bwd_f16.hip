@@ -184,8 +184,9 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 
     const int total_waves = gridDim.x * NW;
     for (int chunk = pvs_xcd_block(blockIdx.x, gridDim.x) * NW + wv; chunk < n_chunks; chunk += total_waves) {
-        const int e_begin = chunk_begin(g, chunk, n_chunks, e_lo, e_hi);
-        const int e_end = chunk_begin(g, chunk + 1, n_chunks, e_lo, e_hi);
+        // (wave-uniform values that come out of global loads: into scalar registers, the vector file is full)
+        const int e_begin = __builtin_amdgcn_readfirstlane(chunk_begin(g, chunk, n_chunks, e_lo, e_hi));
+        const int e_end = __builtin_amdgcn_readfirstlane(chunk_begin(g, chunk + 1, n_chunks, e_lo, e_hi));
         int cur_row = -1;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accx = acc;   // open row: lane = (row slot, quad)
         constexpr int QPR = H / 4;
@@ -212,23 +213,31 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             int lo = 0, hi = g.n_graphs;                // last k with graph_eptr[k] <= e_begin
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
-                if (g.graph_eptr[mid] <= e_begin) lo = mid; else hi = mid;
+                if (__builtin_amdgcn_readfirstlane(g.graph_eptr[mid]) <= e_begin) lo = mid; else hi = mid;
             }
             gk = lo + 1;
-            gb = g.graph_eptr[gk];
+            gb = __builtin_amdgcn_readfirstlane(g.graph_eptr[gk]);
         }
         auto tile_end = [&](int start, int bound) { return min(min(start + kTile, e_end), bound > start ? bound : e_end); };
         int t_end = tile_end(e_begin, gb);
-        TileIdx I = load_tile_idx(g, w.n_attr, e_begin, e_begin, t_end, j);
+        // only what comes out of memory is carried from tile to tile (4 registers); e / ee / valid are recomputed
+        struct Loaded { int i, jn, ty, prev_row; };
+        auto load_idx = [&](int start, int end) {
+            const TileIdx t = load_tile_idx(g, w.n_attr, start, e_begin, end, j);
+            return Loaded{t.i, t.jn, t.ty, t.prev_row};
+        };
+        Loaded I = load_idx(e_begin, t_end);
         for (int e0 = e_begin; e0 < e_end;) {
             const int e_this_end = t_end;
             // the next tile: starts where this one ends; past a graph boundary the next boundary applies
-            if (g.graph_eptr) while (gk < g.n_graphs && gb <= e_this_end) { ++gk; gb = g.graph_eptr[gk]; }   // (empty graphs repeat a boundary)
+            if (g.graph_eptr)    // (empty graphs repeat a boundary)
+                while (gk < g.n_graphs && gb <= e_this_end) { ++gk; gb = __builtin_amdgcn_readfirstlane(g.graph_eptr[gk]); }
             const int e_next = e_this_end < e_end ? e_this_end : e0;
             const int n_end = e_this_end < e_end ? tile_end(e_this_end, gb) : e_this_end;
-            const TileIdx In = load_tile_idx(g, w.n_attr, e_next, e_begin, n_end, j);
-            const int e = I.e, ee = I.ee, i = I.i, ty = I.ty;
-            const bool valid = I.valid;
+            const Loaded In = load_idx(e_next, n_end);
+            const int e = e0 + j, i = I.i, ty = I.ty;
+            const bool valid = e < e_this_end;
+            const int ee = min(max(valid ? e : e_this_end - 1, 0), g.n_edges - 1);   // (as load_tile_idx clamps)
             const float vm = valid ? 1.f : 0.f;
             const unsigned bmask = (unsigned)__ballot(valid && hh == 0 && i != I.prev_row);
             float d0, d1, d2, rho;
@@ -239,7 +248,9 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             float z2[16];
             {
                 TileGather<1> G;
-                gather_tile<1>(io.PQ, io.x, I, hh, G);
+                TileIdx Ig;
+                Ig.i = I.i; Ig.jn = I.jn;
+                gather_tile<1>(io.PQ, io.x, Ig, hh, G);
                 d0 = G.d0; d1 = G.d1; d2 = G.d2;
                 rho = d0 * d0 + d1 * d1 + d2 * d2;
                 float a1[1][16];

@@ -32,8 +32,8 @@ class MultitaskSatorrasEGNN(SartorrasEGNN):
                   gated_residual=False, rezero=False, model_task='classification',
                   final_softplus=False, softmax_attention=False, **kwargs):
         assert not (gated_residual and rezero), 'gated_residual and rezero are incompatible'
-        if dropout and dropout > 0:
-            raise NotImplementedError('dropout_adj (dropout > 0) is outside the HIP path')
+        if not 0.0 <= float(dropout or 0.0) < 1.0:
+            raise ValueError(f'dropout must be in [0, 1), got {dropout}')
         self.n_layers = num_layers
         self.dropout_p = dropout
         self.residual, self.edge_residual = residual, edge_residual

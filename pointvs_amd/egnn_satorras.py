@@ -413,9 +413,8 @@ class SartorrasEGNN(PNNGeometricBase):
                   rezero=False, model_task='classification', include_strain_info=False,
                   final_softplus=False, softmax_attention=False, **kwargs):
         assert not (gated_residual and rezero), 'gated_residual and rezero are incompatible'
-        if dropout and dropout > 0:
-            raise NotImplementedError('dropout_adj (dropout > 0) is outside the HIP path '
-                                      '(SURVEY.md §8a Q7)')
+        if not 0.0 <= float(dropout or 0.0) < 1.0:
+            raise ValueError(f'dropout must be in [0, 1), got {dropout}')
         self.n_layers = num_layers
         self.dropout_p = dropout
         self.residual, self.edge_residual = residual, edge_residual
@@ -445,6 +444,19 @@ class SartorrasEGNN(PNNGeometricBase):
         self.feats_linear_layers = nn.Sequential(*head)
         return nn.Sequential(*layers)
 
+    def edge_dropout(self, edges, edge_attributes):
+        """egnn_satorras.py:320-323: dropout_adj(edges, edge_attributes, dropout, force_undirected=True,
+        training=self.training) ahead of the layer stack; identity when dropout == 0 or in eval mode. The draw
+        is keyed on (torch.initial_seed(), calls so far): reproducible under torch.manual_seed, not torch's
+        stream (no parity vectors). Edge messages come back in the order of the DROPPED edge list,
+        as in the reference."""
+        p = float(getattr(self, 'dropout_p', 0.0) or 0.0)
+        if p == 0.0 or not self.training:
+            return edges, edge_attributes
+        self._dropout_calls = getattr(self, '_dropout_calls', 0) + 1
+        return PF.dropout_adj(edges, edge_attributes, p, force_undirected=True, training=True,
+                              seed=torch.initial_seed(), step=self._dropout_calls)
+
     def embed_prepared(self, pg, feats, coords, need_messages=False, trace=None, need_coords=True):
         """Layer stack on a PreparedGraph. Edge messages stay in sorted order between layers and
         are only materialised where a consumer exists (edge_residual, or need_messages).
@@ -469,6 +481,7 @@ class SartorrasEGNN(PNNGeometricBase):
     def get_embeddings(self, feats, edges, coords, edge_attributes, batch):
         """Reference signature (egnn_satorras.py:319-329): returns (feats, edge_messages) with
         edge_messages in the caller's edge order."""
+        edges, edge_attributes = self.edge_dropout(edges, edge_attributes)
         pg = prepared_for(edges, edge_attributes, feats.size(0))
         feats, _, m_sorted = self.embed_prepared(pg, feats, coords, need_messages=True, need_coords=False)
         edge_messages = None if m_sorted is None else PF.rows_to_input_order(m_sorted, pg)

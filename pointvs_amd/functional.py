@@ -260,3 +260,38 @@ class _SegmentReduceFn(torch.autograd.Function):
 
 def segment_reduce(data, segment_ids, num_segments, mean=False):
     return _SegmentReduceFn.apply(data, segment_ids, int(num_segments), bool(mean))
+
+
+def dropout_adj(edge_index, edge_attr=None, p=0.5, force_undirected=True, training=True, seed=0, step=0):
+    """torch_geometric's dropout_adj as the reference calls it (egnn_satorras.py:320-323: force_undirected=True):
+    of every pair only the row <= col copy is drawn, survivors first, their reverses behind, attributes
+    repeated. Identity when not training or p == 0. The draw is the library's own counter-based stream
+    (pvs_dropout_adj_mark: Philox keyed on (seed, step)), reproducible but not torch's. One host read (the
+    number of survivors sizes the outputs), like every data-dependent filter."""
+    if not training or not p:
+        return edge_index, edge_attr
+    if not force_undirected:
+        raise NotImplementedError('the reference only calls dropout_adj with force_undirected=True')
+    _lib.require_hip(edge_index, edge_attr)
+    lib = _lib.lib()
+    edge_index = edge_index.long().contiguous()
+    n_edges = int(edge_index.shape[1])
+    dev = edge_index.device
+    n_attr = 0
+    if edge_attr is not None:
+        edge_attr = edge_attr.long().contiguous()
+        n_attr = int(edge_attr.shape[1])
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    pos = torch.empty(n_edges + 1, dtype=torch.int32, device=dev)
+    ws_bytes = lib.pvs_dropout_adj_workspace_bytes(n_edges)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.pvs_dropout_adj_mark(_lib.ptr(edge_index), n_edges, float(p), int(seed) & (2 ** 64 - 1),
+                                        int(step), _lib.ptr(pos), _lib.ptr(ws), ws_bytes, stream),
+               'pvs_dropout_adj_mark')
+    kept = int(pos[-1])
+    out_index = torch.empty((2, 2 * kept), dtype=torch.int64, device=dev)
+    out_attr = None if edge_attr is None else torch.empty((2 * kept, n_attr), dtype=torch.int64, device=dev)
+    _lib.check(lib.pvs_dropout_adj_fill(_lib.ptr(edge_index), _lib.ptr(edge_attr), n_attr, n_edges, _lib.ptr(pos),
+                                        kept, _lib.ptr(out_index), _lib.ptr(out_attr), stream),
+               'pvs_dropout_adj_fill')
+    return out_index, out_attr

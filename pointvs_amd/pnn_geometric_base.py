@@ -43,7 +43,16 @@ class PNNGeometricBase(PointNeuralNetworkBase):
             ptr = torch.cat([counts.new_zeros(1), counts.cumsum(0)])
         graph_ptr = ptr.to(device=feats.device, dtype=torch.int32).contiguous()
         pg = getattr(graph, 'prepared', None)     # built on the GPU (radius_graph.attach_radius_graph)
-        if pg is None:
+        dropping = self.training and float(getattr(self, 'dropout_p', 0.0) or 0.0) > 0.0
+        if dropping:      # edge dropout ahead of the layer stack (egnn_satorras.py:320-323): a new edge list
+            if pg is not None:    # graph built on the GPU: its sorted list back as the COO the dropout draws from
+                e = pg.n_edges
+                edges = torch.stack([pg.t['row'][:e].long(), pg.t['col'][:e].long()])
+                edge_attributes = (None if pg.n_edge_attr == 0 else
+                                   torch.nn.functional.one_hot(pg.t['etype'][:e].long(), pg.n_edge_attr))
+            edges, edge_attributes = self.edge_dropout(edges, edge_attributes)
+            pg = prepared_for(edges, edge_attributes, n_nodes)
+        elif pg is None:
             pg = prepared_for(edges, edge_attributes, n_nodes, layout=runs_layout(graph, feats.device))
         pg.poll_status()
         pg.set_graph_ptr(graph_ptr)

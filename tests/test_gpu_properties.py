@@ -826,3 +826,61 @@ def test_upstream_gradients_spanning_many_binades(hid, flags):
         ref = sd['L.' + name].grad.numpy()
         assert np.isfinite(p.grad.cpu().numpy()).all(), name
         assert graph_rel(p.grad.cpu().numpy(), ref) < 2e-5, name
+
+
+def test_edge_dropout_drops_both_directions_of_a_pair_together():
+    """dropout_adj(force_undirected=True) as SartorrasEGNN.get_embeddings applies it (egnn_satorras.py:320-323):
+    survivors are drawn among the row <= col copies only, their reverses are appended with the same attributes,
+    the kept fraction is 1 - p, p = 0 / eval are the identity, and the draw is a function of (seed, step).
+    (Semantics restated from torch_geometric 2.0.4; the random stream is the library's own: no parity vectors.)"""
+    from pointvs_amd import functional as PF
+    from pointvs_amd.graph import Batch
+    from pointvs_amd.synthetic import synthetic_graph
+    g = Batch.from_data_list([synthetic_graph(60 + k, n_nodes=400, n_lig=20, edge_radius=6.0) for k in range(3)]).to('cuda')
+    ei, ea = g.edge_index, g.edge_attr
+    same_i, same_a = PF.dropout_adj(ei, ea, 0.0, training=True)
+    assert same_i is ei and same_a is ea
+    same_i, _ = PF.dropout_adj(ei, ea, 0.4, training=False)
+    assert same_i is ei
+    p = 0.3
+    oi, oa = PF.dropout_adj(ei, ea, p, training=True, seed=5, step=1)
+    oi2, oa2 = PF.dropout_adj(ei, ea, p, training=True, seed=5, step=1)
+    oi3, _ = PF.dropout_adj(ei, ea, p, training=True, seed=5, step=2)
+    assert torch.equal(oi, oi2) and torch.equal(oa, oa2)
+    assert oi.shape != oi3.shape or not torch.equal(oi, oi3)
+    k = oi.shape[1] // 2
+    assert oi.shape[1] == 2 * k and oa.shape == (2 * k, 3)
+    # second half = the reverses of the first half, attributes repeated
+    assert torch.equal(oi[0, :k], oi[1, k:]) and torch.equal(oi[1, :k], oi[0, k:]) and torch.equal(oa[:k], oa[k:])
+    assert bool((oi[0, :k] <= oi[1, :k]).all())
+    # survivors are input edges with their own attributes, in input order (a subsequence of the row <= col copies)
+    cand = (ei[0] <= ei[1]).nonzero().reshape(-1)
+    n = int(g.x.shape[0])
+    key_in = (ei[0, cand] * n + ei[1, cand]) * 4 + ea[cand].argmax(1)
+    key_out = (oi[0, :k] * n + oi[1, :k]) * 4 + oa[:k].argmax(1)
+    it = iter(key_in.tolist())
+    assert all(any(v == w for w in it) for v in key_out.tolist()), 'survivors are not a subsequence of the input'
+    frac = k / cand.numel()
+    assert abs(frac - (1 - p)) < 4 * np.sqrt(p * (1 - p) / cand.numel()) + 1e-3, frac
+
+
+def test_model_with_edge_dropout_trains_and_is_the_plain_model_in_eval():
+    """dropout > 0 no longer raises: in training mode every forward draws a new edge subset (different losses for
+    different steps, same for the same (seed, step)), gradients are finite; in eval mode the model is the plain one."""
+    from pointvs_amd.graph import Batch
+    from pointvs_amd.synthetic import synthetic_graph
+    g = Batch.from_data_list([synthetic_graph(80 + k, n_nodes=300, n_lig=16, edge_radius=6.0) for k in range(2)])
+    plain, _ = make_model(seed=4, num_layers=2, residual=True)
+    drop, _ = make_model(seed=4, num_layers=2, residual=True, dropout=0.25)
+    y_plain, _ = gpu_run(plain, g)
+    y_eval, _ = gpu_run(drop, g)                   # make_model returns .eval()
+    assert np.array_equal(y_plain, y_eval)
+    drop.train()
+    torch.manual_seed(9)
+    drop._dropout_calls = 0
+    y1, g1 = gpu_run(drop, g)
+    y2, _ = gpu_run(drop, g)
+    drop._dropout_calls = 0
+    y1b, _ = gpu_run(drop, g)
+    assert np.array_equal(y1, y1b) and not np.array_equal(y1, y2) and not np.array_equal(y1, y_plain)
+    assert all(np.isfinite(v).all() for v in g1.values() if v is not None)
