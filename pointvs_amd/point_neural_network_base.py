@@ -183,8 +183,8 @@ class PointNeuralNetworkBase(nn.Module):
         the reference's line format. The loop never waits for the host: scores leave the device
         through pinned buffers and a writer thread formats and appends them every `log_interval`
         batches, as the reference's write_predictions does (pointvs_amd/predictions.py).
-        Returns True like the reference (top-1 / Pearson model selection is analysis code outside
-        the path)."""
+        top1_on_end: the reference's model selection on the finished file (top-1 / Pearson); returns
+        False only when `only_save_best_models` is set and this epoch is not the best so far."""
         from .predictions import PredictionsWriter, merge_rank_files, rank_part
         predictions_file = Path(predictions_file or self.predictions_file)
         predictions_file = (predictions_file.parent /
@@ -208,7 +208,21 @@ class PointNeuralNetworkBase(nn.Module):
                 merge_rank_files(predictions_file, world)
             torch.distributed.barrier()         # nobody reads the file before it is whole
         self.last_predictions_file = predictions_file
-        return True
+        if not top1_on_end:
+            return True
+        # model selection (:330-360): top-1 over receptors for pose models, Pearson's r (p < 0.05) for affinity
+        # models, against the best value so far; every rank reads the same joined file and decides alike
+        from .predictions import regression_pearson, top_n
+        if self.model_task == 'classification':
+            metric = top_n(predictions_file)
+            best = metric > self.test_metric
+        else:
+            metric, p_value = regression_pearson(predictions_file)
+            best = bool(p_value < 0.05 and metric > self.test_metric)
+        if best:
+            self.test_metric = float(metric)
+        self.last_validation_metric = float(metric)
+        return bool(best or not self.only_save_best_models)
 
     def save(self, save_path=None):
         """Checkpoint in the reference's format (:501-517). Data parallel: weights and optimiser state

@@ -69,6 +69,37 @@ def merge_rank_files(path, world):
     tmp.replace(path)
 
 
+def read_predictions(path):
+    """Rows of a labelled predictions file: (y_true, y_pred, receptor, ligand[, metric])."""
+    rows = []
+    for line in Path(path).read_text().splitlines():
+        parts = line.split()
+        if len(parts) >= 5 and parts[1] == '|':
+            rows.append((float(parts[0]), float(parts[2]), parts[3], parts[4]) + tuple(parts[6:7]))
+    return rows
+
+
+def top_n(path, n=1):
+    """Fraction of receptors with an active among their n best-scored poses: the reference's model-selection
+    metric for pose models (/root/reference/point_vs/analysis/top_n.py:32-49, used by val(): poses grouped by
+    receptor, sorted by predicted score, descending)."""
+    by_rec = {}
+    for y_true, y_pred, rec, _lig, *_ in read_predictions(path):
+        by_rec.setdefault(rec, []).append((y_pred, int(y_true)))
+    if not by_rec:
+        return 0.0
+    hits = sum(1 for poses in by_rec.values()
+               if sum(label for _, label in sorted(poses, key=lambda t: t[0], reverse=True)[:n]))
+    return hits / len(by_rec)
+
+
+def regression_pearson(path):
+    """(r, p) of predicted against true affinities: /root/reference/point_vs/utils.py:189-198."""
+    from scipy.stats import pearsonr
+    rows = read_predictions(path)
+    return pearsonr([r[0] for r in rows], [r[1] for r in rows])
+
+
 class PredictionsWriter:
     """with PredictionsWriter(path, task) as w:  w.submit(y_pred_device, y_true, receptors, ligands)"""
 

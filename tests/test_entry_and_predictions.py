@@ -8,6 +8,7 @@ import sys
 from pathlib import Path
 
 import numpy as np
+import pytest
 import torch
 
 GOLDEN = Path(__file__).resolve().parent / 'golden'
@@ -101,3 +102,22 @@ def test_bench_launcher_parent_never_loads_torch_and_counts_gpus_from_sysfs(tmp_
     monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,2')
     assert bench.visible_gpu_count(tmp_path) == 2
     assert bench.visible_gpu_count(tmp_path / 'absent') is None
+
+
+def test_model_selection_metrics_follow_the_reference(tmp_path):
+    """val()'s top1_on_end: top-n over receptors (analysis/top_n.py:32-49) and Pearson's r of the affinity file
+    (utils.py:189-198) on predictions files in the reference's line format."""
+    from scipy.stats import pearsonr
+    from pointvs_amd.predictions import regression_pearson, top_n
+    pose = tmp_path / 'pose_predictions.txt'
+    pose.write_text('\n'.join([
+        '1.000 | 0.900 recA ligA_0', '0.000 | 0.950 recA ligA_1', '0.000 | 0.100 recA ligA_2',     # best pose is a decoy
+        '1.000 | 0.700 recB ligB_0', '0.000 | 0.200 recB ligB_1',                                 # best pose is active
+        '0.000 | 0.300 recC ligC_0', '0.000 | 0.600 recC ligC_1']) + '\n')                        # no active at all
+    assert top_n(pose) == pytest.approx(1 / 3) and top_n(pose, n=2) == pytest.approx(2 / 3)
+    aff = tmp_path / 'affinity_predictions.txt'
+    y = np.array([4.1, 5.0, 6.2, 7.7, 5.5, 8.1]); yp = np.array([4.5, 4.9, 6.0, 7.0, 6.1, 7.9])
+    aff.write_text('\n'.join(f'{a:.3f} | {b:.3f} rec lig{i}' for i, (a, b) in enumerate(zip(y, yp))) + '\n')
+    r, p = regression_pearson(aff)
+    r0, p0 = pearsonr(y, yp)
+    assert r == pytest.approx(r0, abs=1e-3) and p < 0.05 and p0 < 0.05

@@ -118,6 +118,9 @@ def soak_family(name, changes, repeats, n_graphs, states=('clean', 'nan', 'garba
     cache = pgraph.CACHE_ENABLED
     pgraph.CACHE_ENABLED = False               # every repeat prepares its graph afresh, like a training step
     try:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()   # (the poison covers THIS family's peak, not an earlier one's)
         one_repeat(model, batch)               # warm-up (lazy allocations, module loading)
         torch.cuda.synchronize()
         reserve = int(torch.cuda.max_memory_allocated() * 1.25) + (256 << 20)
