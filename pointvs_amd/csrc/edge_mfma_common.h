@@ -532,6 +532,22 @@ __device__ __forceinline__ unsigned pvs_f16_lo2(float x0, float x1, float s, uns
     return l;
 }
 
+// The same two words from conversions instead of v_fma_mixlo/hi_f16. Measured on MI355X
+// (tools/micro/valu_issue_bench.hip, profiles/r03_micro_valu_issue.txt; SIMD cycles per wave-instruction at two
+// or more waves per SIMD): v_fma_mixlo/hi_f16 8.4-8.9 - a quarter-rate instruction like v_exp_f32 - against
+// v_mul_f32 2.5, v_cvt_pk_f16_f32 4.6, v_fma_mix_f32 4.3: 33.5 cycles per pair of values for the four mixlo/hi
+// against 22.9 for  y = x s (2 x v_mul, exact: s is a power of two), h = cvt_pk(y0, y1) (round to nearest even,
+// the rounding of mixlo), r = y - f32(h half) (v_fma_mix_f32: exact, the difference has at most 13 significant
+// bits), l = cvt_pk(r0, r1). Bit for bit the words of pvs_f16_hi2 / pvs_f16_lo2.
+__device__ __forceinline__ void pvs_f16_split2(float x0, float x1, float s, unsigned& h, unsigned& l) {
+    const float y0 = x0 * s, y1 = x1 * s;
+    float r0, r1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(y0), "v"(y1));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(y0), "v"(h));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(y1), "v"(h));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(r0), "v"(r1));
+}
+
 __device__ __forceinline__ void split_f16x2(const float (&v)[16], float s, F16Parts& out) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -541,8 +557,12 @@ __device__ __forceinline__ void split_f16x2(const float (&v)[16], float s, F16Pa
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float x0 = v[8 * ks + 2 * q], x1 = v[8 * ks + 2 * q + 1];
+#ifdef PVS_SPLIT_MIXLO
             h[q] = pvs_f16_hi2(x0, x1, s);
             l[q] = pvs_f16_lo2(x0, x1, s, h[q]);
+#else
+            pvs_f16_split2(x0, x1, s, h[q], l[q]);
+#endif
         }
         out.hi[ks] = __builtin_bit_cast(f16x8, ph);
         out.lo[ks] = __builtin_bit_cast(f16x8, pl);
