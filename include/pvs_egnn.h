@@ -144,13 +144,17 @@ int pvs_graph_prepare(const int64_t* edge_index, const int64_t* edge_attr, int32
  * row-sorted runs, and PyG collation (data_loaders.py:517-520) concatenates the graphs. node_ptr / edge_ptr
  * [n_graphs + 1] (DEVICE int32) give each graph's node and edge ranges. The layout is the caller's
  * contract; it is verified on the device and a violation sets bit 4 of *status (bits 1, 2 as in
- * pvs_graph_prepare). Outputs are array-for-array those of pvs_graph_prepare. */
-size_t pvs_graph_prepare_runs_workspace_bytes(int32_t n_nodes, int32_t n_edges, int32_t n_graphs);
+ * pvs_graph_prepare). Outputs are array-for-array those of pvs_graph_prepare.
+ * max_graph_nodes: an upper bound on the nodes of one graph, known to the caller (0 = unknown). With a bound of
+ * at most 4096 the by-column lists are built by a counting transpose per graph (LDS tables over the graph's own
+ * columns) instead of a radix sort of all edges by column; same arrays. A graph larger than the bound sets bit 4. */
+size_t pvs_graph_prepare_runs_workspace_bytes(int32_t n_nodes, int32_t n_edges, int32_t n_graphs,
+                                              int32_t max_graph_nodes);
 int pvs_graph_prepare_runs(const int64_t* edge_index, const int64_t* edge_attr, int32_t n_edge_attr,
                            int32_t n_nodes, int32_t n_edges, int32_t n_graphs, const int32_t* node_ptr,
                            const int32_t* edge_ptr, int32_t* rowptr, int32_t* row, int32_t* col, uint8_t* etype,
                            int32_t* perm, int32_t* colptr, int32_t* cedge, float* inv_deg, int32_t* status,
-                           void* workspace, size_t workspace_bytes, pvs_stream_t stream);
+                           int32_t max_graph_nodes, void* workspace, size_t workspace_bytes, pvs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Radius graph straight from coordinates: generate_edges of the reference

@@ -45,9 +45,9 @@ _PROTOTYPES = {
     'pvs_graph_prepare_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32]),
     'pvs_graph_prepare': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] +
                           [C.c_void_p] * 9 + [C.c_void_p, C.c_size_t, C.c_void_p]),
-    'pvs_graph_prepare_runs_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    'pvs_graph_prepare_runs_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'pvs_graph_prepare_runs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32] +
-                               [C.c_void_p] * 11 + [C.c_void_p, C.c_size_t, C.c_void_p]),
+                               [C.c_void_p] * 11 + [C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     'pvs_radius_graph_state_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     'pvs_radius_graph_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     'pvs_radius_graph_count': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

@@ -290,14 +290,170 @@ __global__ void k_place_runs(const int32_t* __restrict__ row32, const int32_t* _
     perm[pos] = e;
 }
 
+
+// ---- by-column lists of a batch of disjoint graphs WITHOUT a sort ("counting transpose", round 3) ----------
+// cedge = the sorted positions grouped by column, ascending inside a column (what a stable sort by column of the
+// row-sorted list gives). The columns of a graph's edges lie inside the graph's node range (verified by
+// k_extract_runs), so a column has at most max_graph_nodes distinct keys RELATIVE to its graph: a counting sort
+// with one LDS table per wave. Every graph's positions are cut into `cpg` contiguous chunks, one wave per chunk:
+//   pass 1  counts the chunk's edges per column                       (cnt[chunk][column], LDS atomics: integer
+//           sums do not depend on their order)
+//   totals  in-degree per node = sum over the graph's chunks, exclusive scan -> colptr
+//   bases   cnt[chunk][column] <- colptr[column] + edges of that column in EARLIER chunks of the graph
+//   pass 2  walks the chunk in position order, 64 positions per step: slot = running count of the column, which
+//           starts at the chunk's base. Two lanes of one step with the same column (duplicate edges, two rows in one
+//           step) take consecutive slots in LANE order - found by a byte table of "who wrote this column last" and
+//           resolved group by group with ballots, so the order never depends on how the LDS serialises a conflict.
+// Array for array the radix sort's output (tests/test_gpu_properties.py), three launches + one scan instead of a
+// two-pass pair sort over 10 M pairs.
+constexpr int kCscMaxCols = 4096;         // nodes per graph this path handles (one 16 KB + 4 KB table pair per wave)
+constexpr int kCscWaves = 4;              // waves per workgroup
+constexpr int kCscTargetChunks = 2048;    // waves in flight per pass (8 per CU)
+
+struct CscChunk { int begin, end, node_lo, width, g; };
+
+__device__ __forceinline__ CscChunk csc_chunk(int wid, int cpg, int stride, int n_graphs,
+                                              const int32_t* __restrict__ node_ptr,
+                                              const int32_t* __restrict__ edge_ptr) {
+    CscChunk c;
+    c.g = wid / cpg;
+    const int k = wid - c.g * cpg;
+    if (c.g >= n_graphs) { c.begin = c.end = 0; c.node_lo = 0; c.width = 0; return c; }
+    const int e0 = edge_ptr[c.g], e1 = edge_ptr[c.g + 1];
+    const int len = (((e1 - e0) + cpg - 1) / cpg + 63) & ~63;
+    c.begin = min(e0 + k * len, e1);
+    c.end = min(c.begin + len, e1);
+    c.node_lo = node_ptr[c.g];
+    c.width = node_ptr[c.g + 1] - c.node_lo;      // (the caller clamps it to the table and flags a graph that does not fit)
+    return c;
+}
+
+template <bool PLACE>
+__global__ void __launch_bounds__(64 * kCscWaves)
+k_csc_pass(const int32_t* __restrict__ col, int n_graphs, const int32_t* __restrict__ node_ptr,
+           const int32_t* __restrict__ edge_ptr, int cpg, int stride, int32_t* __restrict__ cnt,
+           int32_t* __restrict__ cedge, int32_t* __restrict__ status) {
+    extern __shared__ int32_t csc_lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wid = blockIdx.x * kCscWaves + wv;
+    CscChunk c = csc_chunk(wid, cpg, stride, n_graphs, node_ptr, edge_ptr);
+    if (c.width > stride) {        // a graph larger than the caller's bound: contract violation, stay inside the table
+        if (lane == 0) atomicOr(status, 4);
+        c.width = stride;
+    }
+    if (c.width <= 0) return;
+    int32_t* tab = csc_lds + wv * (stride + stride / 4);
+    unsigned char* tag = reinterpret_cast<unsigned char*>(tab + stride);
+    int32_t* mine = cnt + (size_t)wid * stride;
+    for (int i = lane; i < c.width; i += 64) tab[i] = PLACE ? mine[i] : 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int p0 = c.begin; p0 < c.end; p0 += 64) {
+        const int p = p0 + lane;
+        const bool live = p < c.end;
+        // (a broken layout contract leaves columns outside the graph's range: clamped, so that every table access
+        // and every cedge slot stays in bounds; the host raises on the status word)
+        const int key = live ? min(max(col[p] - c.node_lo, 0), c.width - 1) : 0;
+        if (!PLACE) {
+            if (live) atomicAdd(&tab[key], 1);
+            continue;
+        }
+        // lanes of this step that share a column: leader = the lowest lane, rank = lanes of the group below me
+        int leader = lane, rank = 0, members = 1;
+        if (live) tag[key] = (unsigned char)lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool lost = live && tag[key] != (unsigned char)lane;
+        unsigned long long pending = __ballot(lost);
+        while (pending) {
+            const int l0 = __builtin_ctzll(pending);
+            const int k0 = __builtin_amdgcn_readlane(key, l0);
+            const unsigned long long grp = __ballot(live && key == k0);
+            if (live && key == k0) {
+                leader = __builtin_ctzll(grp);
+                rank = __popcll(grp & ((1ull << lane) - 1ull));
+                members = __popcll(grp);
+            }
+            pending &= ~grp;
+        }
+        int slot = 0;
+        if (live && rank == 0) {       // one lane per distinct column: no two lanes touch one counter
+            slot = tab[key];
+            tab[key] = slot + members;
+        }
+        slot = __shfl(slot, leader, 64) + rank;
+        if (live) cedge[slot] = p;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (!PLACE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int i = lane; i < c.width; i += 64) mine[i] = tab[i];
+    }
+}
+
+__device__ __forceinline__ int csc_graph_of_node(const int32_t* __restrict__ node_ptr, int n_graphs, int n) {
+    int lo = 0, hi = n_graphs;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (node_ptr[mid] <= n) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// indeg[n] = edges whose column is n (sum over the chunks of n's graph); indeg[N] = 0
+__global__ void k_csc_totals(const int32_t* __restrict__ cnt, int N, int n_graphs, const int32_t* __restrict__ node_ptr,
+                             int cpg, int stride, int32_t* __restrict__ indeg) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n > N) return;
+    if (n == N) { indeg[N] = 0; return; }
+    const int g = csc_graph_of_node(node_ptr, n_graphs, n);
+    const int c = n - node_ptr[g];
+    int tot = 0;
+    if (c < stride)
+        for (int k = 0; k < cpg; ++k) tot += cnt[((size_t)g * cpg + k) * stride + c];
+    indeg[n] = tot;
+}
+
+// cnt[chunk][column] <- first cedge slot of that column's edges in that chunk
+__global__ void k_csc_bases(int32_t* __restrict__ cnt, int N, int n_graphs, const int32_t* __restrict__ node_ptr,
+                            int cpg, int stride, const int32_t* __restrict__ colptr) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int g = csc_graph_of_node(node_ptr, n_graphs, n);
+    const int c = n - node_ptr[g];
+    if (c >= stride) return;
+    int run = colptr[n];
+    for (int k = 0; k < cpg; ++k) {
+        int32_t* slot = cnt + ((size_t)g * cpg + k) * stride + c;
+        const int t = *slot;
+        *slot = run;
+        run += t;
+    }
+}
+
+int csc_chunks_per_graph(int n_graphs) {
+    int cpg = kCscTargetChunks / (n_graphs > 0 ? n_graphs : 1);
+    if (cpg < 1) cpg = 1;
+    if (cpg > 128) cpg = 128;
+    return cpg;
+}
+int csc_stride(int max_graph_nodes) { return (max_graph_nodes + 63) & ~63; }
+bool csc_counting_ok(int max_graph_nodes) { return max_graph_nodes > 0 && max_graph_nodes <= kCscMaxCols; }
+
 struct RunsWs {
-    int32_t *row32, *col32, *iota, *keys_tmp, *split, *start_a, *start_b, *cnt_a, *deg;
+    int32_t *row32, *col32, *iota, *keys_tmp, *split, *start_a, *start_b, *cnt_a, *deg, *csc_cnt, *indeg;
     uint8_t* etype_in;
     void *sort_tmp, *scan_tmp;
     size_t sort_bytes, scan_bytes;
 };
 
-size_t carve_runs(PvsArena& a, int N, int E, int B, RunsWs* w) {
+size_t carve_runs(PvsArena& a, int N, int E, int B, int max_graph_nodes, RunsWs* w) {
     const size_t e = (size_t)(E > 0 ? E : 1);
     RunsWs t;
     t.row32 = a.take<int32_t>(e);
@@ -315,31 +471,40 @@ size_t carve_runs(PvsArena& a, int N, int E, int B, RunsWs* w) {
     t.scan_bytes = 0;
     hipcub::DeviceScan::ExclusiveSum(nullptr, t.scan_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, N + 1, 0);
     t.scan_tmp = a.take<char>(t.scan_bytes);
+    t.csc_cnt = nullptr;
+    t.indeg = nullptr;
+    if (csc_counting_ok(max_graph_nodes)) {
+        t.csc_cnt = a.take<int32_t>((size_t)B * csc_chunks_per_graph(B) * csc_stride(max_graph_nodes));
+        t.indeg = a.take<int32_t>((size_t)N + 1);
+    }
     if (w) *w = t;
     return a.off;
 }
 
 }  // namespace
 
-extern "C" size_t pvs_graph_prepare_runs_workspace_bytes(int32_t n_nodes, int32_t n_edges, int32_t n_graphs) {
+extern "C" size_t pvs_graph_prepare_runs_workspace_bytes(int32_t n_nodes, int32_t n_edges, int32_t n_graphs,
+                                                         int32_t max_graph_nodes) {
     PvsArena a(nullptr, 0);
-    return carve_runs(a, n_nodes, n_edges, n_graphs, nullptr) + 256;
+    return carve_runs(a, n_nodes, n_edges, n_graphs, max_graph_nodes, nullptr) + 256;
 }
 
 extern "C" int pvs_graph_prepare_runs(const int64_t* edge_index, const int64_t* edge_attr, int32_t n_edge_attr,
                                       int32_t N, int32_t E, int32_t n_graphs, const int32_t* node_ptr,
                                       const int32_t* edge_ptr, int32_t* rowptr, int32_t* row, int32_t* col,
                                       uint8_t* etype, int32_t* perm, int32_t* colptr, int32_t* cedge, float* inv_deg,
-                                      int32_t* status, void* workspace, size_t workspace_bytes, pvs_stream_t stream_) {
+                                      int32_t* status, int32_t max_graph_nodes, void* workspace,
+                                      size_t workspace_bytes, pvs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     PVS_REQUIRE(N > 0 && E >= 0 && n_graphs > 0, "pvs_graph_prepare_runs: bad sizes N=%d E=%d B=%d", N, E, n_graphs);
+    PVS_REQUIRE(max_graph_nodes >= 0, "pvs_graph_prepare_runs: bad max_graph_nodes %d", max_graph_nodes);
     PVS_REQUIRE(n_edge_attr >= 0 && n_edge_attr <= 255, "pvs_graph_prepare_runs: bad n_edge_attr %d", n_edge_attr);
     PVS_REQUIRE(n_edge_attr == 0 || (edge_attr && etype), "pvs_graph_prepare_runs: edge_attr/etype NULL");
     PVS_REQUIRE(node_ptr && edge_ptr, "pvs_graph_prepare_runs: node_ptr / edge_ptr NULL");
     PVS_REQUIRE((colptr == nullptr) == (cedge == nullptr), "pvs_graph_prepare_runs: colptr and cedge go together");
     PvsArena arena(workspace, workspace_bytes);
     RunsWs w;
-    carve_runs(arena, N, E, n_graphs, &w);
+    carve_runs(arena, N, E, n_graphs, max_graph_nodes, &w);
     PVS_REQUIRE(arena.ok(), "pvs_graph_prepare_runs: workspace too small (%zu < %zu)", workspace_bytes, arena.off);
     PvsProfScope prof(stream, PVS_PROF_PREPARE);
     PVS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), stream));
@@ -361,17 +526,46 @@ extern "C" int pvs_graph_prepare_runs(const int64_t* edge_index, const int64_t* 
                                                         rowptr, w.start_a, w.start_b, w.cnt_a, row, col,
                                                         n_edge_attr ? etype : nullptr, perm, status);
         PVS_CHECK_LAUNCH();
-        if (cedge) {   // by-column lists: only the backward reads them
-            size_t tb = w.sort_bytes;
-            const int bits = key_bits(N > 1 ? N : 2);
-            PVS_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(w.sort_tmp, tb, col, w.keys_tmp, w.iota, cedge, E, 0,
-                                                             bits, stream));
+    }
+    if (!cedge) return 0;
+    // by-column lists: only the backward reads them
+    static const bool force_sort = [] { const char* e = getenv("PVS_CSC_SORT"); return e && e[0] == '1'; }();
+    if (w.csc_cnt && !force_sort) {      // counting transpose (the caller bounds the graphs' sizes)
+        const int cpg = csc_chunks_per_graph(n_graphs), stride = csc_stride(max_graph_nodes);
+        const int waves = n_graphs * cpg, blocks = (waves + kCscWaves - 1) / kCscWaves;
+        const size_t lds = (size_t)kCscWaves * (stride + stride / 4) * sizeof(int32_t);
+        if (lds > 48 * 1024) {
+            PVS_CHECK_HIP(hipFuncSetAttribute((const void*)k_csc_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            PVS_CHECK_HIP(hipFuncSetAttribute((const void*)k_csc_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
-    }
-    if (cedge) {
-        k_lower_bounds<<<(N + 1 + T - 1) / T, T, 0, stream>>>(w.keys_tmp, E, N, colptr, nullptr);
+        if (E > 0) {
+            k_csc_pass<false><<<blocks, 64 * kCscWaves, lds, stream>>>(col, n_graphs, node_ptr, edge_ptr, cpg, stride,
+                                                                        w.csc_cnt, nullptr, status);
+            PVS_CHECK_LAUNCH();
+        } else {
+            PVS_CHECK_HIP(hipMemsetAsync(w.csc_cnt, 0, (size_t)waves * stride * sizeof(int32_t), stream));
+        }
+        k_csc_totals<<<(N + 1 + T - 1) / T, T, 0, stream>>>(w.csc_cnt, N, n_graphs, node_ptr, cpg, stride, w.indeg);
         PVS_CHECK_LAUNCH();
+        sb = w.scan_bytes;
+        PVS_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(w.scan_tmp, sb, w.indeg, colptr, N + 1, stream));
+        if (E > 0) {
+            k_csc_bases<<<(N + T - 1) / T, T, 0, stream>>>(w.csc_cnt, N, n_graphs, node_ptr, cpg, stride, colptr);
+            PVS_CHECK_LAUNCH();
+            k_csc_pass<true><<<blocks, 64 * kCscWaves, lds, stream>>>(col, n_graphs, node_ptr, edge_ptr, cpg, stride,
+                                                                       w.csc_cnt, cedge, status);
+            PVS_CHECK_LAUNCH();
+        }
+        return 0;
     }
+    if (E > 0) {
+        size_t tb = w.sort_bytes;
+        const int bits = key_bits(N > 1 ? N : 2);
+        PVS_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(w.sort_tmp, tb, col, w.keys_tmp, w.iota, cedge, E, 0,
+                                                         bits, stream));
+    }
+    k_lower_bounds<<<(N + 1 + T - 1) / T, T, 0, stream>>>(w.keys_tmp, E, N, colptr, nullptr);
+    PVS_CHECK_LAUNCH();
     return 0;
 }
 

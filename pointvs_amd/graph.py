@@ -167,6 +167,8 @@ def runs_layout(graph, device=None):
     edge_ptr = torch.tensor([0] + list(counts), dtype=torch.int64).cumsum(0).to(dtype=torch.int32)
     node_ptr = torch.tensor([0] + list(nodes), dtype=torch.int64).cumsum(0).to(dtype=torch.int32)
     layout = (node_ptr.to(dev, non_blocking=True), edge_ptr.to(dev, non_blocking=True))
+    # (host knowledge the device pass can use: with a bound on the graphs' sizes the by-column lists need no sort)
+    layout[0].max_graph_nodes = int(max(nodes))
     graph._runs_layout = layout + ((n_edges, graph.edge_index.data_ptr()),)
     return layout
 
@@ -213,11 +215,12 @@ def prepare_graph(edge_index, edge_attr, n_nodes, need_backward=None, layout=Non
     if layout is not None and n_edges > 0 and int(layout[0].numel()) == int(layout[1].numel()) >= 2:
         node_ptr, edge_ptr = layout
         n_graphs = int(node_ptr.numel()) - 1
-        ws_bytes = lib.pvs_graph_prepare_runs_workspace_bytes(n_nodes, n_edges, n_graphs)
+        max_nodes = int(getattr(node_ptr, 'max_graph_nodes', 0)) if need_backward else 0
+        ws_bytes = lib.pvs_graph_prepare_runs_workspace_bytes(n_nodes, n_edges, n_graphs, max_nodes)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         rc = lib.pvs_graph_prepare_runs(
             _lib.ptr(edge_index), _lib.ptr(edge_attr), n_attr, n_nodes, n_edges, n_graphs, _lib.ptr(node_ptr),
-            _lib.ptr(edge_ptr), *outputs, _lib.ptr(ws), ws_bytes, stream)
+            _lib.ptr(edge_ptr), *outputs, max_nodes, _lib.ptr(ws), ws_bytes, stream)
         _lib.check(rc, 'pvs_graph_prepare_runs')
         t['_layout'] = layout      # (keeps the pointer tables alive until the kernels have run)
     else:

@@ -759,6 +759,36 @@ def test_prepare_by_merging_sorted_runs_equals_the_sort():
         pg.check_status()
 
 
+@pytest.mark.parametrize('sizes', [
+    [(2000, 30, 10.0)],                                             # one BASELINE-size graph: 128 chunks of it
+    [(2000, 30, 10.0), (1500, 25, 10.0), (2000, 30, 8.0), (700, 10, 10.0)],
+    [(64, 8, 20.0)] * 70,                                           # many small complete graphs: chunks < one row
+    [(4096, 30, 4.0), (100, 5, 5.0)],                               # the largest graph the counting path takes
+    [(4500, 30, 4.0), (100, 5, 5.0)],                               # one node more than that: the radix sort
+])
+def test_by_column_lists_by_counting_equal_the_sort(sizes):
+    """Round 3: with a host bound on the graphs' sizes pvs_graph_prepare_runs builds colptr / cedge by a counting
+    transpose per graph (graph_prepare.hip, k_csc_pass) instead of a radix sort of all edges by column. Same arrays
+    as the sort (stable: ascending sorted position inside a column, duplicate edges included), whatever the chunking."""
+    from pointvs_amd.graph import Batch, prepare_graph, runs_layout
+    from pointvs_amd.synthetic import synthetic_graph
+    items = [synthetic_graph(900 + k, n_nodes=n, n_lig=nl, edge_radius=r) for k, (n, nl, r) in enumerate(sizes)]
+    batch = Batch.from_data_list(items).to('cuda')
+    layout = runs_layout(batch)
+    assert layout[0].max_graph_nodes == max(s[0] for s in sizes)
+    n = int(batch.x.shape[0])
+    a = prepare_graph(batch.edge_index, batch.edge_attr, n, need_backward=True, layout=layout)
+    b = prepare_graph(batch.edge_index, batch.edge_attr, n, need_backward=True)
+    a.check_status(); b.check_status()
+    for name in ('rowptr', 'row', 'col', 'etype', 'perm', 'colptr', 'cedge'):
+        assert torch.equal(a.t[name], b.t[name]), name
+    # the definition, independent of either implementation
+    col = a.t['col'].cpu().numpy().astype(np.int64)
+    order = np.argsort(col, kind='stable')
+    assert np.array_equal(a.t['cedge'].cpu().numpy(), order)
+    assert np.array_equal(a.t['colptr'].cpu().numpy(), np.searchsorted(col[order], np.arange(n + 1)))
+
+
 @pytest.mark.parametrize('family', ['default', 'h32_att', 'h32_edgeres_att', 'h64_att', 'generic_h16'])
 def test_results_do_not_depend_on_stale_memory(family):
     """A result that changes with the bytes the allocator happens to hand out is a read of memory this step
