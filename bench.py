@@ -605,11 +605,9 @@ def main():
             dom_ms, dom_n = bwd_ms, bwd_n
             dom_bytes = algorithmic_bytes_edge_bwd(n_nodes, n_edges, h)
             dom_flops = (12.0 * h * h + 4 * h) * n_edges     # 2 recompute + 2 dgrad + 2 wgrad products
-            b32 = os.environ.get('PVS_BWD32', '')
-            eres_att = cfg['model'].get('edge_residual') and cfg['model'].get('edge_attention')
-            dom_symbol = (('k_edge_bwd_mfma' if b32[:1] == '0' or (b32[:1] == 'b' and eres_att) else
-                           'k_edge_bwd_bf16' if b32[:1] == 'b' else 'k_edge_bwd_f16') if h == 32
-                          else ('k_edge_bwd_h64' if os.environ.get('PVS_BWD64') != '0' else 'k_edge_bwd_team_parts'))
+            fp32_family = os.environ.get('PVS_EGNN_BF16X3') == '0'
+            dom_symbol = (('k_edge_bwd_mfma' if fp32_family else 'k_edge_bwd_f16') if h == 32
+                          else ('k_edge_bwd_team' if fp32_family else 'k_edge_bwd_h64'))
             dom_name = (f'{dom_symbol} (H={h} edge backward, one launch per layer)')
             step_bytes = layers * algorithmic_bytes_per_layer(n_nodes, n_edges, h)
         else:            # forward only: the edge forward

@@ -106,11 +106,14 @@ struct F16Cfg {
     static_assert(kTile * kTS * 4 + kTile * 16 + kTile * 4 <= 2 * kImg2 * 2, "g_z1 tile + tx + rowbuf must fit the m + gradient images");
 };
 
-template <bool ERES, bool EATT>
+// ERK: edge residual kind - 0 none; 1 the plain sum m + m_prev (nothing of the residual has to survive the tile's
+// coordinate branch); 2 rezero / gated (the gate's gradient needs the pre-residual message and m_prev at the end).
+template <int ERK, bool EATT>
 __global__ void __launch_bounds__(F16Cfg::kThreadsPerBlock, 2)
 k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks, int e_lo, int e_hi) {
     using Cfg = F16Cfg;
     constexpr int H = kH, NT = Cfg::kThreadsPerBlock, NW = Cfg::kWavesPerBlock;
+    constexpr bool ERES = ERK != 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short* W2i = reinterpret_cast<unsigned short*>(smem);         // hi, lo: [H][H] fp16 each
     unsigned short* Wc1i = W2i + kImg2;
@@ -166,7 +169,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 
     const float bac = EATT ? w.ba[0] : 0.f;
     float gate_raw = 0.f, gate = 1.f;
-    if (ERES && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
+    if (ERK == 2 && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
         gate_raw = w.edge_gate[0];
         gate = (flags & PVS_GATED_RESIDUAL) ? fmaxf(gate_raw, 0.f) : gate_raw;
     }
@@ -175,11 +178,16 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 
     // ---- accumulators that live for the whole kernel ----
     f32x16 gW2, gWc1;                          // D layout: [c = ch(r,hh)][k = j]
-    f32x16 gB;                                 // column 0: g_bc1, column 1: g_b2 (rows = channels, D layout)
+    // gB, D layout (rows = channels): column 0 = g_bc1, column 1 = g_b2 (ones-column products, wgrad_tile_f16). With
+    // edge attention the OTHER 30 columns' lanes carry the attention weight's gradient g_wa as per-lane partial sums
+    // (register r of lane (j, hh) is channel xch(r, hh) in the D layout and in the X layout alike, and the partial
+    // sums are added over the lanes at the end anyway): the contributions of edges 0 and 1 go to lanes 2 and 3
+    // through one DPP move. 16 kernel-lifetime registers less than a separate X-layout accumulator - what this
+    // instantiation was spilling.
+    f32x16 gB;
     float g_wc2x[16];                          // X layout (channel in the register, edges on lanes)
-    float g_wax[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { gB[r] = 0.f; g_wc2x[r] = 0.f; gW2[r] = 0.f; gWc1[r] = 0.f; g_wax[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { gB[r] = 0.f; g_wc2x[r] = 0.f; gW2[r] = 0.f; gWc1[r] = 0.f; }
     float g_ba = 0.f, g_gate = 0.f;
 
     const int total_waves = gridDim.x * NW;
@@ -282,18 +290,21 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 for (int r = 0; r < 16; ++r) z2[r] = fmaf(acc2[r], k2, bias[0][r]);
             }
             float dz2[16], m[1][16];          // SiLU'(z2) and the message
-            float m_new[ERES ? 16 : 1], mp[1][16];
+            float m_new[ERK == 2 ? 16 : 1], mp[1][16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float sg = pvs_sigmoid(z2[r]);
                 m[0][r] = z2[r] * sg;
                 dz2[r] = fmaf(m[0][r], 1.0f - sg, sg);
-                if constexpr (ERES) m_new[r] = m[0][r];
+                if constexpr (ERK == 2) m_new[r] = m[0][r];
             }
             if constexpr (ERES) {
                 load_x<1>(io.m_prev + (size_t)ee * H, hh, mp);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m[0][r] = fmaf(res_a, m_new[r], res_b * mp[0][r]);
+                for (int r = 0; r < 16; ++r) {
+                    if constexpr (ERK == 2) m[0][r] = fmaf(res_a, m_new[r], res_b * mp[0][r]);
+                    else m[0][r] += mp[0][r];
+                }
             }
 
             // ---- gradient wrt m: the coordinate branch's term comes from the matrix core first; the external,
@@ -304,6 +315,41 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             for (int r = 0; r < 16; ++r) gm[r] = 0.f;
             float gMi[1][16];
             auto load_row_terms = [&]() { load_x<1>(io.gM + (size_t)i * H, hh, gMi); };
+            // Edge attention: everything that needs the message itself - the logit, m . g_M, the gate's gradient g_l
+            // and its weight gradient g_wa += g_l m - is evaluated HERE, while m is live anyway; two scalars (the gate
+            // value and g_l) cross the coordinate branch and m dies with its split, as in the plain kernel. The g_M
+            // row is fetched a second time behind the branch (an L1 hit: a tile's edges share their row).
+            float att_v = 1.f, g_l = 0.f;
+            if constexpr (EATT) {
+                float logit = 0.f, dot = 0.f;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {       // (quad by quad: eight registers of operands at a time)
+                    const float4 gq4 = *reinterpret_cast<const float4*>(io.gM + (size_t)i * H + 8 * gq + 4 * hh);
+                    const float4 wq4 = *reinterpret_cast<const float4*>(wat + 8 * gq + 4 * hh);
+                    logit = fmaf(wq4.x, m[0][4 * gq], logit); dot = fmaf(m[0][4 * gq], gq4.x, dot);
+                    logit = fmaf(wq4.y, m[0][4 * gq + 1], logit); dot = fmaf(m[0][4 * gq + 1], gq4.y, dot);
+                    logit = fmaf(wq4.z, m[0][4 * gq + 2], logit); dot = fmaf(m[0][4 * gq + 2], gq4.z, dot);
+                    logit = fmaf(wq4.w, m[0][4 * gq + 3], logit); dot = fmaf(m[0][4 * gq + 3], gq4.w, dot);
+                }
+                logit += __shfl_xor(logit, 32, 64);
+                dot += __shfl_xor(dot, 32, 64);
+                logit += bac;
+                const float aval = io.att[ee];
+                g_l = (flags & PVS_SOFTMAX_ATT) ? aval * (dot - io.softD[i]) * vm   // softD = M_i . g_M_i
+                                                : pvs_att_act_grad(att_act, logit, aval) * dot * vm;
+                att_v = aval * vm;
+                if (hh == 0) g_ba += g_l;
+                const float g_own = j >= 2 ? g_l : 0.f;                    // this lane's own edge, columns 2..31
+                const float k_23 = (j == 2 || j == 3) ? 1.f : 0.f;         // lanes that also take edges 0 / 1
+                const float g_in = k_23 * __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g_l), 0x4E, 0xf, 0xf, true));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // m of lane j ^ 2 (quad_perm [2,3,0,1]); only lanes 2 and 3 use it (g_in is zero elsewhere)
+                    const float mt = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m[0][r]), 0x4E, 0xf, 0xf, true));
+                    gB[r] = fmaf(g_own, m[0][r], gB[r]);
+                    gB[r] = fmaf(g_in, mt, gB[r]);
+                }
+            }
             auto add_row_terms = [&]() {
                 if (io.g_m_out) {
                     float init[1][16];
@@ -314,24 +360,8 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 if constexpr (EATT) {
                     float wax[1][16];
                     load_tab<1>(wat, hh, wax);
-                    float logit = 0.f, dot = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        logit = fmaf(wax[0][r], m[0][r], logit);
-                        dot = fmaf(m[0][r], gMi[0][r], dot);
-                    }
-                    logit += __shfl_xor(logit, 32, 64);
-                    dot += __shfl_xor(dot, 32, 64);
-                    logit += bac;
-                    const float aval = io.att[ee];
-                    const float g_l = (flags & PVS_SOFTMAX_ATT) ? aval * (dot - io.softD[i]) * vm   // softD = M_i . g_M_i
-                                                                : pvs_att_act_grad(att_act, logit, aval) * dot * vm;
-                    if (hh == 0) g_ba += g_l;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        gm[r] += (aval * vm) * gMi[0][r] + g_l * wax[0][r];
-                        g_wax[r] = fmaf(g_l, m[0][r], g_wax[r]);
-                    }
+                    for (int r = 0; r < 16; ++r) gm[r] += att_v * gMi[0][r] + g_l * wax[0][r];
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) gm[r] = fmaf(vm, gMi[0][r], gm[r]);
@@ -398,7 +428,8 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             for (int r = 0; r < 16; ++r) {
                 const float gmv = gm[r];
                 float gnew = gmv;
-                if constexpr (ERES) {
+                if constexpr (ERK == 1) mp[0][r] = gmv;      // (plain sum: m_prev receives g_m as it is)
+                if constexpr (ERK == 2) {
                     if (flags & PVS_REZERO) {
                         gnew = gate * gmv;
                         g_gate = fmaf(gmv, m_new[r], g_gate);
@@ -484,9 +515,10 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
     };
 #pragma unroll
     for (int r = 0; r < 16; ++r) g_wc2x[r] = lanes32(g_wc2x[r]);
+    float g_wax[EATT ? 16 : 1];
     if constexpr (EATT) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g_wax[r] = lanes32(g_wax[r]);
+        for (int r = 0; r < 16; ++r) g_wax[r] = lanes32(j >= 2 ? gB[r] : 0.f);      // columns 2..31 of gB
     }
     g_ba += __shfl_xor(g_ba, 32, 64);          // only hh == 0 lanes accumulated
     g_ba = lanes32(g_ba);
@@ -556,10 +588,13 @@ int pvs_launch_edge_bwd_f16(hipStream_t s, int H, const PvsGraph& g, const PvsEd
         k_edge_bwd_f16<ER, EA><<<blocks, Cfg::kThreadsPerBlock, lds, s>>>(g, w, flags, att_act, io, n_chunks, \
                                                                           e_lo, e_hi);                   \
     } while (0)
-    if (eres && eatt) PVS_BWD_F16_LAUNCH(true, true);
-    else if (eres) PVS_BWD_F16_LAUNCH(true, false);
-    else if (eatt) PVS_BWD_F16_LAUNCH(false, true);
-    else PVS_BWD_F16_LAUNCH(false, false);
+    const bool gated = flags & (PVS_REZERO | PVS_GATED_RESIDUAL);
+    if (eres && gated && eatt) PVS_BWD_F16_LAUNCH(2, true);
+    else if (eres && gated) PVS_BWD_F16_LAUNCH(2, false);
+    else if (eres && eatt) PVS_BWD_F16_LAUNCH(1, true);
+    else if (eres) PVS_BWD_F16_LAUNCH(1, false);
+    else if (eatt) PVS_BWD_F16_LAUNCH(0, true);
+    else PVS_BWD_F16_LAUNCH(0, false);
 #undef PVS_BWD_F16_LAUNCH
     PVS_CHECK_LAUNCH();
     return 0;

@@ -298,10 +298,13 @@ __device__ __forceinline__ void reduce_rows16(const float* __restrict__ T, const
 #define H64_CHAIN(T, img, lane, v, acc) chain16<T>(img, lane, v, acc)
 #endif
 
-template <bool ERES, bool EATT>
+// ERK: edge residual kind - 0 none; 1 the plain sum m + m_prev (nothing of the residual has to survive the tile's
+// coordinate branch); 2 rezero / gated (the gate's gradient needs the pre-residual message and m_prev at the end).
+template <int ERK, bool EATT>
 __global__ void __launch_bounds__(256, 1)
 k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks, int e_lo, int e_hi) {
     constexpr int H = kH, NT = 256, NW = 4;
+    constexpr bool ERES = ERK != 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short* W2i = reinterpret_cast<unsigned short*>(smem);         // 3 parts x [H][H] bf16
     unsigned short* Wc1i = W2i + 3 * H * H;
@@ -340,7 +343,7 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 
     const float bac = EATT ? w.ba[0] : 0.f;
     float gate_raw = 0.f, gate = 1.f;
-    if (ERES && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
+    if (ERK == 2 && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
         gate_raw = w.edge_gate[0];
         gate = (flags & PVS_GATED_RESIDUAL) ? fmaxf(gate_raw, 0.f) : gate_raw;
     }
@@ -451,18 +454,21 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 H64_CHAIN(false, W2i, lane, pb, acc2);
             }
             float dz2[16], m[16];             // SiLU'(z2) and the message
-            float m_new[ERES ? 16 : 1];
+            float m_new[ERK == 2 ? 16 : 1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float z2 = acc2[r >> 2][r & 3];
                 const float sg = pvs_sigmoid(z2);
                 m[r] = z2 * sg;
                 dz2[r] = fmaf(m[r], 1.0f - sg, sg);
-                if constexpr (ERES) m_new[r] = m[r];
+                if constexpr (ERK == 2) m_new[r] = m[r];
             }
             if constexpr (ERES) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m[r] = fmaf(res_a, m_new[r], res_b * mp[r]);
+                for (int r = 0; r < 16; ++r) {
+                    if constexpr (ERK == 2) m[r] = fmaf(res_a, m_new[r], res_b * mp[r]);
+                    else m[r] += mp[r];
+                }
             }
 
             // ---- gradient wrt m: the coordinate branch's term first, then the external, aggregated-message
@@ -561,7 +567,8 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             for (int r = 0; r < 16; ++r) {
                 const float gmv = gm[r >> 2][r & 3];
                 float gnew = gmv;
-                if constexpr (ERES) {
+                if constexpr (ERK == 1) mp[r] = gmv;         // (plain sum: m_prev receives g_m as it is)
+                if constexpr (ERK == 2) {
                     if (flags & PVS_REZERO) {
                         gnew = gate * gmv;
                         g_gate = fmaf(gmv, m_new[r], g_gate);
@@ -717,10 +724,13 @@ int pvs_launch_edge_bwd_h64(hipStream_t s, const PvsGraph& g, const PvsEdgeW& w,
         if (set_lds(k_edge_bwd_h64<ER, EA>, lds)) return -2;                                           \
         k_edge_bwd_h64<ER, EA><<<blocks, 256, lds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi); \
     } while (0)
-    if (eres && eatt) PVS_BWD_H64_LAUNCH(true, true);
-    else if (eres) PVS_BWD_H64_LAUNCH(true, false);
-    else if (eatt) PVS_BWD_H64_LAUNCH(false, true);
-    else PVS_BWD_H64_LAUNCH(false, false);
+    const bool gated = flags & (PVS_REZERO | PVS_GATED_RESIDUAL);
+    if (eres && gated && eatt) PVS_BWD_H64_LAUNCH(2, true);
+    else if (eres && gated) PVS_BWD_H64_LAUNCH(2, false);
+    else if (eres && eatt) PVS_BWD_H64_LAUNCH(1, true);
+    else if (eres) PVS_BWD_H64_LAUNCH(1, false);
+    else if (eatt) PVS_BWD_H64_LAUNCH(0, true);
+    else PVS_BWD_H64_LAUNCH(0, false);
 #undef PVS_BWD_H64_LAUNCH
     PVS_CHECK_LAUNCH();
     return 0;

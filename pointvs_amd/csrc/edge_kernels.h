@@ -76,10 +76,6 @@ int pvs_edge_bwd_mfma_supported(int H, uint32_t flags, int n_attr);
 int pvs_edge_bwd_mfma_max_blocks(int H);
 int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,
                              int att_act, const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs);
-// H = 32 / 64 backward with all six products on the bf16 matrix pipe, one wave per tile (edge_bwd_bf16.hip);
-// same contract as pvs_launch_edge_bwd_mfma
-int pvs_launch_edge_bwd_bf16(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags, int att_act,
-                             const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs);
 // H = 32 backward with every product as three fp16 terms (f16x2 split with tile scales), both weight-gradient
 // operands through transposing LDS reads (edge_bwd_f16.hip, round 3); same contract
 int pvs_launch_edge_bwd_f16(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags, int att_act,

@@ -1075,543 +1075,6 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
 }
 
 
-// ====================================================================================================
-// H = 64, bf16x3 everywhere: the team of two waves exchanges its activations as the three bf16 PARTS
-// (one [32 edges][64 channels] image per part, same swizzle as the weight images) instead of fp32
-// tiles. Each wave splits only its own channel block (the partner's block arrives already split: row
-// reads give the chain products' B operands), and the two weight gradients are bf16x3 products over
-// the edge index whose A and B operands are transposing reads (ds_read_b64_tr_b16) of the same
-// images: 48 bf16 MFMAs per tile instead of 64 fp32 ones, no second split, and bf16 MFMAs co-execute
-// with VALU work where fp32 ones do not. Column sums (g_b2, g_bc1, g_wa) ride in X-layout registers.
-// 256 threads = 2 teams per block (122 KB of LDS, one block per CU, one wave per SIMD).
-constexpr int kPart64 = 32 * 64;     // bf16 elements of one part of a [32][64] tile
-
-__device__ __forceinline__ void write_parts64(unsigned short* __restrict__ tile, int j, int hh, int cb,
-                                              const Bf16Parts& p) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int o0 = img_off<2>(j, 32 * cb + 16 * s + 4 * hh), o1 = img_off<2>(j, 32 * cb + 16 * s + 8 + 4 * hh);
-        const uint4 h = __builtin_bit_cast(uint4, p.hi[s]);
-        const uint4 m = __builtin_bit_cast(uint4, p.mid[s]);
-        const uint4 l = __builtin_bit_cast(uint4, p.lo[s]);
-        *reinterpret_cast<uint2*>(tile + o0) = make_uint2(h.x, h.y);
-        *reinterpret_cast<uint2*>(tile + o1) = make_uint2(h.z, h.w);
-        *reinterpret_cast<uint2*>(tile + kPart64 + o0) = make_uint2(m.x, m.y);
-        *reinterpret_cast<uint2*>(tile + kPart64 + o1) = make_uint2(m.z, m.w);
-        *reinterpret_cast<uint2*>(tile + 2 * kPart64 + o0) = make_uint2(l.x, l.y);
-        *reinterpret_cast<uint2*>(tile + 2 * kPart64 + o1) = make_uint2(l.z, l.w);
-    }
-}
-
-__device__ __forceinline__ void read_parts64(const unsigned short* __restrict__ tile, int lane, int blk,
-                                             Bf16Parts& p) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        p.hi[s] = img_fragment<2, false>(tile, lane, 0, blk, s);
-        p.mid[s] = img_fragment<2, false>(tile + kPart64, lane, 0, blk, s);
-        p.lo[s] = img_fragment<2, false>(tile + 2 * kPart64, lane, 0, blk, s);
-    }
-}
-
-// acc (output block cb) += W(cb, blk) v_blk (TRANSPOSE: W^T) for one input block given as parts
-template <bool TRANSPOSE>
-__device__ __forceinline__ void chain_block_parts(const unsigned short* __restrict__ img, int lane, int cb,
-                                                  int blk, const Bf16Parts& b, f32x16& acc) {
-    constexpr int H = 64;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const bf16x8 ah = img_fragment<2, TRANSPOSE>(img, lane, cb, blk, s);
-        const bf16x8 am = img_fragment<2, TRANSPOSE>(img + H * H, lane, cb, blk, s);
-        const bf16x8 al = img_fragment<2, TRANSPOSE>(img + 2 * H * H, lane, cb, blk, s);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.hi[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.lo[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.mid[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.hi[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.mid[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.hi[s], acc, 0, 0, 0);
-    }
-}
-
-// gW[bi] (rows: own channel block cb of gt, columns: channel block bi of at) += sum over the 32 edges
-__device__ __forceinline__ void wgrad_parts64(const unsigned short* __restrict__ gt,
-                                              const unsigned short* __restrict__ at, int lane, int cb,
-                                              f32x16 (&gW)[2]) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const bf16x8 gh = img_fragment<2, true>(gt, lane, cb, 0, s);
-        const bf16x8 gm = img_fragment<2, true>(gt + kPart64, lane, cb, 0, s);
-        const bf16x8 gl = img_fragment<2, true>(gt + 2 * kPart64, lane, cb, 0, s);
-#pragma unroll
-        for (int bi = 0; bi < 2; ++bi) {
-            const bf16x8 ah = img_fragment<2, true>(at, lane, bi, 0, s);
-            const bf16x8 am = img_fragment<2, true>(at + kPart64, lane, bi, 0, s);
-            const bf16x8 al = img_fragment<2, true>(at + 2 * kPart64, lane, bi, 0, s);
-            gW[bi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, ah, gW[bi], 0, 0, 0);
-            gW[bi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, al, gW[bi], 0, 0, 0);
-            gW[bi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gm, am, gW[bi], 0, 0, 0);
-            gW[bi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gm, ah, gW[bi], 0, 0, 0);
-            gW[bi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, am, gW[bi], 0, 0, 0);
-            gW[bi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, ah, gW[bi], 0, 0, 0);
-        }
-    }
-}
-
-// timing-only ablations (tools/ab.py variants; never built into the shipped library)
-#ifdef PVS_ABL_T_NOBAR
-#define TEAM_SYNC() ((void)0)
-#else
-#define TEAM_SYNC() __syncthreads()
-#endif
-#ifdef PVS_ABL_T_NOWGRAD
-#define TEAM_WGRAD(...) ((void)0)
-#else
-#define TEAM_WGRAD(...) wgrad_parts64(__VA_ARGS__)
-#endif
-template <bool ERES, bool EATT>
-__global__ void __launch_bounds__(256, 1)
-k_edge_bwd_team_parts(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks,
-                      int e_lo, int e_hi) {
-    constexpr int HB = 2, H = 64, TS = H + 4, NT = 256, NW = NT / 64, TEAMS = NW / HB;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int kWeightFloats = 2 * 3 * H * H / 2;
-    unsigned short* W2i = reinterpret_cast<unsigned short*>(smem);
-    unsigned short* Wc1i = W2i + 3 * H * H;
-    float* b2t = smem + kWeightFloats;
-    float* bc1t = b2t + H;
-    float* wc2t = bc1t + H;
-    float* wat = wc2t + H;
-    float* wrhot = wat + H;
-    float* attrt = wrhot + H;                              // [PVS_MAX_EDGE_ATTR][H]
-    int* lens = reinterpret_cast<int*>(attrt + PVS_MAX_EDGE_ATTR * H);   // [TEAMS] (+pad to 16)
-    float* team_base = reinterpret_cast<float*>(lens + 16);
-    // per team: PA (a1 parts), PB (m parts, then g_z1 as an fp32 [32][TS] tile), PC (g_zc parts, then
-    //           g_z2 parts), tx[32][4], rowbuf[32], pdA[HB][32], pdB[HB][32]
-    constexpr int kTileFloats = 3 * kPart64 / 2;           // 12 KB
-    static_assert(kTileFloats >= kTile * TS, "the fp32 g_z1 tile must fit the m parts tile");
-    constexpr int kTeamFloats = 3 * kTileFloats + kTile * 4 + kTile + 2 * HB * kTile;
-
-    const bool upd = (flags & PVS_UPDATE_COORDS) && io.gxagg != nullptr;
-    stage_weights_img<HB>(W2i, w.w2);
-    if (upd) stage_weights_img<HB>(Wc1i, w.wc1);
-    for (int c = threadIdx.x; c < H; c += NT) {
-        b2t[c] = w.b2[c];
-        bc1t[c] = upd ? w.bc1[c] : 0.f;
-        wc2t[c] = upd ? w.wc2[c] : 0.f;
-        wat[c] = EATT ? w.wa[c] : 0.f;
-        wrhot[c] = w.w1[c * w.ld1 + w.off_rho];
-        for (int t = 0; t < PVS_MAX_EDGE_ATTR; ++t)
-            attrt[t * H + c] = t < w.n_attr ? w.w1[c * w.ld1 + w.off_rho + 1 + t] : 0.f;
-    }
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int j = lane & 31, hh = lane >> 5;
-    const int team = wv / HB, cb = wv % HB, pb = 1 - cb;
-    const int co = 32 * cb;                       // first channel of this wave's block
-    float* tb = team_base + team * kTeamFloats;
-    unsigned short* PA = reinterpret_cast<unsigned short*>(tb);
-    unsigned short* PB = reinterpret_cast<unsigned short*>(tb + kTileFloats);
-    unsigned short* PC = reinterpret_cast<unsigned short*>(tb + 2 * kTileFloats);
-    float* T1 = tb + kTileFloats;                 // aliases PB
-    float* tx = tb + 3 * kTileFloats;
-    int* rowbuf = reinterpret_cast<int*>(tx + kTile * 4);
-    float* pdA = reinterpret_cast<float*>(rowbuf + kTile);
-    float* pdB = pdA + HB * kTile;
-    const float bac = EATT ? w.ba[0] : 0.f;
-    float gate_raw = 0.f, gate = 1.f;
-    if (ERES && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
-        gate_raw = w.edge_gate[0];
-        gate = (flags & PVS_GATED_RESIDUAL) ? fmaxf(gate_raw, 0.f) : gate_raw;
-    }
-    // edge residual without per-element branches: m = res_a * m_new + res_b * m_prev
-    // (plain: 1, 1; rezero: g, 1; gated: relu(g), 1 - relu(g))
-    const float res_a = (flags & (PVS_REZERO | PVS_GATED_RESIDUAL)) ? gate : 1.f;
-    const float res_b = (flags & PVS_GATED_RESIDUAL) ? 1.f - gate : 1.f;
-    auto sum_pd = [&](const float* pd) {
-        float s = 0.f;
-#pragma unroll
-        for (int b = 0; b < HB; ++b) s += pd[b * kTile + j];
-        return s;
-    };
-
-    // kernel-lifetime accumulators: row block cb of the two weight gradients; X-layout vectors
-    // (channel in the register, edges on the lanes) for g_wc2 and the column sums
-    f32x16 gW2[HB], gWc1[HB];
-#pragma unroll
-    for (int bi = 0; bi < HB; ++bi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { gW2[bi][r] = 0.f; gWc1[bi][r] = 0.f; }
-    float g_wc2x[16], g_b2x[16], g_bc1x[16], g_wax[EATT ? 16 : 1];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { g_wc2x[r] = 0.f; g_b2x[r] = 0.f; g_bc1x[r] = 0.f; }
-#pragma unroll
-    for (int r = 0; r < (EATT ? 16 : 1); ++r) g_wax[r] = 0.f;
-    float g_ba = 0.f, g_gate = 0.f;
-
-    for (int cbase = pvs_xcd_block(blockIdx.x, gridDim.x) * TEAMS; cbase < n_chunks; cbase += gridDim.x * TEAMS) {
-        const int chunk = cbase + team;
-        const int e_begin = chunk < n_chunks ? chunk_begin(g, chunk, n_chunks, e_lo, e_hi) : e_hi;
-        const int e_end = chunk < n_chunks ? chunk_begin(g, chunk + 1, n_chunks, e_lo, e_hi) : e_hi;
-        __syncthreads();
-        if (lane == 0 && cb == 0) lens[team] = e_end - e_begin;
-        __syncthreads();
-        int max_len = 0;
-#pragma unroll
-        for (int t = 0; t < TEAMS; ++t) max_len = max(max_len, lens[t]);
-        const int n_iter = (max_len + kTile - 1) / kTile;
-
-        int cur_row = -1;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accx = acc;
-        const int quad = lane % 8, rsub = lane / 8;
-        auto flush = [&](int row_id) {
-            if (row_id >= 0) {
-                const float4 tot = sum_row_slots<1>(acc);
-                if (rsub == 0) *reinterpret_cast<float4*>(io.gPQ + (size_t)row_id * 2 * H + co + 4 * quad) = tot;
-                const float4 tx4 = sum_row_slots<1>(accx);
-                if (lane == 0 && cb == 0) {
-                    io.gx_row[3 * row_id] = tx4.x;
-                    io.gx_row[3 * row_id + 1] = tx4.y;
-                    io.gx_row[3 * row_id + 2] = tx4.z;
-                }
-            }
-            acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            accx = acc;
-        };
-
-        // software pipeline over the tiles of the chunk: the indices of tile it+2 and the gathered rows
-        // of tile it+1 are in flight while tile it is processed
-        struct Idx { int ee, i, jn, ty, prev; };
-        auto idx_of = [&](int itx) {
-            Idx o;
-            const int e = e_begin + itx * kTile + j;
-            int ee = e < e_end ? e : e_end - 1;
-            ee = min(max(ee, 0), g.n_edges - 1);
-            o.ee = ee;
-            o.i = g.row[ee];
-            o.jn = g.col[ee];
-            o.ty = w.n_attr ? (int)g.etype[ee] : 0;
-            o.prev = (ee == e_begin || ee == 0) ? -1 : g.row[ee - 1];
-            return o;
-        };
-        float pp[16], qq[16], xi[3], xj[3];
-        auto rows_of = [&](const Idx& t) {
-            load16_tab(io.PQ + (size_t)t.i * 2 * H + co, hh, pp);
-            load16_tab(io.PQ + (size_t)t.jn * 2 * H + H + co, hh, qq);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { xi[c] = io.x[3 * t.i + c]; xj[c] = io.x[3 * t.jn + c]; }
-        };
-        Idx cur = idx_of(0), nxt = cur;
-        if (n_iter > 0) {
-            rows_of(cur);
-            nxt = idx_of(1);
-        }
-
-        for (int it = 0; it < n_iter; ++it) {
-            const int e0 = e_begin + it * kTile;
-            const int e = e0 + j;
-            const bool valid = e < e_end;
-            const float vm = valid ? 1.f : 0.f;
-            const int ee = cur.ee, i = cur.i, ty = cur.ty;
-            const unsigned bmask = (unsigned)__ballot(valid && hh == 0 && i != cur.prev);
-            const float d0 = xi[0] - xj[0], d1 = xi[1] - xj[1], d2 = xi[2] - xj[2];
-            const float rho = d0 * d0 + d1 * d1 + d2 * d2;
-
-            // ---- recompute: a1 (own block) -> parts -> PA ----
-            float sd1[16];            // SiLU'(z1), kept in registers
-            Bf16Parts own;
-            {
-                float a1[16], aa[16], rr[16];
-                load16_tab(attrt + ty * H + co, hh, aa);
-                load16_tab(wrhot + co, hh, rr);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a1[r] = pp[r] + qq[r] + fmaf(rr[r], rho, aa[r]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float sg = pvs_sigmoid(a1[r]);
-                    sd1[r] = pvs_silu_grad(a1[r], sg);
-                    a1[r] *= sg;
-                }
-                split_bf16x3(a1, own);
-            }
-            write_parts64(PA, j, hh, cb, own);
-            if (cb == 0 && hh == 0) rowbuf[j] = i;
-            // rows of this tile that are needed later (issued before the prefetch: loads return in order)
-            float gMi[16];
-            load16_tab(io.gM + (size_t)i * H + co, hh, gMi);
-            rows_of(nxt);
-            const Idx nn = idx_of(it + 2);
-            TEAM_SYNC();                                                     // (1) PA complete
-            // ---- z2 = W2 a1 + b2 (own output block) ----
-            float dz2[16], m[16];
-            float m_new[ERES ? 16 : 1], mp[ERES ? 16 : 1];
-            {
-                f32x16 acc2;
-                float bias[16];
-                load16_tab(b2t + co, hh, bias);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[r] = bias[r];
-                Bf16Parts oth;
-                read_parts64(PA, lane, pb, oth);
-                chain_block_parts<false>(W2i, lane, cb, cb, own, acc2);
-                chain_block_parts<false>(W2i, lane, cb, pb, oth, acc2);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float z2 = acc2[r];
-                    const float sg = pvs_sigmoid(z2);
-                    dz2[r] = pvs_silu_grad(z2, sg);
-                    m[r] = z2 * sg;
-                    if constexpr (ERES) m_new[r] = m[r];
-                }
-            }
-            if constexpr (ERES) {
-                load16_tab(io.m_prev + (size_t)ee * H + co, hh, mp);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    m[r] = fmaf(res_a, m_new[r], res_b * mp[r]);
-                }
-            }
-            split_bf16x3(m, own);
-            write_parts64(PB, j, hh, cb, own);
-            // ---- gradient wrt m (own block): external + attention + coordinate branch ----
-            f32x16 gm;
-            {
-                float init[16];
-                if (io.g_m_out) load16_tab(io.g_m_out + (size_t)ee * H + co, hh, init);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gm[r] = io.g_m_out ? init[r] * vm : 0.f;
-            }
-            if constexpr (EATT) {
-                float pl = dot16_tab(wat + co, hh, m);
-                float pdot = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pdot = fmaf(m[r], gMi[r], pdot);
-                pdot += __shfl_xor(pdot, 32, 64);
-                if (hh == 0) { pdA[cb * kTile + j] = pl; pdB[cb * kTile + j] = pdot; }
-            }
-            TEAM_SYNC();                                                     // (2) PB, pd complete
-            float g_l = 0.f, aval = 1.f;
-            if constexpr (EATT) {
-                const float logit = sum_pd(pdA) + bac;
-                const float dot = sum_pd(pdB);
-                aval = io.att[ee];
-                g_l = (flags & PVS_SOFTMAX_ATT) ? aval * (dot - io.softD[i]) * vm      // softD = M_i . g_M_i
-                                             : pvs_att_act_grad(att_act, logit, aval) * dot * vm;
-                if (hh == 0 && cb == 0) g_ba += g_l;
-                float wax[16];
-                load16_tab(wat + co, hh, wax);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    gm[r] += (aval * vm) * gMi[r] + g_l * wax[r];
-                    g_wax[r] = fmaf(g_l, m[r], g_wax[r]);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gm[r] += vm * gMi[r];
-            }
-            float s_coord = 0.f, nrm = 1.f, gT0 = 0.f, gT1 = 0.f, gT2 = 0.f;
-            if (upd) {
-                gT0 = io.gxagg[3 * i]; gT1 = io.gxagg[3 * i + 1]; gT2 = io.gxagg[3 * i + 2];
-                f32x16 accc;
-                float bias2[16];
-                load16_tab(bc1t + co, hh, bias2);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) accc[r] = bias2[r];
-                Bf16Parts oth;
-                read_parts64(PB, lane, pb, oth);
-                chain_block_parts<false>(Wc1i, lane, cb, cb, own, accc);
-                chain_block_parts<false>(Wc1i, lane, cb, pb, oth, accc);
-                float q[16], dq[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float zc = accc[r];
-                    const float sg = pvs_sigmoid(zc);
-                    q[r] = zc * sg;
-                    dq[r] = pvs_silu_grad(zc, sg);
-                }
-                const float ps = dot16_tab(wc2t + co, hh, q);
-                TEAM_SYNC();                                                 // (3a) pdA reads of (2) done
-                if (hh == 0) pdA[cb * kTile + j] = ps;
-                TEAM_SYNC();                                                 // (3) pdA complete
-                float s = sum_pd(pdA);
-                float dact = 1.f;
-                if (flags & PVS_TANH) { s = pvs_tanh(s); dact = 1.f - s * s; }
-                if (flags & PVS_NORMALIZE) nrm = 1.f / (sqrtf(rho) + 1e-8f);
-                s_coord = s;
-                const float g_s = (d0 * gT0 + d1 * gT1 + d2 * gT2) * nrm * dact * vm;
-                float wc2x[16], g_zc[16];
-                load16_tab(wc2t + co, hh, wc2x);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    g_zc[r] = g_s * wc2x[r] * dq[r];
-                    g_wc2x[r] = fmaf(g_s, q[r], g_wc2x[r]);
-                    g_bc1x[r] += g_zc[r];
-                }
-                split_bf16x3(g_zc, own);
-                write_parts64(PC, j, hh, cb, own);
-                TEAM_SYNC();                                                 // (4) PC = g_zc complete
-                read_parts64(PC, lane, pb, oth);
-                chain_block_parts<true>(Wc1i, lane, cb, cb, own, gm);            // g_m += Wc1^T g_zc
-                chain_block_parts<true>(Wc1i, lane, cb, pb, oth, gm);
-                // ---- Wc1 weight gradient (row block cb) ----
-                TEAM_WGRAD(PC, PB, lane, cb, gWc1);
-            }
-            // ---- edge residual, g_z2 ----
-            float g_z2[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float gmv = gm[r];
-                float gnew = gmv;
-                if constexpr (ERES) {
-                    if (flags & PVS_REZERO) {
-                        gnew = gate * gmv;
-                        g_gate = fmaf(gmv, m_new[r], g_gate);
-                        mp[r] = gmv;
-                    } else if (flags & PVS_GATED_RESIDUAL) {
-                        gnew = gate * gmv;
-                        if (gate_raw > 0.f) g_gate = fmaf(gmv, m_new[r] - mp[r], g_gate);
-                        mp[r] = (1.f - gate) * gmv;
-                    } else {
-                        mp[r] = gmv;
-                    }
-                }
-                g_z2[r] = gnew * dz2[r];
-                g_b2x[r] += g_z2[r];
-            }
-            if constexpr (ERES) {
-                if (valid) {
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq)
-                        *reinterpret_cast<float4*>(io.g_m_prev + (size_t)e * H + co + 8 * gq + 4 * hh) =
-                            make_float4(mp[4 * gq], mp[4 * gq + 1], mp[4 * gq + 2], mp[4 * gq + 3]);
-                }
-            }
-            split_bf16x3(g_z2, own);
-            TEAM_SYNC();                                                     // (5) PC / PB reads done
-            write_parts64(PC, j, hh, cb, own);
-            TEAM_SYNC();                                                     // (6) PC = g_z2 complete
-            // ---- g_a1 = W2^T g_z2 (own block); g_z1 = g_a1 * SiLU'(z1) ----
-            f32x16 ga1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ga1[r] = 0.f;
-            {
-                Bf16Parts oth;
-                read_parts64(PC, lane, pb, oth);
-                chain_block_parts<true>(W2i, lane, cb, cb, own, ga1);
-                chain_block_parts<true>(W2i, lane, cb, pb, oth, ga1);
-            }
-            float g_z1[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g_z1[r] = ga1[r] * sd1[r];
-            const float prho = dot16_tab(wrhot + co, hh, g_z1);
-            if (hh == 0) pdA[cb * kTile + j] = prho;
-            // ---- W2 weight gradient (row block cb) ----
-            TEAM_WGRAD(PC, PA, lane, cb, gW2);
-            TEAM_SYNC();                                                     // (7) pdA complete; PB free
-            const float g_rho = sum_pd(pdA);
-            const float k1 = s_coord * nrm * vm;
-            const float gd0 = fmaf(k1, gT0, 2.f * d0 * g_rho);
-            const float gd1 = fmaf(k1, gT1, 2.f * d1 * g_rho);
-            const float gd2 = fmaf(k1, gT2, 2.f * d2 * g_rho);
-            if (hh == 0 && cb == 0) {
-                *reinterpret_cast<float4*>(tx + j * 4) = make_float4(gd0, gd1, gd2, 0.f);
-                if (valid)
-                    *reinterpret_cast<float4*>(io.gd + (size_t)e * 4) =
-                        make_float4(gd0, gd1, gd2, pvs_pack_rho_type(rho, ty));
-            }
-            xwrite_block<HB>(T1, j, hh, cb, g_z1);
-            TEAM_SYNC();                                                     // (8) T1 = g_z1, tx complete
-            // own 128-byte half-rows of g_z1 to HBM + row-side sums of the own channel block
-            {
-                float4 v[4], dx[4];
-                int seg[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int rl = k * 8 + rsub;
-                    v[k] = *reinterpret_cast<const float4*>(T1 + rl * TS + co + 4 * quad);
-                    dx[k] = *reinterpret_cast<const float4*>(tx + rl * 4);
-                    if (e0 + rl < e_end) pvs_store_nt(io.gz1 + (size_t)(e0 + rl) * H + co + 4 * quad, v[k]);
-                    const unsigned upto = rl == 31 ? 0xffffffffu : ((2u << rl) - 1u);
-                    seg[k] = __popc(bmask & upto);
-                }
-                unsigned bm = bmask;
-                for (int sgi = 0;; ++sgi) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float mk = seg[k] == sgi ? 1.f : 0.f;
-                        acc.x = fmaf(mk, v[k].x, acc.x); acc.y = fmaf(mk, v[k].y, acc.y);
-                        acc.z = fmaf(mk, v[k].z, acc.z); acc.w = fmaf(mk, v[k].w, acc.w);
-                        accx.x = fmaf(mk, dx[k].x, accx.x); accx.y = fmaf(mk, dx[k].y, accx.y);
-                        accx.z = fmaf(mk, dx[k].z, accx.z);
-                    }
-                    if (bm == 0u) break;
-                    flush(cur_row);
-                    const int pos = __builtin_ctz(bm);
-                    bm &= bm - 1u;
-                    cur_row = __builtin_amdgcn_readfirstlane(rowbuf[pos]);
-#ifdef PVS_ABL_T_NOBAR
-                    cur_row = min(max(cur_row, 0), g.n_nodes - 1);     // (racy read in this timing-only build)
-#endif
-                }
-            }
-            TEAM_SYNC();                                                     // (9) tile buffers free
-            cur = nxt;
-            nxt = nn;
-        }
-        flush(cur_row);
-    }
-
-    // ---- block reduction into one slab, fixed order ----
-    const PvsSlabLayout L = pvs_slab_layout(H);
-    __syncthreads();
-    float* slab = smem;
-    for (int i = threadIdx.x; i < L.total; i += NT) slab[i] = 0.f;
-    __syncthreads();
-    auto lanes32 = [&](float (&v)[16]) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float t = v[r];
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) t += __shfl_xor(t, o, 64);
-            v[r] = t;
-        }
-    };
-    lanes32(g_wc2x);
-    lanes32(g_b2x);
-    lanes32(g_bc1x);
-    if constexpr (EATT) lanes32(g_wax);
-    g_ba += __shfl_xor(g_ba, 32, 64);
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) g_ba += __shfl_xor(g_ba, o, 64);
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) g_gate += __shfl_xor(g_gate, o, 64);
-    for (int turn = 0; turn < NW; ++turn) {
-        if (wv == turn) {
-#pragma unroll
-            for (int bi = 0; bi < HB; ++bi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int c = co + xch(r, hh), k = 32 * bi + j;
-                    slab[L.w2 + c * H + k] += gW2[bi][r];
-                    slab[L.wc1 + c * H + k] += gWc1[bi][r];
-                }
-            if (j == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int c = co + xch(r, hh);
-                    slab[L.wc2 + c] += g_wc2x[r];
-                    slab[L.b2 + c] += g_b2x[r];
-                    slab[L.bc1 + c] += g_bc1x[r];
-                    if constexpr (EATT) slab[L.wa + c] += g_wax[r];
-                }
-            }
-            if (lane == 0) { slab[L.ba] += g_ba; slab[L.gate] += g_gate; }
-        }
-        __syncthreads();
-    }
-    float* dst = io.slabs + (size_t)blockIdx.x * L.total;
-    for (int i = threadIdx.x; i < L.total; i += NT) dst[i] = slab[i];
-}
-
 }  // namespace
 
 int pvs_edge_bwd_mfma_max_blocks(int H) { (void)H; return 512; }
@@ -1625,35 +1088,21 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     PVS_REQUIRE(H == 32 || H == 64, "MFMA edge backward is built for H = 32, 64 (got %d)", H);
     *n_slabs = 0;
     if (e_hi <= e_lo) return 0;
+    // Default: H = 32 as three-term fp16 products (edge_bwd_f16.hip), H = 64 as one wave per 16-edge tile with
+    // six-term bf16 products (edge_bwd_h64.hip). PVS_EGNN_BF16X3=0: every product as an exact fp32 MFMA
+    // (v_mfma_f32_32x32x2_f32) - the kernels below, kept as the arithmetic cross-check family of the tests
+    // (tests/test_gpu_properties.py); the round-1/2 split kernels they replaced are gone from the library.
     const char* bf = getenv("PVS_EGNN_BF16X3");
-    const bool bf16x3 = !(bf && bf[0] == '0') && H == 32;
-    {   // defaults: the all-bf16 one-wave-per-tile kernels of edge_bwd_bf16.hip.
-        // PVS_BWD32=0: H = 32 with fp32 weight-gradient MFMAs (k_edge_bwd_mfma).
-        // (H = 32 with edge residual AND edge attention needs ~100 more registers than two waves per SIMD have -
-        //  137 spilled - and runs no faster than the round-1 kernel, which keeps that combination; edge residual
-        //  alone spills 29 and is 24 % faster per launch than the round-1 kernel: profiles/r02_variants_edge_residual.txt)
-        const char* b32 = getenv("PVS_BWD32");
-        const char* b64 = getenv("PVS_BWD64");
-        const bool eres_on = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
-        const bool all_bf16 = !(bf && bf[0] == '0');
-        const bool eres_att = eres_on && (flags & PVS_EDGE_ATTENTION);
-        // round 3: H = 32 as three-term fp16 products (edge_bwd_f16.hip), every flag combination;
-        // PVS_BWD32=bf16: the round-2 six-term bf16 kernel (which hands edge residual + attention to round 1's)
-        const bool want_bf16 = b32 && b32[0] == 'b';
-        if (H == 32 && all_bf16 && !want_bf16 && !(b32 && b32[0] == '0'))
-            return pvs_launch_edge_bwd_f16(s, H, g, w, flags, att_act, io, e_lo, e_hi, n_slabs);
-        if (H == 32 && all_bf16 && !eres_att && !(b32 && b32[0] == '0'))
-            return pvs_launch_edge_bwd_bf16(s, H, g, w, flags, att_act, io, e_lo, e_hi, n_slabs);
-        // H = 64: one wave per 16-edge tile (edge_bwd_h64.hip); PVS_BWD64=0: the round-1 team kernel below
-        if (H == 64 && all_bf16 && !(b64 && b64[0] == '0'))
-            return pvs_launch_edge_bwd_h64(s, g, w, flags, att_act, io, e_lo, e_hi, n_slabs);
+    const char* bf64 = getenv("PVS_EGNN_BF16X3_H64");       // (=0: the fp32 family for H = 64 only)
+    if (!(bf && bf[0] == '0') && (H == 32 || !(bf64 && bf64[0] == '0'))) {
+        if (H == 32) return pvs_launch_edge_bwd_f16(s, H, g, w, flags, att_act, io, e_lo, e_hi, n_slabs);
+        return pvs_launch_edge_bwd_h64(s, g, w, flags, att_act, io, e_lo, e_hi, n_slabs);
     }
-    const int nt = bf16x3 ? 512 : kThreads, nw = nt / 64;
-    // resident blocks per launch: H=32 fp32: 2 x 256 threads per CU; bf16x3: 1 x 512; H=64: 1 x 256
+    const int nt = kThreads, nw = nt / 64;
     int blocks, n_chunks;
     {
         const int E = e_hi - e_lo;
-        const int max_blocks = bf16x3 ? 256 : pvs_edge_bwd_mfma_max_blocks(H);
+        const int max_blocks = pvs_edge_bwd_mfma_max_blocks(H);       // H = 32: 2 x 256 threads per CU
         long long b = ((long long)E + (long long)nw * 512 - 1) / ((long long)nw * 512);   // fill the chip first
         if (b < 1) b = 1;
         if (b > max_blocks) b = max_blocks;
@@ -1666,33 +1115,26 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     *n_slabs = blocks;
     PvsProfScope prof(s, PVS_PROF_EDGE_BWD);
     const PvsSlabLayout L = pvs_slab_layout(H);
-    const bool img = bf16x3 && PVS_BWD_IMG;   // (see the kernel)
-    size_t words = (img ? (size_t)3 * H * H + (size_t)nw * 16 * 64
-                        : bf16x3 ? (size_t)4 * 6 * 64 * 4 : (size_t)2 * H * (H + 1)) +
-                   (5 + PVS_MAX_EDGE_ATTR) * H +
+    size_t words = (size_t)2 * H * (H + 1) + (5 + PVS_MAX_EDGE_ATTR) * H +
                    (size_t)nw * (3 * kTile * (H + 4) + kTile * 4 + 2 * kTile);
     if (words < (size_t)L.total) words = L.total;
     const size_t lds = words * sizeof(float);
     const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
     const bool eatt = flags & PVS_EDGE_ATTENTION;
-#define PVS_BWD_LAUNCH(HBV, ER, EA, BF)                                                            \
-    do {                                                                                          \
-        if (set_lds(k_edge_bwd_mfma<HBV, ER, EA, BF>, lds)) return -2;                            \
-        k_edge_bwd_mfma<HBV, ER, EA, BF><<<blocks, nt, lds, s>>>(g, w, flags, att_act, io, n_chunks, \
-                                                                 e_lo, e_hi);                    \
+    if (H == 32) {
+#define PVS_BWD_LAUNCH(ER, EA)                                                                      \
+    do {                                                                                           \
+        if (set_lds(k_edge_bwd_mfma<1, ER, EA, false>, lds)) return -2;                            \
+        k_edge_bwd_mfma<1, ER, EA, false><<<blocks, nt, lds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi); \
     } while (0)
-#define PVS_BWD_PICK(HBV, BF)                                \
-    do {                                                     \
-        if (eres && eatt) PVS_BWD_LAUNCH(HBV, true, true, BF);    \
-        else if (eres) PVS_BWD_LAUNCH(HBV, true, false, BF);      \
-        else if (eatt) PVS_BWD_LAUNCH(HBV, false, true, BF);      \
-        else PVS_BWD_LAUNCH(HBV, false, false, BF);               \
-    } while (0)
-    if (H == 32 && bf16x3) PVS_BWD_PICK(1, true);
-    else if (H == 32) PVS_BWD_PICK(1, false);
-    else {
+        if (eres && eatt) PVS_BWD_LAUNCH(true, true);
+        else if (eres) PVS_BWD_LAUNCH(true, false);
+        else if (eatt) PVS_BWD_LAUNCH(false, true);
+        else PVS_BWD_LAUNCH(false, false);
+#undef PVS_BWD_LAUNCH
+    } else {
         // team kernel: one team of 2 waves per 128-thread block, two blocks per CU: one wave per SIMD
-        // with the whole register file (the 4-team 512-thread block spilled at 256 registers)
+        // with the whole register file
         constexpr int kTeams = 1;
         const int E = e_hi - e_lo;
         long long b = ((long long)E + 511) / 512;
@@ -1704,58 +1146,21 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
         blocks = (int)b;
         n_chunks = (int)(teams * per_team);
         *n_slabs = blocks;
-        const char* bf64 = getenv("PVS_EGNN_BF16X3_H64");
-        const bool team_b3 = !(bf && bf[0] == '0') && !(bf64 && bf64[0] == '0');   // bf16x3 chain products
-        size_t tw = (team_b3 ? (size_t)3 * H * H : (size_t)2 * H * (H + 1)) + (5 + PVS_MAX_EDGE_ATTR) * H + 16 +
+        size_t tw = (size_t)2 * H * (H + 1) + (5 + PVS_MAX_EDGE_ATTR) * H + 16 +
                     (size_t)kTeams * (3 * kTile * (H + 4) + kTile * 4 + 2 * kTile + 2 * 2 * kTile);
         if (tw < (size_t)L.total) tw = L.total;
         const size_t tlds = tw * sizeof(float);
-#define PVS_TEAM_LAUNCH(ER, EA, B3)                                                                \
+#define PVS_TEAM_LAUNCH(ER, EA)                                                                    \
     do {                                                                                          \
-        if (set_lds(k_edge_bwd_team<2, ER, EA, B3>, tlds)) return -2;                             \
-        k_edge_bwd_team<2, ER, EA, B3><<<blocks, 128, tlds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi); \
+        if (set_lds(k_edge_bwd_team<2, ER, EA, false>, tlds)) return -2;                          \
+        k_edge_bwd_team<2, ER, EA, false><<<blocks, 128, tlds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi); \
     } while (0)
-#define PVS_TEAM_PICK(B3)                                     \
-    do {                                                      \
-        if (eres && eatt) PVS_TEAM_LAUNCH(true, true, B3);    \
-        else if (eres) PVS_TEAM_LAUNCH(true, false, B3);      \
-        else if (eatt) PVS_TEAM_LAUNCH(false, true, B3);      \
-        else PVS_TEAM_LAUNCH(false, false, B3);               \
-    } while (0)
-        const char* tp = getenv("PVS_TEAM_PARTS");
-        if (team_b3 && !(tp && tp[0] == '0')) {
-            // activations exchanged as bf16 parts, bf16x3 weight gradients: 2 teams per 256-thread block
-            constexpr int kT = 2;
-            long long pbk = ((long long)E + kT * 512 - 1) / (kT * 512);
-            if (pbk < 1) pbk = 1;
-            if (pbk > 256) pbk = 256;
-            const long long pteams = pbk * kT;
-            long long ppt = ((long long)E + pteams * 4096 - 1) / (pteams * 4096);
-            if (ppt < 1) ppt = 1;
-            blocks = (int)pbk;
-            n_chunks = (int)(pteams * ppt);
-            *n_slabs = blocks;
-            size_t pw = (size_t)3 * H * H + (5 + PVS_MAX_EDGE_ATTR) * H + 16 +
-                        (size_t)kT * (3 * (3 * 32 * 64 / 2) + kTile * 4 + kTile + 2 * 2 * kTile);
-            if (pw < (size_t)L.total) pw = L.total;
-            const size_t plds = pw * sizeof(float);
-#define PVS_PARTS_LAUNCH(ER, EA)                                                                   \
-    do {                                                                                          \
-        if (set_lds(k_edge_bwd_team_parts<ER, EA>, plds)) return -2;                              \
-        k_edge_bwd_team_parts<ER, EA><<<blocks, 256, plds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi); \
-    } while (0)
-            if (eres && eatt) PVS_PARTS_LAUNCH(true, true);
-            else if (eres) PVS_PARTS_LAUNCH(true, false);
-            else if (eatt) PVS_PARTS_LAUNCH(false, true);
-            else PVS_PARTS_LAUNCH(false, false);
-#undef PVS_PARTS_LAUNCH
-        } else if (team_b3) PVS_TEAM_PICK(true);
-        else PVS_TEAM_PICK(false);
-#undef PVS_TEAM_PICK
+        if (eres && eatt) PVS_TEAM_LAUNCH(true, true);
+        else if (eres) PVS_TEAM_LAUNCH(true, false);
+        else if (eatt) PVS_TEAM_LAUNCH(false, true);
+        else PVS_TEAM_LAUNCH(false, false);
 #undef PVS_TEAM_LAUNCH
     }
-#undef PVS_BWD_PICK
-#undef PVS_BWD_LAUNCH
     PVS_CHECK_LAUNCH();
     return 0;
 }

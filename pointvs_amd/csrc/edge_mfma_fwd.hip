@@ -347,48 +347,37 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     const int HB = H / 32;
     const char* bf = getenv("PVS_EGNN_BF16X3");
     const char* bf64 = getenv("PVS_EGNN_BF16X3_H64");
-    // default: fp32 products as bf16x3 (PVS_EGNN_BF16X3=0: fp32 MFMAs; PVS_EGNN_BF16X3_H64=0: only for H = 64)
-    const bool bf16x3 = !(bf && bf[0] == '0') && (H == 32 || !(bf64 && bf64[0] == '0'));
-    // round 3: the chain products as three-term fp16 products with tile scales (default);
-    // PVS_EGNN_F16X2=0 keeps the six-term bf16 products
-    const char* f16e = getenv("PVS_EGNN_F16X2");
-    const bool f16x2 = bf16x3 && !(f16e && f16e[0] == '0');
-    // H = 64 bf16x3: 48 KB of weight operands, so one workgroup per CU: 768 threads = three waves per SIMD
-    // (164-168 registers, no spills; forward kernel -5 % against two waves per SIMD) where the edge-class table
-    // leaves room in the 160 KB of LDS (up to 3 classes: 512 bytes to spare), 512 threads otherwise
+    // default: the two chain products as three-term fp16 products with tile scales ("f16x2", round 3);
+    // PVS_EGNN_BF16X3=0: exact fp32 MFMAs (PVS_EGNN_BF16X3_H64=0: only for H = 64) - the cross-check family of the
+    // tests. (The six-term bf16 form of rounds 1-2 is gone from the library: same accuracy, twice the MFMAs, a
+    // dearer split.)
+    const bool f16x2 = !(bf && bf[0] == '0') && (H == 32 || !(bf64 && bf64[0] == '0'));
+    // H = 64: 32 KB of weight operands, one workgroup per CU: 768 threads = three waves per SIMD where the edge-class
+    // table leaves room in the 160 KB of LDS (up to 3 classes), 512 threads otherwise
     const int attr_rows = w.n_attr > 1 ? w.n_attr : 1;
-    const int nw = (HB == 2 && bf16x3) ? (attr_rows <= 3 ? 12 : 8) : kWaves;
+    const int nw = (HB == 2 && f16x2) ? (attr_rows <= 3 ? 12 : 8) : kWaves;
     int blocks, n_chunks;
     pick_grid(g.n_edges, &blocks, &n_chunks, nw, nw >= 8 ? 256 : 1024);
-    const size_t words = (f16x2 ? (size_t)2 * HB * HB * 4 * 64 * 4 + 4 : bf16x3 ? (size_t)2 * HB * HB * 6 * 64 * 4 : (size_t)2 * H * H) +
+    const size_t words = (f16x2 ? (size_t)2 * HB * HB * 4 * 64 * 4 + 4 : (size_t)2 * H * H) +
                          (5 + attr_rows) * H +
                          (size_t)nw * (kTile * (H + 4) + kTile * 4 + kTile);
     const size_t lds = words * sizeof(float);
     const bool soft = (flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT);
-#define PVS_FWD_LAUNCH(HBV, B3, NTV, SF, F16)                                                        \
+#define PVS_FWD_LAUNCH(HBV, NTV, SF, F16)                                                            \
     do {                                                                                            \
-        if (set_lds(k_edge_fwd_mfma<HBV, B3, NTV, SF, F16>, lds)) return -2;                        \
-        k_edge_fwd_mfma<HBV, B3, NTV, SF, F16><<<blocks, NTV, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges); \
+        if (set_lds(k_edge_fwd_mfma<HBV, false, NTV, SF, F16>, lds)) return -2;                     \
+        k_edge_fwd_mfma<HBV, false, NTV, SF, F16><<<blocks, NTV, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges); \
     } while (0)
-#define PVS_FWD_PICK(HBV, B3, NTV)                             \
-    do {                                                      \
-        if (soft) PVS_FWD_LAUNCH(HBV, B3, NTV, true, false);  \
-        else PVS_FWD_LAUNCH(HBV, B3, NTV, false, false);      \
+#define PVS_FWD_PICK(HBV, NTV, F16)                       \
+    do {                                                  \
+        if (soft) PVS_FWD_LAUNCH(HBV, NTV, true, F16);    \
+        else PVS_FWD_LAUNCH(HBV, NTV, false, F16);        \
     } while (0)
-#define PVS_FWD_PICK16(HBV, NTV)                                \
-    do {                                                       \
-        if (soft) PVS_FWD_LAUNCH(HBV, false, NTV, true, true); \
-        else PVS_FWD_LAUNCH(HBV, false, NTV, false, true);     \
-    } while (0)
-    if (HB == 2 && f16x2 && nw == 12) PVS_FWD_PICK16(2, 768);
-    else if (HB == 2 && f16x2) PVS_FWD_PICK16(2, 512);
-    else if (HB == 1 && f16x2) PVS_FWD_PICK16(1, kThreads);
-    else if (HB == 2 && bf16x3 && nw == 12) PVS_FWD_PICK(2, true, 768);
-    else if (HB == 2 && bf16x3) PVS_FWD_PICK(2, true, 512);
-    else if (HB == 1 && bf16x3) PVS_FWD_PICK(1, true, kThreads);
-    else if (HB == 1) PVS_FWD_PICK(1, false, kThreads);
-    else PVS_FWD_PICK(2, false, kThreads);
-#undef PVS_FWD_PICK16
+    if (HB == 2 && f16x2 && nw == 12) PVS_FWD_PICK(2, 768, true);
+    else if (HB == 2 && f16x2) PVS_FWD_PICK(2, 512, true);
+    else if (HB == 1 && f16x2) PVS_FWD_PICK(1, kThreads, true);
+    else if (HB == 1) PVS_FWD_PICK(1, kThreads, false);
+    else PVS_FWD_PICK(2, kThreads, false);
 #undef PVS_FWD_PICK
 #undef PVS_FWD_LAUNCH
     PVS_CHECK_LAUNCH();

@@ -465,9 +465,8 @@ def test_point_vs_entry_runs_the_readme_sequence_on_synthetic_graphs(tmp_path):
 @pytest.mark.parametrize('seed', range(8))
 def test_kernel_families_agree_on_random_configurations(seed):
     """Fuzz: random layer flags, hidden size, graph shape (isolated nodes, E not a multiple of the
-    tile, several graphs) - the MFMA kernels (bf16x3 and fp32 products; H=64: one wave per 16-edge tile, team kernel with parts or fp32
-    tiles) and the generic kernels give
-    the same outputs and gradients."""
+    tile, several graphs) - the default MFMA kernels (split fp16 / bf16 products), the exact-fp32-MFMA family
+    (PVS_EGNN_BF16X3=0) and the generic kernels give the same outputs and gradients."""
     rng = np.random.default_rng(1000 + seed)
     flags = dict(
         k=int(rng.choice([32, 64])), num_layers=int(rng.integers(1, 4)),
@@ -488,9 +487,8 @@ def test_kernel_families_agree_on_random_configurations(seed):
     e = int(rng.integers(1, 40)) * n + int(rng.integers(0, 31))
     g = random_graph(n, e, seed=seed, n_graphs=int(rng.integers(1, 5)))
     runs = {}
-    for name, env in (('mfma', {}), ('fp32', {'PVS_EGNN_BF16X3': '0'}), ('team_parts', {'PVS_BWD64': '0'}),
-                      ('team', {'PVS_BWD64': '0', 'PVS_TEAM_PARTS': '0'}), ('generic', {'PVS_EGNN_KERNELS': 'generic'})):
-        for k_ in ('PVS_EGNN_BF16X3', 'PVS_EGNN_KERNELS', 'PVS_TEAM_PARTS', 'PVS_BWD64'):
+    for name, env in (('mfma', {}), ('fp32', {'PVS_EGNN_BF16X3': '0'}), ('generic', {'PVS_EGNN_KERNELS': 'generic'})):
+        for k_ in ('PVS_EGNN_BF16X3', 'PVS_EGNN_KERNELS'):
             os.environ.pop(k_, None)
         os.environ.update(env)
         try:
@@ -499,7 +497,7 @@ def test_kernel_families_agree_on_random_configurations(seed):
             for k_ in env:
                 os.environ.pop(k_, None)
     y_ref, g_ref = runs['generic']
-    for name in ('mfma', 'fp32', 'team_parts', 'team'):
+    for name in ('mfma', 'fp32'):
         y, grads = runs[name]
         assert rel_err(y, y_ref) < TOL, (name, flags)
         for pname in g_ref:
