@@ -388,7 +388,10 @@ def main():
     ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg5'],
                     help='cfg5: virtual-screening sweep (BASELINE config 5): forward only, random poses '
                          'of one ligand against one receptor, graphs built on the GPU per batch')
-    ap.add_argument('--batch', type=int, default=32, help='graphs per GPU')
+    ap.add_argument('--batch', type=int, default=None,
+                    help='graphs per GPU (default 32; cfg5: poses per replayed step, default 128 - the sweep streams '
+                         'one ligand\'s poses in fixed-size batches of its choosing: 24.5k / 26.2k / 27.7k / 26.8k poses/s '
+                         'at 32 / 64 / 128 / 256, profiles/r03_cfg5_batch_sizes.txt)')
     ap.add_argument('--sweep', type=int, default=0,
                     help='cfg5: screen this many poses per rank (sets --steps = ceil(sweep / batch)); BASELINE '
                          'config 5 is 100k poses over 8 GPUs')
@@ -421,6 +424,8 @@ def main():
                     help='1: capture the whole step in a hipGraph and time replays (default: 1 for cfg5, the '
                          'configuration BASELINE names; 0 for the training configurations)')
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 128 if args.config == 'cfg5' else 32
     if args.graph is None:
         args.graph = int(os.environ.get('PVS_BENCH_GRAPH', '1' if args.config == 'cfg5' else '0'))
     strong = args.global_batch > 0
