@@ -599,6 +599,23 @@ int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx,
     const int KK = K + K2;
     const bool aligned16 = ((ldx | ldy | (x2 ? ldx2 : 0)) & 3) == 0 &&
                            (((uintptr_t)x | (uintptr_t)y | (uintptr_t)x2) & 15) == 0;
+    // the wide layer (hidden 128): the MFMA kernel is built for <= 64 outputs and <= 128 inputs, so 128 (or 256)
+    // outputs go in chunks of 64 and a second input as a second, accumulating pass
+    auto mfma_k = [](int k) { return k == 32 || k == 64 || k == 128; };
+    if (aligned16 && epi == 0 && C > 64 && C % 64 == 0 && mfma_k(K) && (K2 == 0 || mfma_k(K2)) &&
+        (KK > 128 || C > 64)) {
+        for (int c0 = 0; c0 < C; c0 += 64) {
+            int rc = pvs_launch_linear(s, y + c0, ldy, x, ldx, W + (size_t)c0 * swc, swc, swk, b ? b + c0 : nullptr,
+                                       nullptr, 0, nullptr, 0, 0, N, K, 0, 64, accumulate, 0, nullptr, 0, nullptr, 0);
+            if (rc) return rc;
+            if (K2 > 0) {
+                rc = pvs_launch_linear(s, y + c0, ldy, x2, ldx2, W2 + (size_t)c0 * swc2, swc2, swk2, nullptr, nullptr, 0,
+                                       nullptr, 0, 0, N, K2, 0, 64, true, 0, nullptr, 0, nullptr, 0);
+                if (rc) return rc;
+            }
+        }
+        return 0;
+    }
     if (aligned16 && K % 32 == 0 && K2 % 32 == 0 && C % 32 == 0 && C <= 64 && (KK == 32 || KK == 64 || KK == 128)) {
         const int kb = KK / 32, cb = C / 32;
         const size_t lds_m = (size_t)(C * (KK + 1) + C) * sizeof(float);
@@ -655,6 +672,16 @@ int pvs_launch_tsgemm_tn(hipStream_t s, float* out, int ldo, const float* A, int
                          int ldb, int N, int C, int K, float* slabs, bool accumulate) {
     const int CK = C * K;
     PVS_REQUIRE(C <= 32 * kThreads, "tsgemm: %d x %d outputs unsupported", C, K);
+    if (C % 64 == 0 && K % 64 == 0 && (C > 64 || K > 64)) {
+        // the wide layer (hidden 128): 64 x 64 blocks of the output on the MFMA kernel, one product each
+        for (int c0 = 0; c0 < C; c0 += 64)
+            for (int k0 = 0; k0 < K; k0 += 64) {
+                const int rc = pvs_launch_tsgemm_tn(s, out + (size_t)c0 * ldo + k0, ldo, A + c0, lda, B + k0, ldb, N, 64,
+                                                    64, slabs, accumulate);
+                if (rc) return rc;
+            }
+        return 0;
+    }
     if (CK > 32 * kThreads) {
         // wider than one pass holds (32 outputs per thread): column chunks of the right operand, each a
         // product of its own (hidden sizes above 64 on the decomposed layer path; A is re-read per chunk)

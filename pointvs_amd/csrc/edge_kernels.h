@@ -28,6 +28,7 @@ struct PvsEdgeFwdIO {
     float* att_out;       // [E] (sigmoid-type: activation; softmax: logits, normalised later)
     float* smax;          // [N] softmax running max  (softmax only)
     float* ssum;          // [N] softmax denominator  (softmax only)
+    float* m_scratch;     // [E,H] (H = 128 without m_out: the two launches of the edge forward hand the messages over) or NULL
 };
 
 struct PvsEdgeBwdIO {
@@ -45,6 +46,7 @@ struct PvsEdgeBwdIO {
     float* gx_row;         // [N,3] row-side coordinate gradient
     float* g_m_prev;       // [E,H] sorted or NULL
     float* slabs;          // [blocks][slab_floats] per-block weight-gradient partials
+    float* wpair;          // [2][H][H] scratch (H = 128: coord_mlp.0's weight and its transpose, staged per launch) or NULL
 };
 
 // weight-gradient slab layout (floats), shared by the kernels and the finaliser

@@ -581,13 +581,20 @@ __device__ __forceinline__ void chain_team_b3(const unsigned short* __restrict__
 
 // acc (output block cb) += sum over input blocks bi of W(cb,bi) v_bi ; v_cb from registers, the
 // other blocks from the tile T. Wn natural padded [H][H+1]; TRANSPOSE: W^T.
-template <int HB, bool TRANSPOSE>
+// GLOBAL (H = 128: two fp32 weight matrices do not fit in 160 KB of LDS beside the team's tiles): Wn points at
+// [W | W^T], two dense [H][H] copies in GLOBAL memory (pvs_stage_weight_pair), so that the 32 lanes of a half always
+// read 32 consecutive floats of one row - the product that LDS serves from one padded copy needs the other
+// orientation here to stay coalesced. An L1 / L2 hit per MFMA; the fp32 MFMA's 64 cycles cover it.
+template <int HB, bool TRANSPOSE, bool GLOBAL = false>
 __device__ __forceinline__ void chain_team(const float* __restrict__ Wn, int lane, int cb,
                                            const float (&own)[16], const float* __restrict__ T,
                                            f32x16& acc) {
-    constexpr int H = 32 * HB, LD = H + 1;
+    constexpr int H = 32 * HB, LD = GLOBAL ? H : H + 1;
     const int j = lane & 31, hh = lane >> 5;
-#pragma unroll
+    if constexpr (GLOBAL) { if (!TRANSPOSE) Wn += H * H; }      // W v reads the W^T copy by rows
+    // (HB = 4: one input block at a time - fully unrolled, the 64 operand loads of a product are all hoisted and
+    // the wave's 512 registers overflow by 250)
+#pragma unroll(HB > 2 ? 1 : HB)
     for (int bi = 0; bi < HB; ++bi) {
         float v[16];
         if (bi == cb) {
@@ -599,7 +606,7 @@ __device__ __forceinline__ void chain_team(const float* __restrict__ Wn, int lan
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int kc = 32 * bi + (t & 3) + 8 * (t >> 2) + 4 * hh;
-            const float a = TRANSPOSE ? Wn[kc * LD + 32 * cb + j] : Wn[(32 * cb + j) * LD + kc];
+            const float a = (TRANSPOSE || GLOBAL) ? Wn[kc * LD + 32 * cb + j] : Wn[(32 * cb + j) * LD + kc];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v[t], acc, 0, 0, 0);
         }
     }
@@ -627,12 +634,15 @@ __device__ __forceinline__ void load16_tab(const float* __restrict__ tab, int hh
 template <int HB, bool ERES, bool EATT, bool BF16X3 = false, int NT = 64 * HB>
 __global__ void __launch_bounds__(NT, 1)
 k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks,
-                int e_lo, int e_hi) {
+                int e_lo, int e_hi, const float* __restrict__ wc1_pair) {
     constexpr int H = 32 * HB, TS = H + 4, NW = NT / 64, TEAMS = NW / HB;
+    // H = 128: W2 in LDS, Wc1 (both orientations) from global memory (wc1_pair, chain_team<.., GLOBAL>)
+    constexpr bool WC1G = HB > 2;
+    static_assert(!(WC1G && BF16X3), "the wide team kernel is fp32 only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // fp32: natural padded weights [H][H+1] serving W and W^T; BF16X3: one swizzled bf16 image per
     // part (3 x H*H x 2 B per matrix), also serving both
-    constexpr int kWeightFloats = BF16X3 ? 2 * 3 * H * H / 2 : 2 * H * (H + 1);
+    constexpr int kWeightFloats = BF16X3 ? 2 * 3 * H * H / 2 : (WC1G ? 1 : 2) * H * (H + 1);
     float* W2n = smem;
     float* Wc1n = W2n + H * (H + 1);
     unsigned short* W2i = reinterpret_cast<unsigned short*>(smem);
@@ -656,7 +666,7 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
         if (upd) stage_weights_img<HB>(Wc1i, w.wc1);
     } else {
         stage_weights_nat<HB>(W2n, w.w2);
-        if (upd) stage_weights_nat<HB>(Wc1n, w.wc1);
+        if (upd && !WC1G) stage_weights_nat<HB>(Wc1n, w.wc1);
     }
     for (int c = threadIdx.x; c < H; c += NT) {
         b2t[c] = w.b2[c];
@@ -871,6 +881,7 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accc[r] = bias2[r];
                 if constexpr (BF16X3) chain_team_b3<HB, false>(Wc1i, lane, cb, m, T1, accc);
+                else if constexpr (WC1G) chain_team<HB, false, true>(wc1_pair, lane, cb, m, T1, accc);
                 else chain_team<HB, false>(Wc1n, lane, cb, m, T1, accc);
                 float q[16], dq[16];
 #pragma unroll
@@ -900,6 +911,7 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 xwrite_block<HB>(T2, j, hh, cb, g_zc);
                 __syncthreads();                                                 // (4) T2 = g_zc complete
                 if constexpr (BF16X3) chain_team_b3<HB, true>(Wc1i, lane, cb, g_zc, T2, gm);   // g_m += Wc1^T g_zc
+                else if constexpr (WC1G) chain_team<HB, true, true>(wc1_pair, lane, cb, g_zc, T2, gm);
                 else chain_team<HB, true>(Wc1n, lane, cb, g_zc, T2, gm);
             } else if (EATT) {
                 __syncthreads();                                                 // glb visible
@@ -1075,6 +1087,16 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
 }
 
 
+// dst[0][c][k] = W[c][k], dst[1][k][c] = W[c][k]  (W and W^T, dense [H][H] each)
+__global__ void k_stage_weight_pair(const float* __restrict__ W, int H, float* __restrict__ dst) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * H; i += gridDim.x * blockDim.x) {
+        const int c = i / H, k = i - c * H;
+        const float v = W[i];
+        dst[i] = v;
+        dst[H * H + k * H + c] = v;
+    }
+}
+
 }  // namespace
 
 int pvs_edge_bwd_mfma_max_blocks(int H) { (void)H; return 512; }
@@ -1085,9 +1107,48 @@ int pvs_edge_bwd_mfma_max_blocks(int H) { (void)H; return 512; }
 int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags,
                              int att_act, const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs) {
     PVS_REQUIRE(w.n_attr <= 3, "MFMA edge backward supports up to 3 edge classes (got %d)", w.n_attr);
-    PVS_REQUIRE(H == 32 || H == 64, "MFMA edge backward is built for H = 32, 64 (got %d)", H);
+    PVS_REQUIRE(H == 32 || H == 64 || H == 128, "MFMA edge backward is built for H = 32, 64, 128 (got %d)", H);
     *n_slabs = 0;
     if (e_hi <= e_lo) return 0;
+    if (H == 128) {
+        // The wide layer (64 < hidden <= 128, padded to 128): a team of FOUR waves per 32-edge tile, exact fp32 MFMAs,
+        // W2 in LDS and Wc1 in both orientations from global memory (two fp32 128x128 matrices do not fit beside the
+        // team's 51 KB of tiles). One team per 256-thread block, one block per CU.
+        PVS_REQUIRE(io.wpair, "H = 128 edge backward needs the weight-pair scratch");
+        const bool upd = (flags & PVS_UPDATE_COORDS) && io.gxagg != nullptr;
+        if (upd) {
+            k_stage_weight_pair<<<64, 256, 0, s>>>(w.wc1, H, io.wpair);
+            PVS_CHECK_LAUNCH();
+        }
+        const int E = e_hi - e_lo;
+        long long b = ((long long)E + 511) / 512;
+        if (b < 1) b = 1;
+        if (b > 256) b = 256;
+        long long per_team = ((long long)E + b * 4096 - 1) / (b * 4096);
+        if (per_team < 1) per_team = 1;
+        const int blocks = (int)b, n_chunks = (int)(b * per_team);
+        *n_slabs = blocks;
+        PvsProfScope prof(s, PVS_PROF_EDGE_BWD);
+        const PvsSlabLayout L = pvs_slab_layout(H);
+        size_t tw = (size_t)H * (H + 1) + (5 + PVS_MAX_EDGE_ATTR) * H + 16 +
+                    (size_t)(3 * kTile * (H + 4) + kTile * 4 + 2 * kTile + 2 * 4 * kTile);
+        if (tw < (size_t)L.total) tw = L.total;
+        const size_t tlds = tw * sizeof(float);
+        const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
+        const bool eatt = flags & PVS_EDGE_ATTENTION;
+#define PVS_WIDE_LAUNCH(ER, EA)                                                                    \
+    do {                                                                                          \
+        if (set_lds(k_edge_bwd_team<4, ER, EA, false>, tlds)) return -2;                          \
+        k_edge_bwd_team<4, ER, EA, false><<<blocks, 256, tlds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi, io.wpair); \
+    } while (0)
+        if (eres && eatt) PVS_WIDE_LAUNCH(true, true);
+        else if (eres) PVS_WIDE_LAUNCH(true, false);
+        else if (eatt) PVS_WIDE_LAUNCH(false, true);
+        else PVS_WIDE_LAUNCH(false, false);
+#undef PVS_WIDE_LAUNCH
+        PVS_CHECK_LAUNCH();
+        return 0;
+    }
     // Default: H = 32 as three-term fp16 products (edge_bwd_f16.hip), H = 64 as one wave per 16-edge tile with
     // six-term bf16 products (edge_bwd_h64.hip). PVS_EGNN_BF16X3=0: every product as an exact fp32 MFMA
     // (v_mfma_f32_32x32x2_f32) - the kernels below, kept as the arithmetic cross-check family of the tests
@@ -1153,7 +1214,7 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
 #define PVS_TEAM_LAUNCH(ER, EA)                                                                    \
     do {                                                                                          \
         if (set_lds(k_edge_bwd_team<2, ER, EA, false>, tlds)) return -2;                          \
-        k_edge_bwd_team<2, ER, EA, false><<<blocks, 128, tlds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi); \
+        k_edge_bwd_team<2, ER, EA, false><<<blocks, 128, tlds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi, nullptr); \
     } while (0)
         if (eres && eatt) PVS_TEAM_LAUNCH(true, true);
         else if (eres) PVS_TEAM_LAUNCH(true, false);
@@ -1166,7 +1227,7 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
 }
 
 int pvs_edge_bwd_mfma_supported(int H, uint32_t flags, int n_attr) {
-    if ((H != 32 && H != 64) || n_attr > 3) return 0;
+    if ((H != 32 && H != 64 && H != 128) || n_attr > 3) return 0;
     (void)flags;
     return 1;
 }

@@ -202,7 +202,7 @@ __device__ __forceinline__ void assemble_z1(const TileGather<HB>& G, const float
 // control flow: the first segment continues the carried row, every later one starts at a set bit.
 // acc/accx carry the open row's partial sums (per lane: its quad, summed over its row slots);
 // flush(row) reduces them over the row slots, stores and clears.
-template <int HB, bool WSUM = false, class Flush, class RowStore>
+template <int HB, bool WSUM = false, bool ROWS = true, class Flush, class RowStore>
 __device__ __forceinline__ void reduce_rows_tile(const float* __restrict__ T, const float* __restrict__ tx,
                                                  const int* __restrict__ rowbuf, unsigned bmask, int lane,
                                                  float4& acc, float4& accx, int& cur_row, Flush&& flush,
@@ -215,7 +215,8 @@ __device__ __forceinline__ void reduce_rows_tile(const float* __restrict__ T, co
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const int rl = k * RPI + rsub;
-        v[k] = *reinterpret_cast<const float4*>(T + rl * TS + 4 * quad);
+        if constexpr (ROWS) v[k] = *reinterpret_cast<const float4*>(T + rl * TS + 4 * quad);      // (!ROWS: only the
+        else v[k] = make_float4(0.f, 0.f, 0.f, 0.f);                        // per-edge float4 of tx is reduced)
         dx[k] = *reinterpret_cast<const float4*>(tx + rl * 4);
         store_row(rl, quad, v[k]);
         const unsigned upto = rl == 31 ? 0xffffffffu : ((2u << rl) - 1u);

@@ -20,18 +20,23 @@ namespace {
 
 // F16X2 (round 3): the two chain products as three-term fp16 products with tile scales (edge_mfma_common.h)
 // instead of six-term bf16 products: half the MFMAs, 2 instead of 5.5 VALU instructions per split value.
-template <int HB, bool BF16X3, int NT = kThreads, bool SOFT = false, bool F16X2 = false>
+// MODE (H = 128, where two split weight matrices do not fit in LDS beside the waves' tiles: the layer's edge forward runs
+// as two launches): 0 everything; 1 everything but the coordinate branch, with only W2 staged - the messages go to
+// io.m_out; 2 the coordinate branch alone, with only Wc1 staged - it reads the messages back from io.m_out.
+template <int HB, bool BF16X3, int NT = kThreads, bool SOFT = false, bool F16X2 = false, int MODE = 0>
 __global__ void __launch_bounds__(NT, (F16X2 && HB == 1) ? 4 : (F16X2 && NT == 768) ? 3 : 1)
 k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdIO io, int n_chunks,
                 int e_lo, int e_hi) {
     constexpr int H = 32 * HB;
+    static_assert(MODE == 0 || F16X2, "the two-launch form exists for the f16x2 kernels");
     constexpr int TS = H + 4;   // tile row stride (floats): conflict-free b128 writes / b32 reads
     if (g.n_edges_dev) e_hi = min(e_hi, *g.n_edges_dev);   // edge count only known on the device
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NW = NT / 64;
     static_assert(!(BF16X3 && F16X2), "one split scheme at a time");
     constexpr int kBlkWords = F16X2 ? 4 * 64 * 4 : 6 * 64 * 4;      // one 32x32 block as f16x2: 4 KB, bf16x3: 6 KB
-    constexpr int kWeightWords = (BF16X3 || F16X2) ? 2 * HB * HB * kBlkWords + (F16X2 ? 4 : 0) : 2 * H * H;
+    constexpr int kMats = MODE == 0 ? 2 : 1;
+    constexpr int kWeightWords = (BF16X3 || F16X2) ? kMats * HB * HB * kBlkWords + (F16X2 ? 4 : 0) : 2 * H * H;
     float* W2s = smem;
     float* Wc1s = W2s + H * H;
     float* b2t = smem + kWeightWords;
@@ -44,25 +49,25 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
     float* wave_base = attrt + attr_rows * H;            // per wave: tile[32][TS], tx[32][4], rowbuf[32]
     constexpr int kWaveFloats = kTile * TS + kTile * 4 + kTile;
 
-    const bool upd = flags & PVS_UPDATE_COORDS;
-    const bool eatt = flags & PVS_EDGE_ATTENTION;
+    const bool upd = MODE != 1 && (flags & PVS_UPDATE_COORDS);
+    const bool eatt = MODE != 2 && (flags & PVS_EDGE_ATTENTION);
     constexpr bool soft = SOFT;      // softmax attention: its own instantiation (keeps the others' registers)
     const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
 
     // BF16X3: each 32x32 block takes 3 parts x 2 k-steps x 64 lanes x 16 B = 6 KB
     unsigned* W2b = reinterpret_cast<unsigned*>(W2s);
-    unsigned* Wc1b = W2b + HB * HB * kBlkWords;
+    unsigned* Wc1b = MODE == 0 ? W2b + HB * HB * kBlkWords : W2b;      // (one matrix per launch: the same slot)
     float inv_sw2 = 1.f, inv_swc1 = 1.f;
     if constexpr (F16X2) {
-        unsigned* wmax = Wc1b + HB * HB * kBlkWords;     // [0]: max |W2|, [1]: max |Wc1| (fp32 bits)
+        unsigned* wmax = W2b + kMats * HB * HB * kBlkWords;     // [0]: max |W2|, [1]: max |Wc1| (fp32 bits)
         if (threadIdx.x < 4) wmax[threadIdx.x] = 0u;
         __syncthreads();
-        pvs_block_absmax(w.w2, H * H, wmax);
+        if (MODE != 2) pvs_block_absmax(w.w2, H * H, wmax);
         if (upd) pvs_block_absmax(w.wc1, H * H, wmax + 1);
         __syncthreads();
         const float sw2 = pvs_f16_scale(wmax[0], &inv_sw2);
         const float swc1 = pvs_f16_scale(wmax[1], &inv_swc1);
-        stage_weights_f16x2_blocks<HB>(W2b, w.w2, sw2);
+        if (MODE != 2) stage_weights_f16x2_blocks<HB>(W2b, w.w2, sw2);
         if (upd) stage_weights_f16x2_blocks<HB>(Wc1b, w.wc1, swc1);
     } else if constexpr (BF16X3) {
         stage_weights_bf16x3_blocks<HB>(W2b, w.w2);
@@ -119,7 +124,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                     tot.x *= inv; tot.y *= inv; tot.z *= inv; tot.w *= inv;
                     if (lane == 0) io.ssum[row_id] = tx4.w;
                 }
-                if (rsub == 0) *reinterpret_cast<float4*>(io.Magg + (size_t)row_id * H + 4 * quad) = tot;
+                if (MODE != 2 && rsub == 0) *reinterpret_cast<float4*>(io.Magg + (size_t)row_id * H + 4 * quad) = tot;
                 if (upd) {
                     if (lane == 0) {
                         if (flags & kFwdRawXsum) {
@@ -149,10 +154,21 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
             const bool valid = I.valid;
             const unsigned long long ball = __ballot(valid && hh == 0 && i != I.prev_row);
             const unsigned bmask = (unsigned)ball;
-            gather_tile<HB>(io.PQ, io.x, I, hh, G);
-            const float d0 = G.d0, d1 = G.d1, d2 = G.d2;
+            float d0, d1, d2;
+            if constexpr (MODE == 2) {
+                d0 = io.x[3 * I.i] - io.x[3 * I.jn];
+                d1 = io.x[3 * I.i + 1] - io.x[3 * I.jn + 1];
+                d2 = io.x[3 * I.i + 2] - io.x[3 * I.jn + 2];
+            } else {
+                gather_tile<HB>(io.PQ, io.x, I, hh, G);
+                d0 = G.d0; d1 = G.d1; d2 = G.d2;
+            }
             const float rho = d0 * d0 + d1 * d1 + d2 * d2;
 
+            float m[HB][16];
+            if constexpr (MODE == 2) {      // the messages of the first launch (final: edge residual applied)
+                load_x<HB>(io.m_out + (size_t)ee * H, hh, m);
+            } else {
             // ---- first layer: z1 = P_i + Q_j + w_rho*rho + W_a[type]; a1 = SiLU(z1) ----
             float a1[HB][16];
             assemble_z1<HB>(G, attrt, wrhot, I.ty, hh, rho, a1);
@@ -161,7 +177,6 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a1[b][r] = pvs_silu(a1[b][r]);
             // ---- second layer on the matrix cores: m = SiLU(W2 a1 + b2) ----
-            float m[HB][16];
             {
                 f32x16 acc2[HB];
                 float bias[HB][16];
@@ -216,6 +231,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                         *reinterpret_cast<float4*>(io.m_out + (size_t)e * H + 32 * b + 8 * gq + 4 * hh) =
                             make_float4(m[b][4 * gq], m[b][4 * gq + 1], m[b][4 * gq + 2], m[b][4 * gq + 3]);
             }
+            }   // MODE != 2
             // ---- coordinate branch: s = wc2 . SiLU(Wc1 m + bc1) ----
             float s = 0.f;
             if (upd) {
@@ -286,6 +302,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
             }
             // ---- hand the weighted messages to the channel-per-lane reduction ----
             const float wgt = valid ? a : 0.f;
+            if constexpr (MODE != 2) {
 #pragma unroll
             for (int b = 0; b < HB; ++b)
 #pragma unroll
@@ -293,6 +310,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                     *reinterpret_cast<float4*>(tile + j * TS + 32 * b + 8 * gq + 4 * hh) =
                         make_float4(wgt * m[b][4 * gq], wgt * m[b][4 * gq + 1], wgt * m[b][4 * gq + 2],
                                     wgt * m[b][4 * gq + 3]);
+            }
             if (hh == 0) {
                 const float sv = valid ? s : 0.f;
                 *reinterpret_cast<float4*>(tx + j * 4) = make_float4(d0 * sv, d1 * sv, d2 * sv, soft ? wgt : 0.f);
@@ -301,7 +319,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
             I = In;
             pvs_wave_lds_sync();
             if (!(flags & kAblNoReduce))
-                reduce_rows_tile<HB, soft>(tile, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
+                reduce_rows_tile<HB, soft, MODE != 2>(tile, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
                                      [](int, int, const float4&) {});
             pvs_wave_lds_sync();
         }
@@ -327,7 +345,7 @@ __global__ void k_init_fwd(float* __restrict__ Magg, const float* __restrict__ x
 }  // namespace
 
 int pvs_edge_mfma_supported(int H, uint32_t flags) {
-    if (H != 32 && H != 64) return 0;
+    if (H != 32 && H != 64 && H != 128) return 0;
     return 1;
 }
 
@@ -345,6 +363,38 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     if (g.n_edges == 0) return 0;
     PvsProfScope prof(s, pvs_prof_fwd_tag());
     const int HB = H / 32;
+    if (HB == 4) {
+        // The wide layer (64 < hidden <= 128, padded to 128): two launches of the f16x2 kernel, one split weight matrix
+        // (64 KB) in LDS each - everything but the coordinate branch, messages to m_out (or the scratch); then the
+        // coordinate branch alone, reading the messages back. 256 threads, one workgroup per CU (138 KB of LDS).
+        float* mbuf = io.m_out ? io.m_out : io.m_scratch;
+        const bool upd = flags & PVS_UPDATE_COORDS;
+        PVS_REQUIRE(mbuf || !upd, "H = 128 edge forward needs m_out or the message scratch");
+        const int attr_rows = w.n_attr > 1 ? w.n_attr : 1;
+        int blocks, n_chunks;
+        pick_grid(g.n_edges, &blocks, &n_chunks, kWaves, 256);
+        const size_t words = (size_t)16 * 4 * 64 * 4 + 4 + (5 + attr_rows) * H +
+                             (size_t)kWaves * (kTile * (H + 4) + kTile * 4 + kTile);
+        const size_t lds = words * sizeof(float);
+        const bool soft = (flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT);
+        PvsEdgeFwdIO io1 = io;
+        io1.m_out = upd ? mbuf : io.m_out;
+        if (soft) {
+            if (set_lds(k_edge_fwd_mfma<4, false, kThreads, true, true, 1>, lds)) return -2;
+            k_edge_fwd_mfma<4, false, kThreads, true, true, 1><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io1, n_chunks, 0, g.n_edges);
+        } else {
+            if (set_lds(k_edge_fwd_mfma<4, false, kThreads, false, true, 1>, lds)) return -2;
+            k_edge_fwd_mfma<4, false, kThreads, false, true, 1><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io1, n_chunks, 0, g.n_edges);
+        }
+        PVS_CHECK_LAUNCH();
+        if (upd) {
+            if (set_lds(k_edge_fwd_mfma<4, false, kThreads, false, true, 2>, lds)) return -2;
+            k_edge_fwd_mfma<4, false, kThreads, false, true, 2><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io1, n_chunks, 0, g.n_edges);
+            PVS_CHECK_LAUNCH();
+        }
+        if (soft) return pvs_launch_softmax_finalize(s, g, io.smax, io.ssum, io.att_out);
+        return 0;
+    }
     const char* bf = getenv("PVS_EGNN_BF16X3");
     const char* bf64 = getenv("PVS_EGNN_BF16X3_H64");
     // default: the two chain products as three-term fp16 products with tile scales ("f16x2", round 3);

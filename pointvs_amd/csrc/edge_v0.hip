@@ -632,6 +632,14 @@ int pvs_launch_node_gather(hipStream_t s, int H, const PvsGraph& g, bool wsums, 
     const int blocks = wsums ? pvs_node_gather_blocks(n_hi - n_lo) : pvs_edge_v0_blocks(n_hi - n_lo);
     *n_slabs = wsums ? blocks : 0;
     PvsProfScope prof(s, PVS_PROF_COL_GATHER);
+    if (H == 128) {      // (the wide layer: only the column gather of this file is built at 128 channels)
+        if (wsums)
+            k_node_gather<128, true><<<blocks, kThreads, 0, s>>>(g, gz1, gd4, gx_row, g_x_out, gPQ, g_x, slabs, n_lo, n_hi);
+        else
+            k_node_gather<128, false><<<blocks, kThreads, 0, s>>>(g, gz1, gd4, gx_row, g_x_out, gPQ, g_x, slabs, n_lo, n_hi);
+        PVS_CHECK_LAUNCH();
+        return 0;
+    }
     PVS_DISPATCH_H(H, {
         if (wsums)
             k_node_gather<HH, true><<<blocks, kThreads, 0, s>>>(g, gz1, gd4, gx_row, g_x_out, gPQ, g_x, slabs,

@@ -69,8 +69,12 @@ PvsNodeW make_node_w(const PvsLayerDesc* d, const PvsLayerParams* p) {
 
 int check_desc(const PvsLayerDesc* d, const PvsGraph* g, const PvsLayerParams* p, bool allow_dev_count = false) {
     PVS_REQUIRE(d && g && p, "NULL descriptor/graph/params");
-    PVS_REQUIRE(pvs_edge_v0_supported(d->hidden),
-                "hidden size %d unsupported by this build (16, 32, 64)", d->hidden);
+    // 16 / 32 / 64: every kernel family; 128 (the wide layer: 64 < hidden <= 128 zero-padded by the caller): the MFMA
+    // edge kernels only (up to 3 edge classes, no PVS_EGNN_KERNELS=generic)
+    PVS_REQUIRE(pvs_edge_v0_supported(d->hidden) ||
+                    (d->hidden == 128 && pvs_use_mfma() && pvs_edge_bwd_mfma_supported(128, d->flags, d->n_edge_attr)),
+                "hidden size %d unsupported by this build (16, 32, 64; 128 on the MFMA kernels with <= 3 edge classes)",
+                d->hidden);
     PVS_REQUIRE(d->n_edge_attr >= 0 && d->n_edge_attr <= PVS_MAX_EDGE_ATTR,
                 "n_edge_attr %d unsupported (0..%d)", d->n_edge_attr, PVS_MAX_EDGE_ATTR);
     PVS_REQUIRE(!((d->flags & PVS_GATED_RESIDUAL) && (d->flags & PVS_REZERO)),
@@ -95,7 +99,7 @@ int check_desc(const PvsLayerDesc* d, const PvsGraph* g, const PvsLayerParams* p
 }
 
 struct FwdWs {
-    float *PQ, *y1, *u, *o, *smax, *ssum, *shift, *slabs;
+    float *PQ, *y1, *u, *o, *smax, *ssum, *shift, *slabs, *m_scratch;
 };
 
 size_t carve_fwd(PvsArena& a, const Dims& m, FwdWs* w) {
@@ -109,13 +113,15 @@ size_t carve_fwd(PvsArena& a, const Dims& m, FwdWs* w) {
     t.ssum = a.take<float>(m.N);
     t.shift = a.take<float>(m.H);
     t.slabs = a.take<float>((size_t)pvs_colreduce_blocks(m.N) * m.H);
+    // H = 128: the edge forward is two launches that hand the messages over through memory
+    t.m_scratch = a.take<float>(m.H > 64 ? (size_t)(m.E > 0 ? m.E : 1) * m.H : 4);
     if (w) *w = t;
     return a.off;
 }
 
 struct BwdWs {
     float *PQ, *y1, *u, *o, *g_o, *g_u, *gM, *t1, *tg, *gl, *gxagg, *softD, *gPQ, *gz1, *gd, *gx_row;
-    float *eslabs, *gsum, *dslabs, *S1, *S2, *coefs, *gvec, *nslabs, *nsum, *wslabs;
+    float *eslabs, *gsum, *dslabs, *S1, *S2, *coefs, *gvec, *nslabs, *nsum, *wslabs, *wpair;
 };
 
 size_t carve_bwd(PvsArena& a, const Dims& m, BwdWs* w) {
@@ -148,6 +154,7 @@ size_t carve_bwd(PvsArena& a, const Dims& m, BwdWs* w) {
     t.nslabs = a.take<float>((size_t)2048 * 4 * m.H);      // one [4H] slab per workgroup of the column gather
     t.nsum = a.take<float>(4 * (size_t)m.H);
     t.wslabs = a.take<float>(pvs_node_wgrads_supported(m.H) ? pvs_node_wgrads_slab_floats(m.N, m.H) : 4);
+    t.wpair = a.take<float>(m.H > 64 ? 2 * (size_t)m.H * m.H : 4);      // H = 128: coord_mlp.0's weight and its transpose
     if (w) *w = t;
     return a.off;
 }
@@ -280,7 +287,7 @@ extern "C" int pvs_egnn_layer_fwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     PVS_TRY(node_pre_forward(s, m, p, h, sPQ));
     PvsEdgeFwdIO io;
     io.PQ = sPQ; io.x = x; io.m_prev = m_prev; io.Magg = Magg; io.x_out = x_out; io.m_out = m_out;
-    io.att_out = att_out; io.smax = w.smax; io.ssum = w.ssum;
+    io.att_out = att_out; io.smax = w.smax; io.ssum = w.ssum; io.m_scratch = w.m_scratch;
     if (pvs_use_mfma() && pvs_edge_mfma_supported(H, d->flags))
         PVS_TRY(pvs_launch_edge_fwd_mfma(s, H, *g, ew, d->flags | pvs_ablate_bits(), d->att_act, io));
     else
@@ -352,7 +359,7 @@ extern "C" int pvs_egnn_layer_edge_sums(const PvsLayerDesc* d, const PvsGraph* g
     PVS_TRY(node_pre_forward(s, m, p, h, w.PQ));
     PvsEdgeFwdIO io;
     io.PQ = w.PQ; io.x = x; io.m_prev = nullptr; io.Magg = magg; io.x_out = xsum; io.m_out = nullptr;
-    io.att_out = att; io.smax = w.smax; io.ssum = w.ssum;
+    io.att_out = att; io.smax = w.smax; io.ssum = w.ssum; io.m_scratch = w.m_scratch;
     PVS_TRY(pvs_launch_edge_fwd_mfma(s, m.H, *g, ew, d->flags | kFwdRawXsumFlag, d->att_act, io));
     if (!(d->flags & PVS_UPDATE_COORDS))
         PVS_CHECK_HIP(hipMemsetAsync(xsum, 0, sizeof(float) * 3 * (size_t)m.N, s));
@@ -386,7 +393,7 @@ extern "C" int pvs_egnn_layer_fwd_partial(const PvsLayerDesc* d, const PvsGraph*
     PVS_TRY(node_pre_forward(s, m, p, h, sPQ));
     PvsEdgeFwdIO io;
     io.PQ = sPQ; io.x = x; io.m_prev = nullptr; io.Magg = Magg; io.x_out = x_out; io.m_out = nullptr;
-    io.att_out = att; io.smax = w.smax; io.ssum = w.ssum;
+    io.att_out = att; io.smax = w.smax; io.ssum = w.ssum; io.m_scratch = w.m_scratch;
     pvs_prof_set_fwd_tag(PVS_PROF_EDGE_FWD_PARTIAL);      // timed apart from the full-graph layers (bench.py)
     const int rc_partial = pvs_launch_edge_fwd_mfma(s, H, *g, ew, d->flags | kFwdRawXsumFlag, d->att_act, io);
     pvs_prof_set_fwd_tag(PVS_PROF_EDGE_FWD);
@@ -507,7 +514,7 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     io.gxagg = coord_bwd ? w.gxagg : nullptr;
     io.softD = (eatt && soft) ? w.softD : nullptr;
     io.g_m_out = g_m_out; io.gPQ = w.gPQ; io.gz1 = w.gz1; io.gd = w.gd; io.gx_row = w.gx_row;
-    io.g_m_prev = eres ? g_m_prev : nullptr; io.slabs = w.eslabs;
+    io.g_m_prev = eres ? g_m_prev : nullptr; io.slabs = w.eslabs; io.wpair = w.wpair;
     int n_slabs = 0;
     const PvsSlabLayout L = pvs_slab_layout(H);
     int n_nslabs = 0;
@@ -555,7 +562,7 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     if (gr.edge_b1 && !fused_wgrads)
         PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.edge_b1, w.gPQ, 2 * H, nullptr, 0, nullptr,
                                      N, H, 1.f, w.dslabs, false));
-    k_finalize_edge_grads<<<H == 64 ? 16 : 4, 256, 0, s>>>(w.gsum, L, H, m.A, m.ld1, m.off_rho, gr,
+    k_finalize_edge_grads<<<H * H / 256 > 4 ? H * H / 256 : 4, 256, 0, s>>>(w.gsum, L, H, m.A, m.ld1, m.off_rho, gr,
                                             coord_bwd ? 1 : 0, eatt ? 1 : 0,
                                             (eres && (F & (PVS_REZERO | PVS_GATED_RESIDUAL))) ? 1 : 0,
                                             node_gsum, node_out);

@@ -124,6 +124,114 @@ k_node_out_bwd(const float* __restrict__ g_hout, const float* __restrict__ o,
     }
 }
 
+// H = 64 * K (K >= 2): one wave per node, lane owns channels lane + 64 k. Same arithmetic as the kernels above.
+template <int K>
+__global__ void __launch_bounds__(256)
+k_node_out_fwd_wide(const float* __restrict__ o, const float* __restrict__ h, PvsNodeW w, uint32_t flags,
+                    int att_act, int N, float* __restrict__ h_out, float* __restrict__ natt_out) {
+    constexpr int H = 64 * K;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    const bool natt = flags & PVS_NODE_ATTENTION;
+    const float bna = natt ? w.natt_b[0] : 0.f;
+    float gate = 1.f;
+    if ((flags & PVS_RESIDUAL) && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
+        gate = w.node_gate[0];
+        if (flags & PVS_GATED_RESIDUAL) gate = fmaxf(gate, 0.f);
+    }
+    for (int n = wave; n < N; n += n_waves) {
+        float ov[K];
+        float part = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            ov[k] = o[(size_t)n * H + lane + 64 * k];
+            if (natt) part = fmaf(w.natt_w[lane + 64 * k], ov[k], part);
+        }
+        float a = 1.f;
+        if (natt) {
+            a = pvs_att_act(att_act, pvs_group_sum<64>(part) + bna);
+            if (natt_out && lane == 0) natt_out[n] = a;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float v = ov[k] * a;
+            float r = v;
+            if (flags & PVS_RESIDUAL) {
+                const float hv = h[(size_t)n * H + lane + 64 * k];
+                if (flags & PVS_REZERO) r = hv + gate * v;
+                else if (flags & PVS_GATED_RESIDUAL) r = gate * v + (1.f - gate) * hv;
+                else r = hv + v;
+            }
+            h_out[(size_t)n * H + lane + 64 * k] = r;
+        }
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+k_node_out_bwd_wide(const float* __restrict__ g_hout, const float* __restrict__ o,
+                    const float* __restrict__ h, PvsNodeW w, uint32_t flags, int att_act, int N,
+                    float* __restrict__ g_o, float* __restrict__ g_h, float* __restrict__ gl,
+                    float* __restrict__ t1, float* __restrict__ tg) {
+    constexpr int H = 64 * K;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    const bool natt = flags & PVS_NODE_ATTENTION;
+    const bool res = flags & PVS_RESIDUAL;
+    const float bna = natt ? w.natt_b[0] : 0.f;
+    float gate_raw = 0.f, gate = 1.f;
+    const bool gated = res && (flags & PVS_GATED_RESIDUAL), rez = res && (flags & PVS_REZERO);
+    if (gated || rez) {
+        gate_raw = w.node_gate[0];
+        gate = gated ? fmaxf(gate_raw, 0.f) : gate_raw;
+    }
+    for (int n = wave; n < N; n += n_waves) {
+        float go[K], ov[K], wna[K];
+        float part = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const size_t idx = (size_t)n * H + lane + 64 * k;
+            go[k] = g_hout[idx];
+            ov[k] = o[idx];
+            wna[k] = natt ? w.natt_w[lane + 64 * k] : 0.f;
+            part = fmaf(wna[k], ov[k], part);
+        }
+        float l = 0.f, a = 1.f;
+        if (natt) {
+            l = pvs_group_sum<64>(part) + bna;
+            a = pvs_att_act(att_act, l);
+        }
+        float g_o2[K], g_hres[K], g_gate_el[K];
+        float dpart = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float o2 = ov[k] * a;
+            g_o2[k] = go[k]; g_hres[k] = 0.f; g_gate_el[k] = 0.f;
+            if (res) {
+                if (rez) { g_o2[k] = gate * go[k]; g_hres[k] = go[k]; g_gate_el[k] = go[k] * o2; }
+                else if (gated) {
+                    g_o2[k] = gate * go[k]; g_hres[k] = (1.f - gate) * go[k];
+                    g_gate_el[k] = gate_raw > 0.f ? go[k] * (o2 - h[(size_t)n * H + lane + 64 * k]) : 0.f;
+                } else { g_hres[k] = go[k]; }
+            }
+            dpart = fmaf(g_o2[k], ov[k], dpart);
+        }
+        float g_l = 0.f;
+        if (natt) g_l = pvs_att_act_grad(att_act, l, a) * pvs_group_sum<64>(dpart);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const size_t idx = (size_t)n * H + lane + 64 * k;
+            g_o[idx] = natt ? g_o2[k] * a + g_l * wna[k] : g_o2[k];
+            g_h[idx] = g_hres[k];
+            if (natt) t1[idx] = g_l * ov[k];
+            if (gated || rez) tg[idx] = g_gate_el[k];
+        }
+        if (natt && lane == 0) gl[n] = g_l;
+    }
+}
+
 __global__ void k_node_tail_bwd1(const float* __restrict__ g_u, const float* __restrict__ y1,
                                  const float* __restrict__ stats, PvsNodeW w, int N, int H,
                                  float* __restrict__ g_yn) {
@@ -248,6 +356,11 @@ int pvs_node_tail_fwd(hipStream_t s, const float* y1, const float* stats, const 
 int pvs_node_out_fwd(hipStream_t s, int H, const float* o, const float* h, const PvsNodeW& w,
                      uint32_t flags, int att_act, int N, float* h_out, float* natt_out) {
     const int blocks = ew_grid((long long)N * H);
+    if (H == 128) {
+        k_node_out_fwd_wide<2><<<blocks, 256, 0, s>>>(o, h, w, flags, att_act, N, h_out, natt_out);
+        PVS_CHECK_LAUNCH();
+        return 0;
+    }
     PVS_NODE_DISPATCH_H(H, {
         k_node_out_fwd<HH><<<blocks, 256, 0, s>>>(o, h, w, flags, att_act, N, h_out, natt_out);
     });
@@ -259,6 +372,11 @@ int pvs_node_out_bwd(hipStream_t s, int H, const float* g_hout, const float* o, 
                      const PvsNodeW& w, uint32_t flags, int att_act, int N, float* g_o, float* g_h,
                      float* gl, float* t1, float* tg) {
     const int blocks = ew_grid((long long)N * H);
+    if (H == 128) {
+        k_node_out_bwd_wide<2><<<blocks, 256, 0, s>>>(g_hout, o, h, w, flags, att_act, N, g_o, g_h, gl, t1, tg);
+        PVS_CHECK_LAUNCH();
+        return 0;
+    }
     PVS_NODE_DISPATCH_H(H, {
         k_node_out_bwd<HH><<<blocks, 256, 0, s>>>(g_hout, o, h, w, flags, att_act, N, g_o, g_h, gl,
                                                   t1, tg);

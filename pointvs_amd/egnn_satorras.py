@@ -165,7 +165,17 @@ class EGNNLayer(nn.Module):
             None if natt is None else natt.weight, None if natt is None else natt.bias,
             getattr(self, 'edge_gate_parameter', None), getattr(self, 'node_gate_parameter', None))
 
-    _KERNEL_WIDTHS = (16, 32, 64)
+    _KERNEL_WIDTHS = (16, 32, 64, 128)
+
+    def _fused_width_ok(self):
+        """Hidden sizes above 64 run on the fused 128-channel kernels (zero-padded: 65..127) - two launches of the
+        f16x2 edge forward and the four-wave fp32 team backward, built for the MFMA path with up to 3 edge classes.
+        PVS_WIDE=decomposed (or the generic kernel family, or more edge classes) takes the composition of the public
+        sub-methods instead."""
+        if self.hidden_nf <= 64:
+            return True
+        return (self.hidden_nf <= 128 and self.edges_in_d <= 3 and os.environ.get('PVS_WIDE') != 'decomposed'
+                and os.environ.get('PVS_EGNN_KERNELS', '')[:1] != 'g')
 
     def _padded_call(self, pg, h, coord, m_prev_sorted, need_m, flags=None):
         """Hidden sizes the kernels are not built for run zero-padded to the next built width.
@@ -213,7 +223,7 @@ class EGNNLayer(nn.Module):
         desc = self._desc()
         if skip_coords:
             desc = (desc[0], desc[1], desc[2] & ~_lib.UPDATE_COORDS, desc[3])
-        if self.hidden_nf > max(self._KERNEL_WIDTHS):
+        if not self._fused_width_ok():
             # wider than the fused kernels are built for: the layer as the composition of its public
             # sub-methods (dense products and segment reductions through the C ABI, per-edge glue as torch
             # ops on the HIP tensors), in CSR-sorted edge order

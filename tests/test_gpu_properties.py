@@ -105,13 +105,32 @@ def test_ragged_graphs_match_oracle(name, flags):
 
 @pytest.mark.parametrize('k', [96, 128])
 @pytest.mark.parametrize('flags', ['default', 'att_res'])
-def test_wide_layers_run_decomposed_and_match_oracle(k, flags):
-    """Hidden sizes above the fused kernels' 64 channels (the reference accepts any --channels) run as the
-    composition of the layer's public sub-methods on the prepared graph (EGNNLayer._decomposed_call): same
-    logits and gradients as the oracle, attention values and coordinates still available."""
+def test_wide_layers_run_decomposed_and_match_oracle(k, flags, monkeypatch):
+    """Hidden sizes above 64 channels (the reference accepts any --channels) can run as the composition of the
+    layer's public sub-methods on the prepared graph (EGNNLayer._decomposed_call; PVS_WIDE=decomposed selects it
+    since round 3, when the fused 128-channel kernels became the default): same logits and gradients as the oracle,
+    attention values and coordinates still available."""
+    monkeypatch.setenv('PVS_WIDE', 'decomposed')
+    _check_wide(k, flags)
+
+
+@pytest.mark.parametrize('k,flags', [(96, 'default'), (128, 'default'), (128, 'att_res'), (72, 'att_res'),
+                                     (128, 'softmax'), (100, 'rezero')])
+def test_wide_layers_run_fused_and_match_oracle(k, flags):
+    """Round 3: 64 < hidden <= 128 on the fused kernels at 128 channels (zero-padded below 128): the f16x2 edge
+    forward as two launches (one split weight matrix in LDS each, the messages handed over through memory) and the
+    four-wave fp32 team backward with coord_mlp.0's weight read from global memory. Oracle: fp64 autograd."""
+    _check_wide(k, flags)
+
+
+def _check_wide(k, flags):
     changes = dict(k=k, num_layers=2) if flags == 'default' else dict(
         k=k, num_layers=2, edge_attention=True, node_attention=True, residual=True, normalize=True, tanh=True,
         edge_residual=True, graphnorm=True)
+    if flags == 'softmax':
+        changes = dict(k=k, num_layers=2, edge_attention=True, softmax_attention=True, node_attention=True, residual=True)
+    if flags == 'rezero':
+        changes = dict(k=k, num_layers=3, edge_residual=True, rezero=True, residual=True, edge_attention=True)
     model, kw = make_model(seed=3, **changes)
     g = random_graph(300, 6000, seed=21, n_graphs=3)
     y, grads = gpu_run(model, g)
