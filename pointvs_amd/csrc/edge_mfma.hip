@@ -9,31 +9,20 @@ namespace {
 // gradients as products over the EDGE index (operands re-read edge-major from per-wave LDS tiles),
 // 96 MFMAs per 32x32 block in total. Vector gradients ride on the same LDS tiles with the channel
 // on the lane (one accumulator register each).
-template <int HB, bool ERES, bool EATT, bool BF16X3>
-__global__ void __launch_bounds__(BF16X3 ? 512 : kThreads, HB == 1 ? 2 : 1)
+template <int HB, bool ERES, bool EATT>
+__global__ void __launch_bounds__(kThreads, HB == 1 ? 2 : 1)
 k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks,
                 int e_lo, int e_hi) {
     constexpr int H = 32 * HB;
     constexpr int TS = H + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // fp32 path: W2 / Wc1 natural with padded rows (one copy serves W and W^T products)
-    // BF16X3 path (H = 32, 512 threads): 4 operand matrices x 3 parts x 2 k-steps x 1 KB
-    static_assert(!BF16X3 || HB == 1, "bf16x3 variant is built for H = 32");
-    constexpr int NT = BF16X3 ? 512 : kThreads;
+    // W2 / Wc1 natural with padded rows (one copy serves W and W^T products); exact fp32 MFMAs throughout: the
+    // arithmetic cross-check family of the tests. The split-product forms this kernel carried in rounds 1-2 are gone.
+    constexpr int NT = kThreads;
     constexpr int NW = NT / 64;
-#ifndef PVS_BWD_IMG
-#define PVS_BWD_IMG 1   // bf16x3: one weight image per matrix (W and W^T), SiLU'(z1) kept in LDS
-#endif
-    constexpr bool IMG = BF16X3 && PVS_BWD_IMG;
-    constexpr int kWeightWords = IMG ? 2 * 3 * H * H / 2 : (BF16X3 ? 4 * 6 * 64 * 4 : 2 * H * (H + 1));
-    unsigned short* W2i = reinterpret_cast<unsigned short*>(smem);
-    unsigned short* Wc1i = W2i + 3 * H * H;
+    constexpr int kWeightWords = 2 * H * (H + 1);
     float* W2n = smem;
     float* Wc1n = W2n + H * (H + 1);
-    unsigned* W2b = reinterpret_cast<unsigned*>(smem);      // z2 = W2 a1
-    unsigned* W2tb = W2b + 6 * 64 * 4;                      // g_a1 = W2^T g_z2
-    unsigned* Wc1b = W2tb + 6 * 64 * 4;                     // zc = Wc1 m
-    unsigned* Wc1tb = Wc1b + 6 * 64 * 4;                    // g_m += Wc1^T g_zc
     float* b2t = smem + kWeightWords;
     float* bc1t = b2t + H;
     float* wc2t = bc1t + H;
@@ -48,20 +37,8 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     constexpr bool eatt = EATT;
     constexpr bool eres = ERES;
 
-    if constexpr (IMG) {
-        stage_weights_img<HB>(W2i, w.w2);
-        if (upd) stage_weights_img<HB>(Wc1i, w.wc1);
-    } else if constexpr (BF16X3) {
-        stage_weights_bf16x3(W2b, w.w2, false);
-        stage_weights_bf16x3(W2tb, w.w2, true);
-        if (upd) {
-            stage_weights_bf16x3(Wc1b, w.wc1, false);
-            stage_weights_bf16x3(Wc1tb, w.wc1, true);
-        }
-    } else {
-        stage_weights_nat<HB>(W2n, w.w2);
-        if (upd) stage_weights_nat<HB>(Wc1n, w.wc1);
-    }
+    stage_weights_nat<HB>(W2n, w.w2);
+    if (upd) stage_weights_nat<HB>(Wc1n, w.wc1);
     for (int c = threadIdx.x; c < H; c += NT) {
         b2t[c] = w.b2[c];
         bc1t[c] = upd ? w.bc1[c] : 0.f;
@@ -81,9 +58,6 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     float* tx = T2 + kTile * TS;
     float* glb = tx + kTile * 4;
     int* rowbuf = reinterpret_cast<int*>(glb + kTile);
-    // IMG: SiLU'(z1) of the tile, X layout, private to the lane (4 KB per wave) instead of
-    // re-gathering and re-evaluating z1 after the W2^T product
-    float* d1b = wave_base + NW * kWaveFloats + wv * (16 * 64);
     const float bac = eatt ? w.ba[0] : 0.f;
     float gate_raw = 0.f, gate = 1.f;
     if (eres && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
@@ -155,25 +129,10 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
             {
                 float a1[HB][16];
                 assemble_z1<HB>(G, attrt, wrhot, ty, hh, rho, a1);
-                if constexpr (IMG) {
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        float dd[4];
+                for (int b = 0; b < HB; ++b)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float z = a1[0][4 * gq + q];
-                            const float sg = pvs_sigmoid(z);
-                            dd[q] = pvs_silu_grad(z, sg);
-                            a1[0][4 * gq + q] = z * sg;
-                        }
-                        *reinterpret_cast<float4*>(d1b + (gq * 64 + lane) * 4) = make_float4(dd[0], dd[1], dd[2], dd[3]);
-                    }
-                } else {
-#pragma unroll
-                    for (int b = 0; b < HB; ++b)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) a1[b][r] = pvs_silu(a1[b][r]);
-                }
+                    for (int r = 0; r < 16; ++r) a1[b][r] = pvs_silu(a1[b][r]);
                 // a1 edge-major in T0 for the W2 weight gradient (zero rows for padded slots)
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
@@ -189,9 +148,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[b][r] = bias[b][r];
-                if constexpr (IMG) mfma_chain_img<false>(W2i, lane, a1[0], acc2[0]);
-                else if constexpr (BF16X3) mfma_chain_bf16x3(W2b, lane, a1[0], acc2[0]);
-                else mfma_chain_nat<HB, false>(W2n, lane, a1, acc2, flags & kAblNoMfma);
+                mfma_chain_nat<HB, false>(W2n, lane, a1, acc2, flags & kAblNoMfma);
                 float dz2[HB][16], m[HB][16];     // SiLU'(z2) and the message
                 float m_new[ERES ? HB : 1][16], mp[ERES ? HB : 1][16];
 #pragma unroll
@@ -269,9 +226,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                     for (int b = 0; b < HB; ++b)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) accc[b][r] = bias2[b][r];
-                    if constexpr (IMG) mfma_chain_img<false>(Wc1i, lane, m[0], accc[0]);
-                    else if constexpr (BF16X3) mfma_chain_bf16x3(Wc1b, lane, m[0], accc[0]);
-                    else mfma_chain_nat<HB, false>(Wc1n, lane, m, accc, flags & kAblNoMfma);
+                    mfma_chain_nat<HB, false>(Wc1n, lane, m, accc, flags & kAblNoMfma);
                     float q[HB][16], dq[HB][16];
 #pragma unroll
                     for (int b = 0; b < HB; ++b)
@@ -304,9 +259,7 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                             *reinterpret_cast<float4*>(T2 + j * TS + 32 * b + 8 * gq + 4 * hh) =
                                 make_float4(g_zc[b][4 * gq], g_zc[b][4 * gq + 1], g_zc[b][4 * gq + 2],
                                             g_zc[b][4 * gq + 3]);
-                    if constexpr (IMG) mfma_chain_img<true>(Wc1i, lane, g_zc[0], gm[0]);   // g_m += Wc1^T g_zc
-                    else if constexpr (BF16X3) mfma_chain_bf16x3(Wc1tb, lane, g_zc[0], gm[0]);
-                    else mfma_chain_nat<HB, true>(Wc1n, lane, g_zc, gm, flags & kAblNoMfma);
+                    mfma_chain_nat<HB, true>(Wc1n, lane, g_zc, gm, flags & kAblNoMfma);      // g_m += Wc1^T g_zc
                 }
                 if (hh == 0) { glb[j] = g_l; rowbuf[j] = i; }
                 pvs_wave_lds_sync();
@@ -374,33 +327,20 @@ k_edge_bwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 // ---- g_a1 = W2^T g_z2 ; g_z1 = g_a1 * SiLU'(z1) ----
                 // SiLU'(z1): this tile's rows are re-gathered (L2-hot) under the W2^T product
                 // instead of holding z1 in 16 registers across the whole tile
-                if constexpr (!IMG) gather_tile<HB>(io.PQ, io.x, I, hh, G);
+                gather_tile<HB>(io.PQ, io.x, I, hh, G);
                 f32x16 ga1[HB];
 #pragma unroll
                 for (int b = 0; b < HB; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ga1[b][r] = 0.f;
-                if constexpr (IMG) mfma_chain_img<true>(W2i, lane, g_z2[0], ga1[0]);
-                else if constexpr (BF16X3) mfma_chain_bf16x3(W2tb, lane, g_z2[0], ga1[0]);
-                else mfma_chain_nat<HB, true>(W2n, lane, g_z2, ga1, flags & kAblNoMfma);
+                mfma_chain_nat<HB, true>(W2n, lane, g_z2, ga1, flags & kAblNoMfma);
                 float g_z1[HB][16];
-                if constexpr (IMG) {
+                assemble_z1<HB>(G, attrt, wrhot, ty, hh, rho, g_z1);
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const float4 dd = *reinterpret_cast<const float4*>(d1b + (gq * 64 + lane) * 4);
-                        g_z1[0][4 * gq] = ga1[0][4 * gq] * dd.x;
-                        g_z1[0][4 * gq + 1] = ga1[0][4 * gq + 1] * dd.y;
-                        g_z1[0][4 * gq + 2] = ga1[0][4 * gq + 2] * dd.z;
-                        g_z1[0][4 * gq + 3] = ga1[0][4 * gq + 3] * dd.w;
-                    }
-                } else {
-                    assemble_z1<HB>(G, attrt, wrhot, ty, hh, rho, g_z1);
+                for (int b = 0; b < HB; ++b)
 #pragma unroll
-                    for (int b = 0; b < HB; ++b)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            g_z1[b][r] = ga1[b][r] * pvs_silu_grad(g_z1[b][r], pvs_sigmoid(g_z1[b][r]));
-                }
+                    for (int r = 0; r < 16; ++r)
+                        g_z1[b][r] = ga1[b][r] * pvs_silu_grad(g_z1[b][r], pvs_sigmoid(g_z1[b][r]));
                 const float g_rho = dot_tab<HB>(wrhot, hh, g_z1);
                 const float k1 = s_coord * nrm * vm;
                 const float gd0 = fmaf(k1, gT0, 2.f * d0 * g_rho);
@@ -545,40 +485,6 @@ __device__ __forceinline__ void xwrite_block(float* __restrict__ T, int j, int h
             make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 }
 
-// acc (output block cb) += sum over input blocks bi of W(cb,bi) v_bi as six bf16 MFMA terms per
-// k-step; v_cb from registers, the other blocks from the tile T.
-template <int HB, bool TRANSPOSE>
-__device__ __forceinline__ void chain_team_b3(const unsigned short* __restrict__ img, int lane, int cb,
-                                              const float (&own)[16], const float* __restrict__ T,
-                                              f32x16& acc) {
-    constexpr int H = 32 * HB;
-    const int j = lane & 31, hh = lane >> 5;
-#pragma unroll
-    for (int bi = 0; bi < HB; ++bi) {
-        float v[16];
-        if (bi == cb) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) v[t] = own[t];
-        } else {
-            xread_block<HB>(T, j, hh, bi, v);
-        }
-        Bf16Parts b;
-        split_bf16x3(v, b);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const bf16x8 ah = img_fragment<HB, TRANSPOSE>(img, lane, cb, bi, s);
-            const bf16x8 am = img_fragment<HB, TRANSPOSE>(img + H * H, lane, cb, bi, s);
-            const bf16x8 al = img_fragment<HB, TRANSPOSE>(img + 2 * H * H, lane, cb, bi, s);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.hi[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.lo[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.mid[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.hi[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.mid[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.hi[s], acc, 0, 0, 0);
-        }
-    }
-}
-
 // acc (output block cb) += sum over input blocks bi of W(cb,bi) v_bi ; v_cb from registers, the
 // other blocks from the tile T. Wn natural padded [H][H+1]; TRANSPOSE: W^T.
 // GLOBAL (H = 128: two fp32 weight matrices do not fit in 160 KB of LDS beside the team's tiles): Wn points at
@@ -631,22 +537,18 @@ __device__ __forceinline__ void load16_tab(const float* __restrict__ tab, int hh
     }
 }
 
-template <int HB, bool ERES, bool EATT, bool BF16X3 = false, int NT = 64 * HB>
+template <int HB, bool ERES, bool EATT, int NT = 64 * HB>
 __global__ void __launch_bounds__(NT, 1)
 k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks,
                 int e_lo, int e_hi, const float* __restrict__ wc1_pair) {
     constexpr int H = 32 * HB, TS = H + 4, NW = NT / 64, TEAMS = NW / HB;
     // H = 128: W2 in LDS, Wc1 (both orientations) from global memory (wc1_pair, chain_team<.., GLOBAL>)
     constexpr bool WC1G = HB > 2;
-    static_assert(!(WC1G && BF16X3), "the wide team kernel is fp32 only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // fp32: natural padded weights [H][H+1] serving W and W^T; BF16X3: one swizzled bf16 image per
-    // part (3 x H*H x 2 B per matrix), also serving both
-    constexpr int kWeightFloats = BF16X3 ? 2 * 3 * H * H / 2 : (WC1G ? 1 : 2) * H * (H + 1);
+    // natural padded weights [H][H+1] serving W and W^T (exact fp32 MFMAs throughout)
+    constexpr int kWeightFloats = (WC1G ? 1 : 2) * H * (H + 1);
     float* W2n = smem;
     float* Wc1n = W2n + H * (H + 1);
-    unsigned short* W2i = reinterpret_cast<unsigned short*>(smem);
-    unsigned short* Wc1i = W2i + 3 * H * H;
     float* b2t = smem + kWeightFloats;
     float* bc1t = b2t + H;
     float* wc2t = bc1t + H;
@@ -661,13 +563,8 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
 
     const bool upd = (flags & PVS_UPDATE_COORDS) && io.gxagg != nullptr;
 
-    if constexpr (BF16X3) {
-        stage_weights_img<HB>(W2i, w.w2);
-        if (upd) stage_weights_img<HB>(Wc1i, w.wc1);
-    } else {
-        stage_weights_nat<HB>(W2n, w.w2);
-        if (upd && !WC1G) stage_weights_nat<HB>(Wc1n, w.wc1);
-    }
+    stage_weights_nat<HB>(W2n, w.w2);
+    if (upd && !WC1G) stage_weights_nat<HB>(Wc1n, w.wc1);
     for (int c = threadIdx.x; c < H; c += NT) {
         b2t[c] = w.b2[c];
         bc1t[c] = upd ? w.bc1[c] : 0.f;
@@ -820,8 +717,7 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 load16_tab(b2t + co, hh, bias);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[r] = bias[r];
-                if constexpr (BF16X3) chain_team_b3<HB, false>(W2i, lane, cb, a1, T0, acc2);
-                else chain_team<HB, false>(W2n, lane, cb, a1, T0, acc2);
+                chain_team<HB, false>(W2n, lane, cb, a1, T0, acc2);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float z2 = acc2[r];
@@ -880,8 +776,7 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 load16_tab(bc1t + co, hh, bias2);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accc[r] = bias2[r];
-                if constexpr (BF16X3) chain_team_b3<HB, false>(Wc1i, lane, cb, m, T1, accc);
-                else if constexpr (WC1G) chain_team<HB, false, true>(wc1_pair, lane, cb, m, T1, accc);
+                if constexpr (WC1G) chain_team<HB, false, true>(wc1_pair, lane, cb, m, T1, accc);
                 else chain_team<HB, false>(Wc1n, lane, cb, m, T1, accc);
                 float q[16], dq[16];
 #pragma unroll
@@ -910,8 +805,7 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 }
                 xwrite_block<HB>(T2, j, hh, cb, g_zc);
                 __syncthreads();                                                 // (4) T2 = g_zc complete
-                if constexpr (BF16X3) chain_team_b3<HB, true>(Wc1i, lane, cb, g_zc, T2, gm);   // g_m += Wc1^T g_zc
-                else if constexpr (WC1G) chain_team<HB, true, true>(wc1_pair, lane, cb, g_zc, T2, gm);
+                if constexpr (WC1G) chain_team<HB, true, true>(wc1_pair, lane, cb, g_zc, T2, gm);
                 else chain_team<HB, true>(Wc1n, lane, cb, g_zc, T2, gm);
             } else if (EATT) {
                 __syncthreads();                                                 // glb visible
@@ -970,8 +864,7 @@ k_edge_bwd_team(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
             f32x16 ga1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ga1[r] = 0.f;
-            if constexpr (BF16X3) chain_team_b3<HB, true>(W2i, lane, cb, g_z2, T2, ga1);
-            else chain_team<HB, true>(W2n, lane, cb, g_z2, T2, ga1);
+            chain_team<HB, true>(W2n, lane, cb, g_z2, T2, ga1);
             float g_z1[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) g_z1[r] = ga1[r] * sd1[r];
@@ -1138,8 +1031,8 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
         const bool eatt = flags & PVS_EDGE_ATTENTION;
 #define PVS_WIDE_LAUNCH(ER, EA)                                                                    \
     do {                                                                                          \
-        if (set_lds(k_edge_bwd_team<4, ER, EA, false>, tlds)) return -2;                          \
-        k_edge_bwd_team<4, ER, EA, false><<<blocks, 256, tlds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi, io.wpair); \
+        if (set_lds(k_edge_bwd_team<4, ER, EA>, tlds)) return -2;                          \
+        k_edge_bwd_team<4, ER, EA><<<blocks, 256, tlds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi, io.wpair); \
     } while (0)
         if (eres && eatt) PVS_WIDE_LAUNCH(true, true);
         else if (eres) PVS_WIDE_LAUNCH(true, false);
@@ -1185,8 +1078,8 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     if (H == 32) {
 #define PVS_BWD_LAUNCH(ER, EA)                                                                      \
     do {                                                                                           \
-        if (set_lds(k_edge_bwd_mfma<1, ER, EA, false>, lds)) return -2;                            \
-        k_edge_bwd_mfma<1, ER, EA, false><<<blocks, nt, lds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi); \
+        if (set_lds(k_edge_bwd_mfma<1, ER, EA>, lds)) return -2;                            \
+        k_edge_bwd_mfma<1, ER, EA><<<blocks, nt, lds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi); \
     } while (0)
         if (eres && eatt) PVS_BWD_LAUNCH(true, true);
         else if (eres) PVS_BWD_LAUNCH(true, false);
@@ -1213,8 +1106,8 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
         const size_t tlds = tw * sizeof(float);
 #define PVS_TEAM_LAUNCH(ER, EA)                                                                    \
     do {                                                                                          \
-        if (set_lds(k_edge_bwd_team<2, ER, EA, false>, tlds)) return -2;                          \
-        k_edge_bwd_team<2, ER, EA, false><<<blocks, 128, tlds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi, nullptr); \
+        if (set_lds(k_edge_bwd_team<2, ER, EA>, tlds)) return -2;                          \
+        k_edge_bwd_team<2, ER, EA><<<blocks, 128, tlds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, e_hi, nullptr); \
     } while (0)
         if (eres && eatt) PVS_TEAM_LAUNCH(true, true);
         else if (eres) PVS_TEAM_LAUNCH(true, false);

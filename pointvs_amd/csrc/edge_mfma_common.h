@@ -300,50 +300,6 @@ __device__ __forceinline__ void split_bf16x3(const float (&v)[16], Bf16Parts& ou
     }
 }
 
-// Stage W[32][32] (row-major, W[out][in]) as bf16x3 A operands: dst[((part*2 + s)*64 + l)*4 .. +3]
-// (uint words) = 8 bf16 of W[l&31][ch(8s + j', l>>5)], j' = 0..7, part in {hi, mid, lo}.
-// ld / row0 / col0: the 32x32 block W[row0 + .][col0 + .] of a matrix with row stride ld.
-__device__ __forceinline__ void stage_weights_bf16x3(unsigned* dst, const float* __restrict__ W,
-                                                     bool transpose = false, int ld = 32, int row0 = 0,
-                                                     int col0 = 0) {
-    // transpose: operand rows are the columns of W (Z = W^T V)
-    W += (size_t)row0 * ld + col0;
-    for (int i = threadIdx.x; i < 2 * 64 * 4; i += blockDim.x) {
-        const int q = i & 3, l = (i >> 2) & 63, s = i >> 8;
-        const int o = l & 31, hh = l >> 5;
-        const int k0 = xch(8 * s + 2 * q, hh), k1 = xch(8 * s + 2 * q + 1, hh);
-        const float x0 = transpose ? W[k0 * ld + o] : W[o * ld + k0];
-        const float x1 = transpose ? W[k1 * ld + o] : W[o * ld + k1];
-        const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
-        const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
-        const float t0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
-        const float t1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-        dst[((0 * 2 + s) * 64 + l) * 4 + q] = pvs_pack_hi16(x0, x1);
-        dst[((1 * 2 + s) * 64 + l) * 4 + q] = pvs_pack_hi16(r0, r1);
-        dst[((2 * 2 + s) * 64 + l) * 4 + q] = pvs_pack_hi16(t0, t1);
-    }
-}
-
-__device__ __forceinline__ void mfma_chain_bf16x3(const unsigned* __restrict__ Wb, int lane,
-                                                  const float (&v)[16], f32x16& acc) {
-    Bf16Parts b;
-    split_bf16x3(v, b);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wb + ((0 * 2 + s) * 64 + lane) * 4));
-        const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wb + ((1 * 2 + s) * 64 + lane) * 4));
-        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wb + ((2 * 2 + s) * 64 + lane) * 4));
-        // smallest terms first
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.hi[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.lo[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.mid[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.hi[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.mid[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.hi[s], acc, 0, 0, 0);
-    }
-}
-
-
 // ---- bf16x3 weights as ONE swizzled row-major image per part, read row-wise for W v and, through
 // ds_read_b64_tr_b16 (gfx950's transposing LDS read), column-wise for W^T v: half the LDS of two
 // pre-transposed copies. Element (r, c) of W [H][H] sits at 16-bit index
@@ -356,26 +312,6 @@ template <int HB>
 __device__ __forceinline__ int img_off(int r, int c) {
     constexpr int H = 32 * HB, NCH = H / 4, RPC = 128 / H;
     return r * H + 4 * ((c >> 2) ^ ((r / RPC) & (NCH - 1))) + (c & 3);
-}
-
-template <int HB>
-__device__ __forceinline__ void stage_weights_img(unsigned short* img, const float* __restrict__ W) {
-    constexpr int H = 32 * HB;
-    unsigned* hi = reinterpret_cast<unsigned*>(img);
-    unsigned* mid = reinterpret_cast<unsigned*>(img + H * H);
-    unsigned* lo = reinterpret_cast<unsigned*>(img + 2 * H * H);
-    for (int i = threadIdx.x; i < H * H / 2; i += blockDim.x) {
-        const int r = (2 * i) / H, c = (2 * i) % H;
-        const float x0 = W[r * H + c], x1 = W[r * H + c + 1];
-        const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
-        const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
-        const float t0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
-        const float t1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-        const int o = img_off<HB>(r, c) >> 1;
-        hi[o] = pvs_pack_hi16(x0, x1);
-        mid[o] = pvs_pack_hi16(r0, r1);
-        lo[o] = pvs_pack_hi16(t0, t1);
-    }
 }
 
 // A-operand fragment (8 bf16 in the k order of the X layout) of block (bo, bi), k-step s, of one part
@@ -408,64 +344,6 @@ __device__ __forceinline__ bf16x8 img_fragment(const unsigned short* __restrict_
                                                int bi, int s) {
     return __builtin_bit_cast(bf16x8, img_fragment_bits<HB, TRANSPOSE>(part, lane, bo, bi, s));
 }
-
-// acc += W v (TRANSPOSE: W^T v) for H = 32 with the weights as one image per part
-template <bool TRANSPOSE>
-__device__ __forceinline__ void mfma_chain_img(const unsigned short* __restrict__ img, int lane,
-                                               const float (&v)[16], f32x16& acc) {
-    Bf16Parts b;
-    split_bf16x3(v, b);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const bf16x8 ah = img_fragment<1, TRANSPOSE>(img, lane, 0, 0, s);
-        const bf16x8 am = img_fragment<1, TRANSPOSE>(img + 32 * 32, lane, 0, 0, s);
-        const bf16x8 al = img_fragment<1, TRANSPOSE>(img + 2 * 32 * 32, lane, 0, 0, s);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.hi[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.lo[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.mid[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.hi[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.mid[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.hi[s], acc, 0, 0, 0);
-    }
-}
-
-// H = 32*HB: all HB x HB blocks of W (row-major [H][H]) staged block after block ((bo*HB + bi) * 6 KB),
-// and the product acc[bo] += sum_bi W[bo][bi] v[bi] with each input block split once.
-template <int HB>
-__device__ __forceinline__ void stage_weights_bf16x3_blocks(unsigned* dst, const float* __restrict__ W) {
-#pragma unroll
-    for (int bo = 0; bo < HB; ++bo)
-#pragma unroll
-        for (int bi = 0; bi < HB; ++bi)
-            stage_weights_bf16x3(dst + (bo * HB + bi) * (6 * 64 * 4), W, false, 32 * HB, 32 * bo, 32 * bi);
-}
-
-template <int HB>
-__device__ __forceinline__ void mfma_chain_bf16x3_blocks(const unsigned* __restrict__ Wb, int lane,
-                                                         const float (&v)[HB][16], f32x16 (&acc)[HB]) {
-#pragma unroll
-    for (int bi = 0; bi < HB; ++bi) {
-        Bf16Parts b;
-        split_bf16x3(v[bi], b);
-#pragma unroll
-        for (int bo = 0; bo < HB; ++bo) {
-            const unsigned* Wblk = Wb + (bo * HB + bi) * (6 * 64 * 4);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wblk + ((0 * 2 + s) * 64 + lane) * 4));
-                const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wblk + ((1 * 2 + s) * 64 + lane) * 4));
-                const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wblk + ((2 * 2 + s) * 64 + lane) * 4));
-                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.hi[s], acc[bo], 0, 0, 0);
-                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.lo[s], acc[bo], 0, 0, 0);
-                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.mid[s], acc[bo], 0, 0, 0);
-                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.hi[s], acc[bo], 0, 0, 0);
-                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.mid[s], acc[bo], 0, 0, 0);
-                acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.hi[s], acc[bo], 0, 0, 0);
-            }
-        }
-    }
-}
-
 
 // ---- fp32 products as 3 fp16 MFMA terms ("f16x2", round 3) ------------------------------------------
 // x*s = hi + lo with hi = fp16(x*s) (round to nearest) and lo = fp16(x*s - hi): 22 significant bits in two
@@ -571,7 +449,7 @@ __device__ __forceinline__ void split_f16x2(const float (&v)[16], float s, F16Pa
 }
 
 // W [H][H] (row-major) * s as two swizzled row-major fp16 images (hi at img, lo at img + H*H), the layout of
-// stage_weights_img: rows through ds_read_b64 for W v, columns through ds_read_b64_tr_b16 for W^T v.
+// img_off: rows through ds_read_b64 for W v, columns through ds_read_b64_tr_b16 for W^T v.
 template <int HB>
 __device__ __forceinline__ void stage_weights_img_f16(unsigned short* img, const float* __restrict__ W, float s) {
     constexpr int H = 32 * HB;

@@ -23,7 +23,7 @@ namespace {
 // MODE (H = 128, where two split weight matrices do not fit in LDS beside the waves' tiles: the layer's edge forward runs
 // as two launches): 0 everything; 1 everything but the coordinate branch, with only W2 staged - the messages go to
 // io.m_out; 2 the coordinate branch alone, with only Wc1 staged - it reads the messages back from io.m_out.
-template <int HB, bool BF16X3, int NT = kThreads, bool SOFT = false, bool F16X2 = false, int MODE = 0>
+template <int HB, int NT = kThreads, bool SOFT = false, bool F16X2 = false, int MODE = 0>
 __global__ void __launch_bounds__(NT, (F16X2 && HB == 1) ? 4 : (F16X2 && NT == 768) ? 3 : 1)
 k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdIO io, int n_chunks,
                 int e_lo, int e_hi) {
@@ -33,10 +33,9 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
     if (g.n_edges_dev) e_hi = min(e_hi, *g.n_edges_dev);   // edge count only known on the device
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NW = NT / 64;
-    static_assert(!(BF16X3 && F16X2), "one split scheme at a time");
-    constexpr int kBlkWords = F16X2 ? 4 * 64 * 4 : 6 * 64 * 4;      // one 32x32 block as f16x2: 4 KB, bf16x3: 6 KB
+    constexpr int kBlkWords = 4 * 64 * 4;      // one 32x32 block as f16x2: 4 KB
     constexpr int kMats = MODE == 0 ? 2 : 1;
-    constexpr int kWeightWords = (BF16X3 || F16X2) ? kMats * HB * HB * kBlkWords + (F16X2 ? 4 : 0) : 2 * H * H;
+    constexpr int kWeightWords = F16X2 ? kMats * HB * HB * kBlkWords + 4 : 2 * H * H;
     float* W2s = smem;
     float* Wc1s = W2s + H * H;
     float* b2t = smem + kWeightWords;
@@ -54,7 +53,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
     constexpr bool soft = SOFT;      // softmax attention: its own instantiation (keeps the others' registers)
     const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
 
-    // BF16X3: each 32x32 block takes 3 parts x 2 k-steps x 64 lanes x 16 B = 6 KB
+    // F16X2: each 32x32 block takes 2 parts x 2 k-steps x 64 lanes x 16 B = 4 KB
     unsigned* W2b = reinterpret_cast<unsigned*>(W2s);
     unsigned* Wc1b = MODE == 0 ? W2b + HB * HB * kBlkWords : W2b;      // (one matrix per launch: the same slot)
     float inv_sw2 = 1.f, inv_swc1 = 1.f;
@@ -69,9 +68,6 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
         const float swc1 = pvs_f16_scale(wmax[1], &inv_swc1);
         if (MODE != 2) stage_weights_f16x2_blocks<HB>(W2b, w.w2, sw2);
         if (upd) stage_weights_f16x2_blocks<HB>(Wc1b, w.wc1, swc1);
-    } else if constexpr (BF16X3) {
-        stage_weights_bf16x3_blocks<HB>(W2b, w.w2);
-        if (upd) stage_weights_bf16x3_blocks<HB>(Wc1b, w.wc1);
     } else {
         stage_weights<HB>(W2s, w.w2, false);
         if (upd) stage_weights<HB>(Wc1s, w.wc1, false);
@@ -200,8 +196,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                     for (int b = 0; b < HB; ++b)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc2[b][r] = bias[b][r];
-                    if constexpr (BF16X3) mfma_chain_bf16x3_blocks<HB>(W2b, lane, a1, acc2);
-                    else mfma_chain<HB>(W2s, lane, a1, acc2, flags & kAblNoMfma);
+                    mfma_chain<HB>(W2s, lane, a1, acc2, flags & kAblNoMfma);
 #pragma unroll
                     for (int b = 0; b < HB; ++b)
 #pragma unroll
@@ -258,8 +253,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                     for (int b = 0; b < HB; ++b)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) accc[b][r] = bias[b][r];
-                    if constexpr (BF16X3) mfma_chain_bf16x3_blocks<HB>(Wc1b, lane, m, accc);
-                    else mfma_chain<HB>(Wc1s, lane, m, accc, flags & kAblNoMfma);
+                    mfma_chain<HB>(Wc1s, lane, m, accc, flags & kAblNoMfma);
 #pragma unroll
                     for (int b = 0; b < HB; ++b)
 #pragma unroll
@@ -380,16 +374,16 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
         PvsEdgeFwdIO io1 = io;
         io1.m_out = upd ? mbuf : io.m_out;
         if (soft) {
-            if (set_lds(k_edge_fwd_mfma<4, false, kThreads, true, true, 1>, lds)) return -2;
-            k_edge_fwd_mfma<4, false, kThreads, true, true, 1><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io1, n_chunks, 0, g.n_edges);
+            if (set_lds(k_edge_fwd_mfma<4, kThreads, true, true, 1>, lds)) return -2;
+            k_edge_fwd_mfma<4, kThreads, true, true, 1><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io1, n_chunks, 0, g.n_edges);
         } else {
-            if (set_lds(k_edge_fwd_mfma<4, false, kThreads, false, true, 1>, lds)) return -2;
-            k_edge_fwd_mfma<4, false, kThreads, false, true, 1><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io1, n_chunks, 0, g.n_edges);
+            if (set_lds(k_edge_fwd_mfma<4, kThreads, false, true, 1>, lds)) return -2;
+            k_edge_fwd_mfma<4, kThreads, false, true, 1><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io1, n_chunks, 0, g.n_edges);
         }
         PVS_CHECK_LAUNCH();
         if (upd) {
-            if (set_lds(k_edge_fwd_mfma<4, false, kThreads, false, true, 2>, lds)) return -2;
-            k_edge_fwd_mfma<4, false, kThreads, false, true, 2><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io1, n_chunks, 0, g.n_edges);
+            if (set_lds(k_edge_fwd_mfma<4, kThreads, false, true, 2>, lds)) return -2;
+            k_edge_fwd_mfma<4, kThreads, false, true, 2><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io1, n_chunks, 0, g.n_edges);
             PVS_CHECK_LAUNCH();
         }
         if (soft) return pvs_launch_softmax_finalize(s, g, io.smax, io.ssum, io.att_out);
@@ -415,8 +409,8 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     const bool soft = (flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT);
 #define PVS_FWD_LAUNCH(HBV, NTV, SF, F16)                                                            \
     do {                                                                                            \
-        if (set_lds(k_edge_fwd_mfma<HBV, false, NTV, SF, F16>, lds)) return -2;                     \
-        k_edge_fwd_mfma<HBV, false, NTV, SF, F16><<<blocks, NTV, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges); \
+        if (set_lds(k_edge_fwd_mfma<HBV, NTV, SF, F16>, lds)) return -2;                     \
+        k_edge_fwd_mfma<HBV, NTV, SF, F16><<<blocks, NTV, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges); \
     } while (0)
 #define PVS_FWD_PICK(HBV, NTV, F16)                       \
     do {                                                  \

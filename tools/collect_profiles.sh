@@ -1,0 +1,24 @@
+#!/bin/bash
+# Copy the summaries of tools/final_pass.sh <tag> from gpurun_out/ into profiles/ (what the judge reads).
+# usage: tools/collect_profiles.sh <tag>
+tag=$1; src=gpurun_out/final_$tag; dst=profiles
+cp $src/bench_cfg2.json $dst/${tag}_bench_cfg2.json
+cp $src/bench_cfg3.json $dst/${tag}_bench_cfg3.json
+cp $src/bench_cfg2_infer.json $dst/${tag}_bench_cfg2_infer.json
+cp $src/bench_cfg5.json $dst/${tag}_bench_cfg5_sweep12800.json
+cp $src/bench_cfg5_sweep100000.json $dst/${tag}_bench_cfg5_sweep100000.json 2>/dev/null
+cp $src/bench_cfg2_skip.json $dst/${tag}_bench_cfg2_skip_dead_coords.json
+cp $src/bench_cfg2_gpus2_gloo_shared_gpu.json $dst/${tag}_bench_cfg2_gpus2_gloo_shared_gpu.json
+for c in cfg2 cfg3 cfg5; do
+  cp $src/prof_$c.json $dst/${tag}_profiled_bench_$c.json
+  f=$(ls $src/prof_$c/*/*kernel_stats.csv | head -1); cp $f $dst/${tag}_bench_${c}_kernel_stats.csv
+done
+cp $src/pmc_sq_summary.txt $dst/${tag}_cfg2_pmc_sq.txt
+cp $src/pmc_sq_cfg3_summary.txt $dst/${tag}_cfg3_pmc_sq.txt
+cp $src/pmc_lat.txt $dst/${tag}_cfg2_pmc_instruction_classes.txt
+for c in cfg2 cfg3 cfg5; do cp gpurun_out/${tag}_${c}_traffic.json $dst/${tag}_${c}_traffic.json 2>/dev/null; done
+cp $src/soak_alone.json $dst/${tag}_soak_alone.json
+cp $src/soak_load.json $dst/${tag}_soak_concurrent_gpu_load.json
+cp $src/soak_poison.json $dst/${tag}_soak_poisoned_allocator.json
+cp $src/variants.txt $dst/${tag}_variants_backward_timings.txt
+ls $dst | grep "^${tag}_" | wc -l

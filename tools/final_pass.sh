@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 python3 bench.py --steps 20 --warmup 5 > $out/bench_cfg2.json 2> $out/bench_cfg2.err
 python3 bench.py --config cfg3 --no-cpu-baseline > $out/bench_cfg3.json 2>/dev/null
 python3 bench.py --infer --no-cpu-baseline > $out/bench_cfg2_infer.json 2>/dev/null
-python3 bench.py --config cfg5 --sweep 12500 > $out/bench_cfg5.json 2>/dev/null
+python3 bench.py --config cfg5 --sweep 12800 > $out/bench_cfg5.json 2>/dev/null
 python3 bench.py --skip-dead-coords --no-cpu-baseline > $out/bench_cfg2_skip.json 2>/dev/null
 PVS_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 5 --warmup 2 > $out/bench_cfg2_gpus2_gloo_shared_gpu.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg2 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/prof_cfg2.json 2> $out/prof_cfg2.err
@@ -25,3 +25,11 @@ tools/pmc_sq.sh ${tag}_cfg3 --config cfg3 > $out/pmc_sq_cfg3.log 2>&1
 python3 tools/pmc_summary.py gpurun_out/pmc_${tag}_cfg3 k_edge_bwd k_edge_fwd k_node_gather > $out/pmc_sq_cfg3_summary.txt 2>&1
 find gpurun_out/pmc_${tag} gpurun_out/pmc_${tag}_cfg3 gpurun_out/traffic_${tag}_cfg2 gpurun_out/traffic_${tag}_cfg5 gpurun_out/traffic_${tag}_cfg3 -name '*.csv' -size +1M -delete
 for f in $out/bench_*.json $out/prof_cfg*.json; do echo "$f: $(cut -c1-260 $f | grep -o '"value": [0-9.]*')"; done
+# round 3 additions: soak (reproducibility of every kernel family), latency / instruction-class counters, variants
+python3 tools/soak.py --repeats 300 --states clean --out $out/soak_alone.json > $out/soak_alone.log 2>&1
+python3 tools/soak.py --repeats 300 --states clean --load --out $out/soak_load.json > $out/soak_load.log 2>&1
+python3 tools/soak.py --repeats 40 --states nan,garbage --out $out/soak_poison.json > $out/soak_poison.log 2>&1
+tools/pmc_lat.sh ${tag} > $out/pmc_lat.txt 2>&1
+find gpurun_out/pmc_lat_${tag} -name '*.csv' -size +1M -delete
+tools/variants_r3b.sh $out/variants.txt > /dev/null 2>&1
+python3 bench.py --config cfg5 --sweep 100000 --no-cpu-baseline > $out/bench_cfg5_sweep100000.json 2>/dev/null
