@@ -82,6 +82,11 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
 // operands through transposing LDS reads (edge_bwd_f16.hip, round 3); same contract
 int pvs_launch_edge_bwd_f16(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags, int att_act,
                             const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs);
+// H = 128 backward (hidden sizes 65..128): a team of four waves per tile on the f16x2 arithmetic (edge_bwd_wide.hip);
+// same contract, io.wpair = pvs_edge_bwd_wide_scratch_floats() floats of scratch
+size_t pvs_edge_bwd_wide_scratch_floats();
+int pvs_launch_edge_bwd_wide(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags, int att_act,
+                             const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs);
 // H = 64 backward, one wave per 16-edge tile with 16x16x32 chain products (edge_bwd_h64.hip); same contract
 int pvs_launch_edge_bwd_h64(hipStream_t s, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags, int att_act,
                             const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs);

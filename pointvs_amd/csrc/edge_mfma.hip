@@ -1004,9 +1004,15 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     *n_slabs = 0;
     if (e_hi <= e_lo) return 0;
     if (H == 128) {
-        // The wide layer (64 < hidden <= 128, padded to 128): a team of FOUR waves per 32-edge tile, exact fp32 MFMAs,
-        // W2 in LDS and Wc1 in both orientations from global memory (two fp32 128x128 matrices do not fit beside the
-        // team's 51 KB of tiles). One team per 256-thread block, one block per CU.
+        // The wide layer (64 < hidden <= 128, padded to 128). Default: the four-wave team on three-term fp16 products
+        // (edge_bwd_wide.hip). PVS_EGNN_BF16X3=0: the same team layout on exact fp32 MFMAs - the cross-check family -
+        // with W2 in LDS and Wc1 in both orientations from global memory (two fp32 128x128 matrices do not fit beside
+        // the team's 51 KB of tiles). One team per 256-thread block, one block per CU.
+        {
+            const char* bfw = getenv("PVS_EGNN_BF16X3");
+            if (!(bfw && bfw[0] == '0'))
+                return pvs_launch_edge_bwd_wide(s, H, g, w, flags, att_act, io, e_lo, e_hi, n_slabs);
+        }
         PVS_REQUIRE(io.wpair, "H = 128 edge backward needs the weight-pair scratch");
         const bool upd = (flags & PVS_UPDATE_COORDS) && io.gxagg != nullptr;
         if (upd) {

@@ -154,7 +154,8 @@ size_t carve_bwd(PvsArena& a, const Dims& m, BwdWs* w) {
     t.nslabs = a.take<float>((size_t)2048 * 4 * m.H);      // one [4H] slab per workgroup of the column gather
     t.nsum = a.take<float>(4 * (size_t)m.H);
     t.wslabs = a.take<float>(pvs_node_wgrads_supported(m.H) ? pvs_node_wgrads_slab_floats(m.N, m.H) : 4);
-    t.wpair = a.take<float>(m.H > 64 ? 2 * (size_t)m.H * m.H : 4);      // H = 128: coord_mlp.0's weight and its transpose
+    // H = 128: coord_mlp.0's weight staged per launch for the team backward (split A operands, or the fp32 pair)
+    t.wpair = a.take<float>(m.H > 64 ? pvs_edge_bwd_wide_scratch_floats() + 2 * (size_t)m.H * m.H : 4);
     if (w) *w = t;
     return a.off;
 }

@@ -123,6 +123,15 @@ def test_wide_layers_run_fused_and_match_oracle(k, flags):
     _check_wide(k, flags)
 
 
+@pytest.mark.parametrize('k,flags', [(128, 'att_res'), (80, 'default')])
+def test_wide_layers_fp32_family_matches_oracle(k, flags, monkeypatch):
+    """PVS_EGNN_BF16X3=0 at 128 channels: the four-wave team backward on exact fp32 MFMAs (coord_mlp.0's weight read
+    from global memory) - the arithmetic cross-check of the f16x2 team backward (the forward has no fp32 form at this
+    width: two fp32 128x128 matrices do not fit in LDS)."""
+    monkeypatch.setenv('PVS_EGNN_BF16X3', '0')
+    _check_wide(k, flags)
+
+
 def _check_wide(k, flags):
     changes = dict(k=k, num_layers=2) if flags == 'default' else dict(
         k=k, num_layers=2, edge_attention=True, node_attention=True, residual=True, normalize=True, tanh=True,
