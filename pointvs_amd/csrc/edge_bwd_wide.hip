@@ -22,10 +22,14 @@
 
 namespace {
 
-constexpr int kWHB = 4, kWH = 128;
-constexpr int kWPart = 32 * kWH;                  // one fp16 part image of a [32 edges][128 channels] tensor (shorts)
-constexpr int kWImg = 2 * kWPart;                 // hi + lo
-constexpr int kWTS = kWH + 4;                     // g_z1 tile row stride (floats)
+constexpr int kWH = 128;                          // (the staging kernel of the global weight copies: H = 128 only)
+template <int HB>
+struct WideDims {
+    static constexpr int H = 32 * HB;
+    static constexpr int kPart = 32 * H;          // one fp16 part image of a [32 edges][H channels] tensor (shorts)
+    static constexpr int kImg = 2 * kPart;        // hi + lo
+    static constexpr int kTS = H + 4;             // g_z1 tile row stride (floats)
+};
 // global A-operand copies of Wc1: [orientation 2][part 2][bo 4][bi 4][ks 2][64 lanes][4 words] + a header
 constexpr int kWFragWords = 64 * 4;
 constexpr int kWCopyWords = 2 * 2 * 4 * 4 * 2 * kWFragWords;      // 32,768 words = 128 KB
@@ -64,21 +68,22 @@ __device__ __forceinline__ f16x8 wide_gfrag(const unsigned* __restrict__ body, i
     return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(body + frag * kWFragWords + lane * 4));
 }
 
-template <bool TRANSPOSE>
+template <int HB, bool TRANSPOSE>
 __device__ __forceinline__ f16x8 wide_frag(const unsigned short* __restrict__ part, int lane, int bo, int bi, int s) {
-    return __builtin_bit_cast(f16x8, img_fragment_bits<kWHB, TRANSPOSE>(part, lane, bo, bi, s));
+    return __builtin_bit_cast(f16x8, img_fragment_bits<HB, TRANSPOSE>(part, lane, bo, bi, s));
 }
 
 // own block of a tensor (X layout) -> the team's image pair
+template <int HB>
 __device__ __forceinline__ void wide_write_image(unsigned short* __restrict__ img, int j, int hh, int cb, const F16Parts& b) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        unsigned short* part = img + p * kWPart;
+        unsigned short* part = img + p * WideDims<HB>::kPart;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const uint4 u = __builtin_bit_cast(uint4, p ? b.lo[s] : b.hi[s]);
-            *reinterpret_cast<uint2*>(part + img_off<kWHB>(j, 32 * cb + 16 * s + 4 * hh)) = make_uint2(u.x, u.y);
-            *reinterpret_cast<uint2*>(part + img_off<kWHB>(j, 32 * cb + 16 * s + 8 + 4 * hh)) = make_uint2(u.z, u.w);
+            *reinterpret_cast<uint2*>(part + img_off<HB>(j, 32 * cb + 16 * s + 4 * hh)) = make_uint2(u.x, u.y);
+            *reinterpret_cast<uint2*>(part + img_off<HB>(j, 32 * cb + 16 * s + 8 + 4 * hh)) = make_uint2(u.z, u.w);
         }
     }
 }
@@ -86,7 +91,7 @@ __device__ __forceinline__ void wide_write_image(unsigned short* __restrict__ im
 // acc (output block cb) += sum over the input blocks of (W s_w)(cb, bi) (v s_v)_bi, three terms each; the own block's
 // parts from registers, the others from the team's image. LDSW: W as image pair in LDS (TRANSPOSE through the
 // transposing read); else W from the global A-operand copies (orientation = TRANSPOSE).
-template <bool TRANSPOSE, bool LDSW>
+template <int HB, bool TRANSPOSE, bool LDSW>
 __device__ __forceinline__ void wide_chain(const unsigned short* __restrict__ wimg, const unsigned* __restrict__ wglob,
                                            const unsigned short* __restrict__ vimg, int lane, int cb,
                                            const F16Parts& own, f32x16& acc) {
@@ -94,19 +99,19 @@ __device__ __forceinline__ void wide_chain(const unsigned short* __restrict__ wi
     // and the wave's 512 registers overflow by 300. Fetching the next block's fragments ahead by hand (rotating
     // buffers) costs 60 spilled registers and 15 % (2.32 against 2.01 ms per launch at k = 128, 4 graphs): not kept.
 #pragma unroll 1
-    for (int bi = 0; bi < kWHB; ++bi) {
+    for (int bi = 0; bi < HB; ++bi) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f16x8 bh, bl;
             if (bi == cb) { bh = own.hi[s]; bl = own.lo[s]; }
             else {
-                bh = wide_frag<false>(vimg, lane, 0, bi, s);
-                bl = wide_frag<false>(vimg + kWPart, lane, 0, bi, s);
+                bh = wide_frag<HB, false>(vimg, lane, 0, bi, s);
+                bl = wide_frag<HB, false>(vimg + WideDims<HB>::kPart, lane, 0, bi, s);
             }
             f16x8 ah, al;
             if constexpr (LDSW) {
-                ah = wide_frag<TRANSPOSE>(wimg, lane, cb, bi, s);
-                al = wide_frag<TRANSPOSE>(wimg + kWH * kWH, lane, cb, bi, s);
+                ah = wide_frag<HB, TRANSPOSE>(wimg, lane, cb, bi, s);
+                al = wide_frag<HB, TRANSPOSE>(wimg + WideDims<HB>::H * WideDims<HB>::H, lane, cb, bi, s);
             } else {
                 ah = wide_gfrag(wglob, TRANSPOSE ? 1 : 0, 0, cb, bi, s, lane);
                 al = wide_gfrag(wglob, TRANSPOSE ? 1 : 0, 1, cb, bi, s, lane);
@@ -120,16 +125,17 @@ __device__ __forceinline__ void wide_chain(const unsigned short* __restrict__ wi
 
 // gW[bi] (rows: own channel block cb of G, columns: channel block bi of Act) += inv_w * sum over the tile's edges of
 // G'[e][c] Act'[e][k]; gB[.][col] += inv_b * sum_e G'[e][.] (ones-column product). Both operands read transposed.
+template <int HB>
 __device__ __forceinline__ void wide_wgrad(const unsigned short* __restrict__ g_img,
                                            const unsigned short* __restrict__ act_img,
                                            const unsigned* __restrict__ ones, int lane, int cb, float inv_w, float inv_b,
-                                           f32x16 (&gW)[kWHB], f32x16& gB) {
+                                           f32x16 (&gW)[HB], f32x16& gB) {
     const f16x8 one = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ones + lane * 4));
     f16x8 gh[2], gl[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        gh[s] = wide_frag<true>(g_img, lane, cb, 0, s);
-        gl[s] = wide_frag<true>(g_img + kWPart, lane, cb, 0, s);
+        gh[s] = wide_frag<HB, true>(g_img, lane, cb, 0, s);
+        gl[s] = wide_frag<HB, true>(g_img + WideDims<HB>::kPart, lane, cb, 0, s);
     }
     {
         f32x16 tb;
@@ -144,15 +150,15 @@ __device__ __forceinline__ void wide_wgrad(const unsigned short* __restrict__ g_
         for (int r = 0; r < 16; ++r) gB[r] = fmaf(tb[r], inv_b, gB[r]);
     }
 #pragma unroll
-    for (int bi = 0; bi < kWHB; ++bi) {
+    for (int bi = 0; bi < HB; ++bi) {
         __builtin_amdgcn_sched_barrier(0);       // (one block at a time: see wide_chain)
         f32x16 t;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const f16x8 ah = wide_frag<true>(act_img, lane, bi, 0, s);
-            const f16x8 al = wide_frag<true>(act_img + kWPart, lane, bi, 0, s);
+            const f16x8 ah = wide_frag<HB, true>(act_img, lane, bi, 0, s);
+            const f16x8 al = wide_frag<HB, true>(act_img + WideDims<HB>::kPart, lane, bi, 0, s);
             t = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[s], ah, t, 0, 0, 0);
             t = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[s], al, t, 0, 0, 0);
             t = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[s], ah, t, 0, 0, 0);
@@ -162,36 +168,43 @@ __device__ __forceinline__ void wide_wgrad(const unsigned short* __restrict__ g_
     }
 }
 
+template <int HB>
 struct WideCfg {
-    static constexpr int kThreads = 256;
-    // W2 images, tables, two ones columns, weight maximum, per-tile team words, three tensor images, SiLU'(z1) per wave
-    static constexpr int kW2Bytes = 2 * kWH * kWH * 2;
-    static constexpr int kTabBytes = (5 + PVS_MAX_EDGE_ATTR) * kWH * 4;
+    using D = WideDims<HB>;
+    static constexpr int kThreads = 64 * HB;              // one team per workgroup
+    static constexpr bool kWc1Global = HB > 2;            // H = 128: coord_mlp.0's weight from global memory
+    // W images (W2, and Wc1 where it fits), tables, two ones columns, weight maxima, per-tile team words, three tensor
+    // images, SiLU'(z1) per wave
+    static constexpr int kWBytes = (kWc1Global ? 1 : 2) * 2 * D::H * D::H * 2;
+    static constexpr int kTabBytes = (5 + PVS_MAX_EDGE_ATTR) * D::H * 4;
     static constexpr int kOnesBytes = 2 * 64 * 16;
-    static constexpr int kTeamBytes = 16 + 4 * 4 * 4 + 2 * kWHB * kTile * 4;     // wmax | tmax[4 tensors][4] | pdA, pdB
-    static constexpr int kImgBytes = 3 * kWImg * 2;
-    static constexpr int kD1Bytes = kWHB * 16 * 64 * 4;
-    static constexpr int kBytes = kW2Bytes + kTabBytes + kOnesBytes + kTeamBytes + kImgBytes + kD1Bytes;
-    static_assert(kTile * kWTS * 4 + kTile * 16 + kTile * 4 <= 2 * kWImg * 2, "g_z1 tile + tx + rowbuf must fit the m + gradient images");
+    static constexpr int kTeamBytes = 16 + 4 * 4 * 4 + 2 * HB * kTile * 4;       // wmax | tmax[4 tensors][4] | pdA, pdB
+    static constexpr int kImgBytes = 3 * D::kImg * 2;
+    static constexpr int kD1Bytes = HB * 16 * 64 * 4;
+    static constexpr int kBytes = kWBytes + kTabBytes + kOnesBytes + kTeamBytes + kImgBytes + kD1Bytes;
+    static_assert(kTile * D::kTS * 4 + kTile * 16 + kTile * 4 <= 2 * D::kImg * 2, "g_z1 tile + tx + rowbuf must fit the m + gradient images");
     static_assert(kBytes <= 160 * 1024, "LDS");
 };
 
-template <bool ERES, bool EATT>
-__global__ void __launch_bounds__(WideCfg::kThreads, 1)
+template <int HB, bool ERES, bool EATT>
+__global__ void __launch_bounds__(WideCfg<HB>::kThreads, 1)
 k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks, int e_lo, int e_hi,
                 const unsigned* __restrict__ wc1_glob) {
-    using Cfg = WideCfg;
-    constexpr int H = kWH, NT = Cfg::kThreads, HB = kWHB;
+    using Cfg = WideCfg<HB>;
+    using D = WideDims<HB>;
+    constexpr int H = D::H, NT = Cfg::kThreads, kWImg = D::kImg, kWTS = D::kTS;
+    constexpr bool WC1G = Cfg::kWc1Global;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* base = reinterpret_cast<char*>(smem);
     unsigned short* W2i = reinterpret_cast<unsigned short*>(base);                  // hi, lo: [H][H] fp16 each
-    float* b2t = reinterpret_cast<float*>(base + Cfg::kW2Bytes);
+    unsigned short* Wc1i = W2i + 2 * H * H;                                         // (only where it fits: !WC1G)
+    float* b2t = reinterpret_cast<float*>(base + Cfg::kWBytes);
     float* bc1t = b2t + H;
     float* wc2t = bc1t + H;
     float* wat = wc2t + H;
     float* wrhot = wat + H;
     float* attrt = wrhot + H;                                                       // [PVS_MAX_EDGE_ATTR][H]
-    unsigned* ones0 = reinterpret_cast<unsigned*>(base + Cfg::kW2Bytes + Cfg::kTabBytes);   // column 0 (g_bc1)
+    unsigned* ones0 = reinterpret_cast<unsigned*>(base + Cfg::kWBytes + Cfg::kTabBytes);   // column 0 (g_bc1)
     unsigned* ones1 = ones0 + 64 * 4;                                               // column 1 (g_b2)
     unsigned* wmax = ones1 + 64 * 4;                                                // [0]: max |W2|
     unsigned* tmax = wmax + 4;                                                      // [4 tensors][4 waves]
@@ -212,11 +225,17 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     if (threadIdx.x < 4) wmax[threadIdx.x] = 0u;
     __syncthreads();
     pvs_block_absmax(w.w2, H * H, wmax);
+    if (!WC1G && upd) pvs_block_absmax(w.wc1, H * H, wmax + 1);
     __syncthreads();
-    float inv_sw2;
+    float inv_sw2, inv_swc1 = 1.f;
     const float sw2 = pvs_f16_scale(wmax[0], &inv_sw2);
-    const float inv_swc1 = upd ? reinterpret_cast<const float*>(wc1_glob)[0] : 1.f;
     stage_weights_img_f16<HB>(W2i, w.w2, sw2);
+    if constexpr (WC1G) {
+        if (upd) inv_swc1 = reinterpret_cast<const float*>(wc1_glob)[0];
+    } else if (upd) {
+        const float swc1 = pvs_f16_scale(wmax[1], &inv_swc1);
+        stage_weights_img_f16<HB>(Wc1i, w.wc1, swc1);
+    }
     for (int c = threadIdx.x; c < H; c += NT) {
         b2t[c] = w.b2[c];
         bc1t[c] = upd ? w.bc1[c] : 0.f;
@@ -264,7 +283,9 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
         const unsigned mine = pvs_wave_max_u32(__float_as_uint(pvs_absmax16(v)));
         if (lane == 0) tmax[ts * 4 + cb] = mine;
         __syncthreads();
-        const unsigned m4 = max(max(tmax[ts * 4], tmax[ts * 4 + 1]), max(tmax[ts * 4 + 2], tmax[ts * 4 + 3]));
+        unsigned m4 = tmax[ts * 4];
+#pragma unroll
+        for (int b = 1; b < HB; ++b) m4 = max(m4, tmax[ts * 4 + b]);
         return pvs_f16_scale(__builtin_amdgcn_readfirstlane(m4), inv);
     };
     auto sum_pd = [&](const float* pd) {
@@ -365,7 +386,7 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
             }
             const float sa1 = team_scale(a1, 0, &inv_sa1);                        // barrier 1
             split_f16x2(a1, sa1, pb);
-            wide_write_image(A1I, j, hh, cb, pb);
+            wide_write_image<HB>(A1I, j, hh, cb, pb);
             __syncthreads();                                                      // barrier 2: the a1 image is complete
             // ---- z2 = W2 a1 + b2 (own output block); m, SiLU'(z2) ----
             float dz2[16], m[16];
@@ -374,7 +395,7 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 f32x16 acc2;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-                wide_chain<false, true>(W2i, nullptr, A1I, lane, cb, pb, acc2);
+                wide_chain<HB, false, true>(W2i, nullptr, A1I, lane, cb, pb, acc2);
                 float bias[16];
                 tab16(b2t + co, bias);
                 const float k2 = inv_sa1 * inv_sw2;
@@ -404,7 +425,7 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
             }
             const float sm = team_scale(m, 1, &inv_sm);                           // barrier 3 (also: pdA / pdB complete)
             split_f16x2(m, sm, pb);
-            wide_write_image(MI, j, hh, cb, pb);
+            wide_write_image<HB>(MI, j, hh, cb, pb);
             float att_v = 1.f, g_l = 0.f;
             if constexpr (EATT) {
                 const float logit = sum_pd(pdA) + bac;
@@ -428,7 +449,7 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 f32x16 accc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accc[r] = 0.f;
-                wide_chain<false, false>(nullptr, wc1b, MI, lane, cb, pb, accc);          // (Wc1 m) s_m s_wc1
+                wide_chain<HB, false, !WC1G>(Wc1i, wc1b, MI, lane, cb, pb, accc);       // (Wc1 m) s_m s_wc1
                 float bias2[16], wc2x[16], q[16], dq[16];
                 tab16(bc1t + co, bias2);
                 tab16(wc2t + co, wc2x);
@@ -461,16 +482,16 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 float inv_sg;
                 const float sg_ = team_scale(g_zc, 2, &inv_sg);                   // barrier 6
                 split_f16x2(g_zc, sg_, pb);
-                wide_write_image(GI, j, hh, cb, pb);
+                wide_write_image<HB>(GI, j, hh, cb, pb);
                 __syncthreads();                                                  // barrier 7: the g_zc image is complete
                 f32x16 accg;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accg[r] = 0.f;
-                wide_chain<true, false>(nullptr, wc1b, GI, lane, cb, pb, accg);            // (Wc1^T g_zc) s_g s_wc1
+                wide_chain<HB, true, !WC1G>(Wc1i, wc1b, GI, lane, cb, pb, accg);         // (Wc1^T g_zc) s_g s_wc1
                 const float kg = inv_sg * inv_swc1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gm[r] = accg[r] * kg;
-                wide_wgrad(GI, MI, ones0, lane, cb, inv_sg * inv_sm, inv_sg, gWc1, gB);    // gWc1 += g_zc (x) m ; g_bc1
+                wide_wgrad<HB>(GI, MI, ones0, lane, cb, inv_sg * inv_sm, inv_sg, gWc1, gB);    // gWc1 += g_zc (x) m ; g_bc1
             }
             if (io.g_m_out) {
                 float init[16];
@@ -520,13 +541,13 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
             float inv_sg2;
             const float sg2 = team_scale(g_z2, 3, &inv_sg2);                      // barrier 8 (also: every read of the
             split_f16x2(g_z2, sg2, pb);                                           //   g_zc image by the team is done)
-            wide_write_image(GI, j, hh, cb, pb);
+            wide_write_image<HB>(GI, j, hh, cb, pb);
             __syncthreads();                                                      // barrier 9: the g_z2 image is complete
             f32x16 ga1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ga1[r] = 0.f;
-            wide_chain<true, true>(W2i, nullptr, GI, lane, cb, pb, ga1);
-            wide_wgrad(GI, A1I, ones1, lane, cb, inv_sg2 * inv_sa1, inv_sg2, gW2, gB);
+            wide_chain<HB, true, true>(W2i, nullptr, GI, lane, cb, pb, ga1);
+            wide_wgrad<HB>(GI, A1I, ones1, lane, cb, inv_sg2 * inv_sa1, inv_sg2, gW2, gB);
             float g_z1[16];
             const float k1g = inv_sg2 * inv_sw2;
 #pragma unroll
@@ -644,39 +665,38 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
 
 size_t pvs_edge_bwd_wide_scratch_floats() { return (size_t)kWHeaderWords + kWCopyWords; }
 
-// Same contract as pvs_launch_edge_bwd_mfma (edge_mfma.hip). H = 128 only; io.wpair: pvs_edge_bwd_wide_scratch_floats().
-int pvs_launch_edge_bwd_wide(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags, int att_act,
-                             const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs) {
-    PVS_REQUIRE(w.n_attr <= 3, "MFMA edge backward supports up to 3 edge classes (got %d)", w.n_attr);
-    PVS_REQUIRE(H == kWH, "the wide edge backward is built for H = 128 (got %d)", H);
-    PVS_REQUIRE(io.wpair, "H = 128 edge backward needs its weight scratch");
-    *n_slabs = 0;
-    if (e_hi <= e_lo) return 0;
+namespace {
+template <int HB>
+int launch_wide(hipStream_t s, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags, int att_act, const PvsEdgeBwdIO& io,
+                int e_lo, int e_hi, int* n_slabs) {
+    using Cfg = WideCfg<HB>;
+    constexpr int H = 32 * HB;
     const bool upd = (flags & PVS_UPDATE_COORDS) && io.gxagg != nullptr;
     unsigned* wglob = reinterpret_cast<unsigned*>(io.wpair);
-    if (upd) {
+    if (Cfg::kWc1Global && upd) {
         k_stage_wide_weights<<<1, 1024, 0, s>>>(w.wc1, wglob);
         PVS_CHECK_LAUNCH();
     }
+    const PvsSlabLayout L = pvs_slab_layout(H);
+    size_t lds = Cfg::kBytes;
+    if (lds < (size_t)L.total * 4) lds = (size_t)L.total * 4;
+    const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;     // teams resident per CU
     const int E = e_hi - e_lo;
     long long b = ((long long)E + 511) / 512;          // fill the chip first: >= 16 tiles per team
     if (b < 1) b = 1;
-    if (b > 256) b = 256;                              // one team per CU (LDS)
+    if (b > 256LL * per_cu) b = 256LL * per_cu;
     long long per_team = ((long long)E + b * 4096 - 1) / (b * 4096);
     if (per_team < 1) per_team = 1;
     const int blocks = (int)b, n_chunks = (int)(b * per_team);
     *n_slabs = blocks;
     PvsProfScope prof(s, PVS_PROF_EDGE_BWD);
-    const PvsSlabLayout L = pvs_slab_layout(kWH);
-    size_t lds = WideCfg::kBytes;
-    if (lds < (size_t)L.total * 4) lds = (size_t)L.total * 4;
     const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
     const bool eatt = flags & PVS_EDGE_ATTENTION;
-#define PVS_BWD_WIDE_LAUNCH(ER, EA)                                                                         \
-    do {                                                                                                   \
-        if (set_lds(k_edge_bwd_wide<ER, EA>, lds)) return -2;                                              \
-        k_edge_bwd_wide<ER, EA><<<blocks, WideCfg::kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, \
-                                                                       e_lo, e_hi, wglob);               \
+#define PVS_BWD_WIDE_LAUNCH(ER, EA)                                                                            \
+    do {                                                                                                      \
+        if (set_lds(k_edge_bwd_wide<HB, ER, EA>, lds)) return -2;                                             \
+        k_edge_bwd_wide<HB, ER, EA><<<blocks, Cfg::kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, \
+                                                                       e_hi, wglob);                        \
     } while (0)
     if (eres && eatt) PVS_BWD_WIDE_LAUNCH(true, true);
     else if (eres) PVS_BWD_WIDE_LAUNCH(true, false);
@@ -685,4 +705,19 @@ int pvs_launch_edge_bwd_wide(hipStream_t s, int H, const PvsGraph& g, const PvsE
 #undef PVS_BWD_WIDE_LAUNCH
     PVS_CHECK_LAUNCH();
     return 0;
+}
+}  // namespace
+
+// Same contract as pvs_launch_edge_bwd_mfma (edge_mfma.hip). H = 128; io.wpair: pvs_edge_bwd_wide_scratch_floats()
+// floats of scratch. (The kernel is written for H = 32 HB; its HB = 2 form - two waves per tile, both weight matrices in
+// LDS, two teams per CU - is correct, 138 GPU tests, but 50 % slower than the one-wave-per-16-edge-tile kernel of
+// edge_bwd_h64.hip at cfg3: 1.51 against 1.01 ms per launch, profiles/r03_ab_h64_team_f16_rejected.txt. Not built.)
+int pvs_launch_edge_bwd_wide(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags, int att_act,
+                             const PvsEdgeBwdIO& io, int e_lo, int e_hi, int* n_slabs) {
+    PVS_REQUIRE(w.n_attr <= 3, "MFMA edge backward supports up to 3 edge classes (got %d)", w.n_attr);
+    PVS_REQUIRE(H == 128, "the team edge backward is built for H = 128 (got %d)", H);
+    PVS_REQUIRE(io.wpair, "H = 128 edge backward needs its weight scratch");
+    *n_slabs = 0;
+    if (e_hi <= e_lo) return 0;
+    return launch_wide<4>(s, g, w, flags, att_act, io, e_lo, e_hi, n_slabs);
 }
