@@ -622,7 +622,10 @@ int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx,
 #ifndef PVS_LIN_ROWS
 #define PVS_LIN_ROWS 256   // rows per block: 2 tiles per wave amortise the weight staging (cfg3 step -0.4 %)
 #endif
-        int blocks_m = (N + PVS_LIN_ROWS - 1) / PVS_LIN_ROWS;
+        // (few rows - 4-graph batches of the wide layers, 8000 nodes: 32 blocks of 256 rows leave 7/8 of the chip idle
+        // behind the weight staging - one 32-row tile per wave)
+        const int rows_m = N >= 32768 ? PVS_LIN_ROWS : 128;
+        int blocks_m = (N + rows_m - 1) / rows_m;
         if (blocks_m > 1024) blocks_m = 1024;
 #define PVS_LIN(KBV, CBV)                                                                          \
     k_linear_mfma<KBV, CBV><<<blocks_m, kThreads, lds_m, s>>>(y, ldy, x, ldx, K / 32, x2, ldx2, W, swc, \
