@@ -50,7 +50,9 @@ enum {
 enum { PVS_ACT_SIGMOID = 0, PVS_ACT_TANH = 1, PVS_ACT_RELU = 2, PVS_ACT_SILU = 3, PVS_ACT_IDENTITY = 4 };
 
 typedef struct PvsLayerDesc {
-    int32_t  hidden;       /* H = input_nf = hidden_nf = output_nf (always k,k,k in build_net) */
+    int32_t  hidden;       /* H = input_nf = hidden_nf = output_nf (always k,k,k in build_net). Built widths: 16, 32, 64
+                            * (every kernel family) and 128 (MFMA kernels, <= 3 edge classes: the reference's --channels
+                            * 65..128, parse_args.py:56, zero-padded by the caller); other sizes are padded up by the caller */
     int32_t  n_edge_attr;  /* A = edges_in_d: number of one-hot edge classes (0 = no edge_attr) */
     uint32_t flags;        /* PVS_* bits */
     int32_t  att_act;      /* PVS_ACT_* */

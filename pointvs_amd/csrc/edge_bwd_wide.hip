@@ -186,7 +186,8 @@ struct WideCfg {
     static_assert(kBytes <= 160 * 1024, "LDS");
 };
 
-template <int HB, bool ERES, bool EATT>
+// ERK: edge residual kind - 0 none, 1 the plain sum m + m_prev, 2 rezero / gated (edge_bwd_f16.hip)
+template <int HB, int ERK, bool EATT>
 __global__ void __launch_bounds__(WideCfg<HB>::kThreads, 1)
 k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks, int e_lo, int e_hi,
                 const unsigned* __restrict__ wc1_glob) {
@@ -194,6 +195,7 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     using D = WideDims<HB>;
     constexpr int H = D::H, NT = Cfg::kThreads, kWImg = D::kImg, kWTS = D::kTS;
     constexpr bool WC1G = Cfg::kWc1Global;
+    constexpr bool ERES = ERK != 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* base = reinterpret_cast<char*>(smem);
     unsigned short* W2i = reinterpret_cast<unsigned short*>(base);                  // hi, lo: [H][H] fp16 each
@@ -259,7 +261,7 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
 
     const float bac = EATT ? w.ba[0] : 0.f;
     float gate_raw = 0.f, gate = 1.f;
-    if (ERES && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
+    if (ERK == 2 && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
         gate_raw = w.edge_gate[0];
         gate = (flags & PVS_GATED_RESIDUAL) ? fmaxf(gate_raw, 0.f) : gate_raw;
     }
@@ -390,7 +392,7 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
             __syncthreads();                                                      // barrier 2: the a1 image is complete
             // ---- z2 = W2 a1 + b2 (own output block); m, SiLU'(z2) ----
             float dz2[16], m[16];
-            float m_new[ERES ? 16 : 1], mp[ERES ? 16 : 1];
+            float m_new[ERK == 2 ? 16 : 1], mp[ERES ? 16 : 1];
             {
                 f32x16 acc2;
 #pragma unroll
@@ -405,13 +407,16 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                     const float sg = pvs_sigmoid(z2);
                     m[r] = z2 * sg;
                     dz2[r] = fmaf(m[r], 1.0f - sg, sg);
-                    if constexpr (ERES) m_new[r] = m[r];
+                    if constexpr (ERK == 2) m_new[r] = m[r];
                 }
             }
             if constexpr (ERES) {
                 tab16(io.m_prev + (size_t)ee * H + co, mp);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m[r] = fmaf(res_a, m_new[r], res_b * mp[r]);
+                for (int r = 0; r < 16; ++r) {
+                    if constexpr (ERK == 2) m[r] = fmaf(res_a, m_new[r], res_b * mp[r]);
+                    else m[r] += mp[r];
+                }
             }
             float gMi[16];
             tab16(io.gM + (size_t)i * H + co, gMi);
@@ -514,7 +519,8 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
             for (int r = 0; r < 16; ++r) {
                 const float gmv = gm[r];
                 float gnew = gmv;
-                if constexpr (ERES) {
+                if constexpr (ERK == 1) mp[r] = gmv;         // (plain sum: m_prev receives g_m as it is)
+                if constexpr (ERK == 2) {
                     if (flags & PVS_REZERO) {
                         gnew = gate * gmv;
                         g_gate = fmaf(gmv, m_new[r], g_gate);
@@ -698,10 +704,13 @@ int launch_wide(hipStream_t s, const PvsGraph& g, const PvsEdgeW& w, uint32_t fl
         k_edge_bwd_wide<HB, ER, EA><<<blocks, Cfg::kThreads, lds, s>>>(g, w, flags, att_act, io, n_chunks, e_lo, \
                                                                        e_hi, wglob);                        \
     } while (0)
-    if (eres && eatt) PVS_BWD_WIDE_LAUNCH(true, true);
-    else if (eres) PVS_BWD_WIDE_LAUNCH(true, false);
-    else if (eatt) PVS_BWD_WIDE_LAUNCH(false, true);
-    else PVS_BWD_WIDE_LAUNCH(false, false);
+    const bool gated = flags & (PVS_REZERO | PVS_GATED_RESIDUAL);
+    if (eres && gated && eatt) PVS_BWD_WIDE_LAUNCH(2, true);
+    else if (eres && gated) PVS_BWD_WIDE_LAUNCH(2, false);
+    else if (eres && eatt) PVS_BWD_WIDE_LAUNCH(1, true);
+    else if (eres) PVS_BWD_WIDE_LAUNCH(1, false);
+    else if (eatt) PVS_BWD_WIDE_LAUNCH(0, true);
+    else PVS_BWD_WIDE_LAUNCH(0, false);
 #undef PVS_BWD_WIDE_LAUNCH
     PVS_CHECK_LAUNCH();
     return 0;

@@ -22,3 +22,4 @@ cp $src/soak_load.json $dst/${tag}_soak_concurrent_gpu_load.json
 cp $src/soak_poison.json $dst/${tag}_soak_poisoned_allocator.json
 cp $src/variants.txt $dst/${tag}_variants_backward_timings.txt
 ls $dst | grep "^${tag}_" | wc -l
+python3 tools/pmc_header.py $dst/${tag}_cfg2_pmc_sq.txt cfg2 > /dev/null; python3 tools/pmc_header.py $dst/${tag}_cfg3_pmc_sq.txt cfg3 > /dev/null
