@@ -676,11 +676,20 @@ int pvs_launch_tsgemm_tn(hipStream_t s, float* out, int ldo, const float* A, int
     const int CK = C * K;
     PVS_REQUIRE(C <= 32 * kThreads, "tsgemm: %d x %d outputs unsupported", C, K);
     if (C % 64 == 0 && K % 64 == 0 && (C > 64 || K > 64)) {
-        // the wide layer (hidden 128): 64 x 64 blocks of the output on the MFMA kernel, one product each
+        // the wide layer (hidden 128): 64 x 64 blocks of the output on the MFMA kernel, one product each. The caller's
+        // slab buffer holds pvs_reduce_blocks(N) slabs of the WHOLE product, i.e. (C K / 4096) times as many of a
+        // 64 x 64 block: with few rows (4-graph batches: 8000 nodes = 16 row blocks) the rows are cut finer
+        int blocks = pvs_reduce_blocks(N) * (CK / 4096);
+        const int by_rows = (N + 127) / 128;
+        if (blocks > by_rows) blocks = by_rows;
+        if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+        if (blocks < 1) blocks = 1;
+        const int rpb = rows_per_block_for(N, blocks);
         for (int c0 = 0; c0 < C; c0 += 64)
             for (int k0 = 0; k0 < K; k0 += 64) {
-                const int rc = pvs_launch_tsgemm_tn(s, out + (size_t)c0 * ldo + k0, ldo, A + c0, lda, B + k0, ldb, N, 64,
-                                                    64, slabs, accumulate);
+                k_tsgemm_mfma<2, 2><<<blocks, kThreads, 0, s>>>(slabs, A + c0, lda, B + k0, ldb, N, rpb, 64);
+                PVS_CHECK_LAUNCH();
+                const int rc = pvs_launch_reduce_slabs(s, out + (size_t)c0 * ldo + k0, ldo, 64, slabs, blocks, 4096, accumulate);
                 if (rc) return rc;
             }
         return 0;
