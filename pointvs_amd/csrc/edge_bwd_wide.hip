@@ -14,7 +14,7 @@
 // in A-operand order for both orientations (k_stage_wide_weights: one 16-byte load per lane and fragment, coalesced
 // 1 KB per wave; an L2 hit) - two split 128x128 matrices do not fit beside 64 KB of images.
 // Replaces the four-wave fp32 team kernel (k_edge_bwd_team<4>, 384 fp32 MFMAs of 64 cycles per tile and wave) with
-// 152 fp16 MFMAs of 32. Twelve workgroup barriers per tile; one team per 256-thread block, one block per CU.
+// 152 fp16 MFMAs of 32. Eleven workgroup barriers per tile; one team per 256-thread block, one block per CU.
 //
 // Reference semantics: autograd of EGNNLayer.edge_model / coord_model / node_model's aggregation,
 // /root/reference/point_vs/models/geometric/egnn_satorras.py:123-206 (SURVEY.md §8a "Backward spec").
@@ -96,10 +96,29 @@ __device__ __forceinline__ void wide_chain(const unsigned short* __restrict__ wi
                                            const unsigned short* __restrict__ vimg, int lane, int cb,
                                            const F16Parts& own, f32x16& acc) {
     // One input block at a time, the loop NOT unrolled: unrolled, the 32 fragment loads of a product are all hoisted
-    // and the wave's 512 registers overflow by 300. Fetching the next block's fragments ahead by hand (rotating
-    // buffers) costs 60 spilled registers and 15 % (2.32 against 2.01 ms per launch at k = 128, 4 graphs): not kept.
+    // and the wave's 512 registers overflow by 300. The GLOBAL weight fragments (an L2 hit of 500+ cycles) of the next
+    // block are fetched before this block's MFMAs (16 loop-carried registers); fetching the LDS fragments ahead as
+    // well costs 60 spilled registers and 15 % (2.32 against 2.01 ms per launch at k = 128, 4 graphs): not kept.
+    f16x8 nah[2], nal[2];
+    if constexpr (!LDSW) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            nah[s] = wide_gfrag(wglob, TRANSPOSE ? 1 : 0, 0, cb, 0, s, lane);
+            nal[s] = wide_gfrag(wglob, TRANSPOSE ? 1 : 0, 1, cb, 0, s, lane);
+        }
+    }
 #pragma unroll 1
     for (int bi = 0; bi < HB; ++bi) {
+        f16x8 ah[2], al[2];
+        if constexpr (!LDSW) {
+            const int bn = bi + 1 < HB ? bi + 1 : bi;       // (the last block re-fetches itself: no branch)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                ah[s] = nah[s]; al[s] = nal[s];
+                nah[s] = wide_gfrag(wglob, TRANSPOSE ? 1 : 0, 0, cb, bn, s, lane);
+                nal[s] = wide_gfrag(wglob, TRANSPOSE ? 1 : 0, 1, cb, bn, s, lane);
+            }
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f16x8 bh, bl;
@@ -108,17 +127,13 @@ __device__ __forceinline__ void wide_chain(const unsigned short* __restrict__ wi
                 bh = wide_frag<HB, false>(vimg, lane, 0, bi, s);
                 bl = wide_frag<HB, false>(vimg + WideDims<HB>::kPart, lane, 0, bi, s);
             }
-            f16x8 ah, al;
             if constexpr (LDSW) {
-                ah = wide_frag<HB, TRANSPOSE>(wimg, lane, cb, bi, s);
-                al = wide_frag<HB, TRANSPOSE>(wimg + WideDims<HB>::H * WideDims<HB>::H, lane, cb, bi, s);
-            } else {
-                ah = wide_gfrag(wglob, TRANSPOSE ? 1 : 0, 0, cb, bi, s, lane);
-                al = wide_gfrag(wglob, TRANSPOSE ? 1 : 0, 1, cb, bi, s, lane);
+                ah[s] = wide_frag<HB, TRANSPOSE>(wimg, lane, cb, bi, s);
+                al[s] = wide_frag<HB, TRANSPOSE>(wimg + WideDims<HB>::H * WideDims<HB>::H, lane, cb, bi, s);
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc, 0, 0, 0);
         }
     }
 }
@@ -178,7 +193,7 @@ struct WideCfg {
     static constexpr int kWBytes = (kWc1Global ? 1 : 2) * 2 * D::H * D::H * 2;
     static constexpr int kTabBytes = (5 + PVS_MAX_EDGE_ATTR) * D::H * 4;
     static constexpr int kOnesBytes = 2 * 64 * 16;
-    static constexpr int kTeamBytes = 16 + 4 * 4 * 4 + 2 * HB * kTile * 4;       // wmax | tmax[4 tensors][4] | pdA, pdB
+    static constexpr int kTeamBytes = 16 + 4 * 4 * 4 + 4 * HB * kTile * 4;       // wmax | tmax[4 tensors][4] | pdA..pdD
     static constexpr int kImgBytes = 3 * D::kImg * 2;
     static constexpr int kD1Bytes = HB * 16 * 64 * 4;
     static constexpr int kBytes = kWBytes + kTabBytes + kOnesBytes + kTeamBytes + kImgBytes + kD1Bytes;
@@ -211,8 +226,10 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
     unsigned* wmax = ones1 + 64 * 4;                                                // [0]: max |W2|
     unsigned* tmax = wmax + 4;                                                      // [4 tensors][4 waves]
     float* pdA = reinterpret_cast<float*>(tmax + 16);                               // [HB][32]
-    float* pdB = pdA + HB * kTile;
-    unsigned short* A1I = reinterpret_cast<unsigned short*>(pdB + HB * kTile);
+    float* pdB = pdA + HB * kTile;                                                   // (one array per dot: no
+    float* pdC = pdB + HB * kTile;                                                   //  barrier between a read of one
+    float* pdD = pdC + HB * kTile;                                                   //  and the next dot's writes)
+    unsigned short* A1I = reinterpret_cast<unsigned short*>(pdD + HB * kTile);
     unsigned short* MI = A1I + kWImg;
     unsigned short* GI = MI + kWImg;
     float* d1all = reinterpret_cast<float*>(GI + kWImg);
@@ -352,6 +369,7 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
             if (g.graph_eptr)
                 while (gk < g.n_graphs && gb <= e_this_end) { ++gk; gb = __builtin_amdgcn_readfirstlane(g.graph_eptr[gk]); }
             const int n_end = e_this_end < e_end ? tile_end(e_this_end, gb) : e_this_end;
+            // (prefetching the next tile's indices here costs 7 spilled registers more than it hides: 1.91 against 1.87 ms)
             const TileIdx I = load_tile_idx(g, w.n_attr, e0, e_begin, e_this_end, j);
             const int e = e0 + j, i = I.i, ty = I.ty, ee = I.ee;
             const bool valid = e < e_this_end;
@@ -469,10 +487,9 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                     ps = fmaf(wc2x[r], q[r], ps);
                 }
                 ps += __shfl_xor(ps, 32, 64);
-                __syncthreads();                                                  // barrier 5a: the pdA reads above are done
-                if (hh == 0) pdA[cb * kTile + j] = ps;
-                __syncthreads();                                                  // barrier 5: pdA complete
-                float s = sum_pd(pdA);
+                if (hh == 0) pdC[cb * kTile + j] = ps;
+                __syncthreads();                                                  // barrier 5: pdC complete
+                float s = sum_pd(pdC);
                 float dact = 1.f;
                 if (flags & PVS_TANH) { s = pvs_tanh(s); dact = 1.f - s * s; }
                 if (flags & PVS_NORMALIZE) nrm = 1.f / (sqrtf(rho) + 1e-8f);
@@ -565,9 +582,9 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 g_z1[4 * gq + 3] = ga1[4 * gq + 3] * (dd.w * k1g);
             }
             const float prho = dot16(wrhot + co, g_z1);
-            if (hh == 0) pdB[cb * kTile + j] = prho;
-            __syncthreads();               // barrier 10: pdB complete; every read of the m / gradient images is done
-            const float g_rho = sum_pd(pdB);
+            if (hh == 0) pdD[cb * kTile + j] = prho;
+            __syncthreads();               // barrier 10: pdD complete; every read of the m / gradient images is done
+            const float g_rho = sum_pd(pdD);
             const float k1 = s_coord * nrm * vm;
             const float gd0 = fmaf(k1, gT0, 2.f * d0 * g_rho);
             const float gd1 = fmaf(k1, gT1, 2.f * d1 * g_rho);
