@@ -662,17 +662,18 @@ def test_backward_on_a_forward_only_graph_fails_loudly():
 @pytest.mark.parametrize('changes', [dict(), dict(edge_attention=True, node_attention=True, residual=True),
                                      dict(k=64, edge_attention=True), dict(edge_residual=True, tanh=True),
                                      dict(k=64, edge_residual=True, edge_attention=True, tanh=True),
-                                     dict(edge_residual=True, edge_attention=True)])
+                                     dict(edge_residual=True, edge_attention=True),
+                                     dict(k=128), dict(k=100, edge_residual=True, edge_attention=True, node_attention=True)])
 def test_bitwise_reproducible_at_baseline_size(changes):
     """No atomics and no unordered LDS hand-offs anywhere: four runs of the same cfg2-shaped batch give
-    identical bits in the outputs and in every gradient (every kernel family: H = 32 all-bf16 backward with and
-    without edge residual, the round-1 H = 32 kernel that keeps edge residual + edge attention, the H = 64
-    one-wave-per-16-edge-tile backward with and without edge residual). A race in a kernel shows up here as run-to-run
-    differences long before it breaks a tolerance."""
+    identical bits in the outputs and in every gradient (every kernel family: the H = 32 f16x2 backward with and
+    without edge residual / attention, the H = 64 one-wave-per-16-edge-tile backward with and without edge residual,
+    the four-wave team backward of the wide layers - eleven workgroup barriers and shared LDS images per tile). A race
+    in a kernel shows up here as run-to-run differences long before it breaks a tolerance."""
     from pointvs_amd.synthetic import CONFIGS, synthetic_batch
     cfg = CONFIGS['cfg2']
     model, _ = make_model(seed=11, **dict({k: v for k, v in cfg['model'].items() if k in BASE_KW}, **changes))
-    g = synthetic_batch(cfg['cfg_id'], 8, **cfg['graph'])
+    g = synthetic_batch(cfg['cfg_id'], 2 if changes.get('k', 32) > 64 else 8, **cfg['graph'])
     # (every product of the step, the head's included, is one of this library's kernels - no rocBLAS, no
     # atomics: profiles/r02_bench_cfg2_kernel_stats.csv lists every kernel of a step)
     runs = [gpu_run(model, g) for _ in range(4)]
@@ -815,7 +816,8 @@ def test_by_column_lists_by_counting_equal_the_sort(sizes):
     assert np.array_equal(a.t['colptr'].cpu().numpy(), np.searchsorted(col[order], np.arange(n + 1)))
 
 
-@pytest.mark.parametrize('family', ['default', 'h32_att', 'h32_edgeres_att', 'h64_att', 'generic_h16'])
+@pytest.mark.parametrize('family', ['default', 'h32_att', 'h32_edgeres_att', 'h64_att', 'generic_h16', 'wide128',
+                                    'wide96_edgeres_att'])
 def test_results_do_not_depend_on_stale_memory(family):
     """A result that changes with the bytes the allocator happens to hand out is a read of memory this step
     has not written - invisible while every step repeats the previous one (the block comes back holding the

@@ -28,7 +28,7 @@ def main():
         kw = dict(soak.BASE_KW, **soak.FAMILIES[fam])
         model = SartorrasEGNN(Path('/tmp/pvs_hash'), 2e-3, 1e-4, silent=True, **kw).cuda().train()
         graph_kw = dict(cfg['graph'])
-        if kw['k'] == 64:
+        if kw['k'] >= 64:
             graph_kw['edge_radius'] = 6.0
         batch = synthetic_batch(cfg['cfg_id'], args.graphs, **graph_kw).to('cuda')
         out[fam] = soak.one_repeat(model, batch)

@@ -48,6 +48,8 @@ FAMILIES = {
     'h64_att': dict(k=64, edge_attention=True, node_attention=True),       # cfg3's layers
     'h64_edgeres_att': dict(k=64, edge_residual=True, edge_attention=True, tanh=True),
     'generic_h16': dict(k=16, normalize=True),                             # edge_v0 kernels
+    'wide128': dict(k=128),                                                # k_edge_bwd_wide<4,0,false>, two-launch forward
+    'wide96_edgeres_att': dict(k=96, edge_residual=True, edge_attention=True, node_attention=True, tanh=True),
 }
 
 
@@ -112,7 +114,7 @@ def soak_family(name, changes, repeats, n_graphs, states=('clean', 'nan', 'garba
     kw = dict(BASE_KW, **changes)
     model = SartorrasEGNN(Path('/tmp/pvs_soak'), 2e-3, 1e-4, silent=True, **kw).cuda().train()
     graph_kw = dict(cfg['graph'])
-    if kw['k'] == 64:
+    if kw['k'] >= 64:
         graph_kw['edge_radius'] = 6.0          # cfg3's sparser graphs
     batch = synthetic_batch(cfg['cfg_id'], n_graphs, **graph_kw).to('cuda')
     cache = pgraph.CACHE_ENABLED
