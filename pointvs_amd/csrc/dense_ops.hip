@@ -11,13 +11,12 @@ __global__ void __launch_bounds__(kThreads)
 k_linear(float* __restrict__ y, int ldy, const float* __restrict__ x, int ldx,
          const float* __restrict__ W, int swc, int swk, const float* __restrict__ b,
          const float* __restrict__ x2, int ldx2, const float* __restrict__ W2, int swc2, int swk2,
-         int N, int K, int K2, int C, int accumulate) {
+         int N, int K, int K2, int C, int accumulate, int NB) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int KK = K + K2;
     float* Wt = smem;             // [KK][C]  transposed: lanes over c read consecutive words
     float* xs = smem + KK * C;    // [NB][KK]
     const int tid = threadIdx.x;
-    const int NB = kThreads / C > 0 ? kThreads / C : 1;
     for (int i = tid; i < KK * C; i += kThreads) {
         int k = i / C, c = i % C;
         Wt[i] = k < K ? W[(size_t)c * swc + (size_t)k * swk]
@@ -251,13 +250,16 @@ k_reduce_slabs2(float* __restrict__ out_a, const float* __restrict__ slabs_a, in
 }
 
 constexpr int kPoolThreads = 1024;
-// One workgroup per graph; thread = (row slot, channel), 4 independent partial sums per thread so
-// that 4 * (1024 / width) rows are in flight; fixed summation order.
+// One workgroup per graph (and per chunk of 1024 channels); thread = (row slot, channel), 4 independent partial sums
+// per thread so that 4 * (1024 / width) rows are in flight; fixed summation order.
 __global__ void __launch_bounds__(kPoolThreads)
 k_mean_pool_fwd(const float* __restrict__ h, const int32_t* __restrict__ gptr,
-                float* __restrict__ pooled, int width) {
+                float* __restrict__ pooled, int ld) {
     __shared__ float part[kPoolThreads];
     const int g = blockIdx.x, tid = threadIdx.x;
+    const int c0 = blockIdx.y * kPoolThreads;
+    const int width = min(kPoolThreads, ld - c0);
+    h += c0;
     const int n0 = gptr[g], n1 = gptr[g + 1];
     const int R = kPoolThreads / width;
     const int c = tid % width, r = tid / width;
@@ -265,12 +267,12 @@ k_mean_pool_fwd(const float* __restrict__ h, const int32_t* __restrict__ gptr,
     if (r < R) {
         int n = n0 + r;
         for (; n + 3 * R < n1; n += 4 * R) {
-            a0 += h[(size_t)n * width + c];
-            a1 += h[(size_t)(n + R) * width + c];
-            a2 += h[(size_t)(n + 2 * R) * width + c];
-            a3 += h[(size_t)(n + 3 * R) * width + c];
+            a0 += h[(size_t)n * ld + c];
+            a1 += h[(size_t)(n + R) * ld + c];
+            a2 += h[(size_t)(n + 2 * R) * ld + c];
+            a3 += h[(size_t)(n + 3 * R) * ld + c];
         }
-        for (; n < n1; n += R) a0 += h[(size_t)n * width + c];
+        for (; n < n1; n += R) a0 += h[(size_t)n * ld + c];
     }
     part[tid] = (a0 + a1) + (a2 + a3);
     __syncthreads();
@@ -278,7 +280,7 @@ k_mean_pool_fwd(const float* __restrict__ h, const int32_t* __restrict__ gptr,
         float s = 0.f;
         for (int rr = 0; rr < R; ++rr) s += part[rr * width + tid];
         int cnt = n1 - n0;
-        pooled[(size_t)g * width + tid] = s / (float)(cnt > 1 ? cnt : 1);
+        pooled[(size_t)g * ld + c0 + tid] = s / (float)(cnt > 1 ? cnt : 1);
     }
 }
 
@@ -641,15 +643,17 @@ int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx,
         PVS_CHECK_LAUNCH();
         return 0;
     }
-    const int NB = kThreads / C > 0 ? kThreads / C : 1;
+    int NB = kThreads / C > 0 ? kThreads / C : 1;      // rows per pass: one output per thread ...
+    const int fit = (160 * 1024 / (int)sizeof(float) - KK * C) / KK;
+    if (NB > fit) NB = fit;                            // ... or as many input rows as fit beside the weights
+    PVS_REQUIRE(NB >= 1, "linear: %d x %d weights do not fit LDS", KK, C);
     size_t lds = (size_t)(KK * C + NB * KK) * sizeof(float);
-    PVS_REQUIRE(lds <= 160 * 1024, "linear: %d x %d weights do not fit LDS", KK, C);
     if (lds > 48 * 1024)
         PVS_CHECK_HIP(hipFuncSetAttribute((const void*)k_linear,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int blocks = grid_for(N, NB * 4);
     k_linear<<<blocks, kThreads, lds, s>>>(y, ldy, x, ldx, W, swc, swk, b, x2, ldx2, W2, swc2, swk2,
-                                           N, K, K2, C, accumulate ? 1 : 0);
+                                           N, K, K2, C, accumulate ? 1 : 0, NB);
     PVS_CHECK_LAUNCH();
     return 0;
 }
@@ -769,7 +773,16 @@ int pvs_launch_node_wgrads(hipStream_t s, int H, int N, const PvsNodeWgradIn& in
 int pvs_launch_colreduce(hipStream_t s, int mode, float* out, const float* A, int lda, const float* B,
                          int ldb, const float* shift, int N, int C, float scale, float* slabs,
                          bool accumulate) {
-    PVS_REQUIRE(C >= 1 && C <= kThreads, "colreduce: width %d unsupported", C);
+    PVS_REQUIRE(C >= 1, "colreduce: width %d unsupported", C);
+    if (C > kThreads) {      // one thread per column: wider inputs in chunks of 256 columns (the slabs are reused in stream order)
+        for (int c0 = 0; c0 < C; c0 += kThreads) {
+            const int rc = pvs_launch_colreduce(s, mode, out + c0, A + c0, lda, B ? B + c0 : nullptr, ldb,
+                                                shift ? shift + c0 : nullptr, N, C - c0 < kThreads ? C - c0 : kThreads,
+                                                scale, slabs, accumulate);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     const int blocks = pvs_colreduce_blocks(N);
     const int rpb = rows_per_block_for(N, blocks);
     const bool vec4 = C % 4 == 0 && lda % 4 == 0 && (B == nullptr || ldb % 4 == 0) &&
@@ -822,9 +835,10 @@ extern "C" int pvs_linear_bwd(const float* x, const float* w, const float* g_y, 
 
 extern "C" int pvs_mean_pool_fwd(const float* h, const int32_t* graph_ptr, float* pooled,
                                  int32_t B, int32_t width, pvs_stream_t stream) {
-    PVS_REQUIRE(width >= 1 && width <= kThreads, "mean_pool: width %d unsupported", width);
+    PVS_REQUIRE(width >= 1, "mean_pool: width %d unsupported", width);
     if (B <= 0) return 0;
-    k_mean_pool_fwd<<<B, kPoolThreads, 0, (hipStream_t)stream>>>(h, graph_ptr, pooled, width);
+    k_mean_pool_fwd<<<dim3(B, (width + kPoolThreads - 1) / kPoolThreads), kPoolThreads, 0, (hipStream_t)stream>>>(
+        h, graph_ptr, pooled, width);
     PVS_CHECK_LAUNCH();
     return 0;
 }

@@ -168,10 +168,10 @@ class EGNNLayer(nn.Module):
     _KERNEL_WIDTHS = (16, 32, 64, 128)
 
     def _fused_width_ok(self):
-        """Hidden sizes above 64 run on the fused 128-channel kernels (zero-padded: 65..127) - two launches of the
-        f16x2 edge forward and the four-wave fp32 team backward, built for the MFMA path with up to 3 edge classes.
-        PVS_WIDE=decomposed (or the generic kernel family, or more edge classes) takes the composition of the public
-        sub-methods instead."""
+        """Hidden sizes 65..128 run on the fused 128-channel kernels (zero-padded: 65..127) - two launches of the
+        f16x2 edge forward and the four-wave team backward, built for the MFMA path with up to 3 edge classes.
+        Wider layers, PVS_WIDE=decomposed, the generic kernel family or more edge classes take the composition of
+        the public sub-methods instead."""
         if self.hidden_nf <= 64:
             return True
         return (self.hidden_nf <= 128 and self.edges_in_d <= 3 and os.environ.get('PVS_WIDE') != 'decomposed'
@@ -246,16 +246,12 @@ class EGNNLayer(nn.Module):
             self._coords_src = (lambda: x_out.detach()) if self.use_coords else self._coords_src
         return h_out, x_out, m_sorted
 
-    _MAX_DECOMPOSED_WIDTH = 128       # pvs_linear_* stages the whole [C, K] weight in LDS: edge_mlp.0 is [k, 2k+1+A]
-
     def _decomposed_call(self, pg, h, coord, m_prev_sorted, skip_coords):
-        """EGNNLayer.forward (egnn_satorras.py:189-206) for hidden sizes above the fused kernels' 64 channels:
-        coord2radial -> edge_model -> edge residual -> coord_model -> node_model on the prepared graph's sorted
-        edge list. Not fused (the [E, H] intermediates live in HBM and autograd keeps them), so it runs at a
-        fraction of the fused layers' rate; same values as the reference (oracle-checked at k = 96, 128)."""
-        if self.hidden_nf > self._MAX_DECOMPOSED_WIDTH:
-            raise NotImplementedError(f'hidden size {self.hidden_nf} > {self._MAX_DECOMPOSED_WIDTH} is not '
-                                      f'built in libpvs_egnn.so')
+        """EGNNLayer.forward (egnn_satorras.py:189-206) for hidden sizes above the fused kernels' 128 channels (any
+        width: the reference accepts any --channels): coord2radial -> edge_model -> edge residual -> coord_model ->
+        node_model on the prepared graph's sorted edge list. Not fused (the [E, H] intermediates live in HBM and
+        autograd keeps them), so it runs at a fraction of the fused layers' rate; same values as the reference
+        (oracle-checked at k = 96 ... 1100)."""
         e = pg.n_edges
         row, col = pg.t['row'][:e].long(), pg.t['col'][:e].long()
         edge_index = torch.stack([row, col])
