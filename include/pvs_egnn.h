@@ -314,6 +314,23 @@ int pvs_mean_pool_fwd(const float* h, const int32_t* graph_ptr, float* pooled,
 int pvs_mean_pool_bwd(const float* g_pooled, const int32_t* graph_ptr, float* g_h,
                       int32_t n_graphs, int32_t n_nodes, int32_t width, pvs_stream_t stream);
 
+/* global_mean_pool followed by the head's first Linear (pnn_geometric_base.py:29-36: `feats_linear_layers(global_mean_pool(
+ * feats, batch))`; egnn_multitask.py:158-166) in one launch, and the backward of the pair in one launch: pooled [B, width]
+ * is kept by the caller for the backward; y [B, n_out] = pooled W^T + b (b NULL: no bias). width <= 1024.
+ * Backward: g_h [N, width] (NULL to skip), g_w [n_out, width], g_b [n_out] (NULL if no bias). */
+int pvs_pool_head_fwd(const float* h, const int32_t* graph_ptr, const float* w, const float* b, float* pooled,
+                      float* y, int32_t n_graphs, int32_t width, int32_t n_out, pvs_stream_t stream);
+int pvs_pool_head_bwd(const float* g_y, const float* pooled, const float* w, const int32_t* graph_ptr,
+                      float* g_h, float* g_w, float* g_b, int32_t n_graphs, int32_t n_nodes, int32_t width,
+                      int32_t n_out, pvs_stream_t stream);
+
+/* nn.BCEWithLogitsLoss() with its default mean reduction (point_neural_network_base.py:74, used at :365) over n logits:
+ * loss[0] = mean(max(x, 0) - x t + log1p(exp(-|x|))), grad[i] = (sigmoid(x_i) - t_i) / n (what the backward scales by
+ * the upstream gradient: pvs_scale_by_device_scalar, out[i] = a[i] * scalar[0] with the scalar in device memory). */
+int pvs_bce_logits_fwd(const float* x, const float* target, int32_t n, float* loss, float* grad,
+                       pvs_stream_t stream);
+int pvs_scale_by_device_scalar(const float* a, const float* scalar, int32_t n, float* out, pvs_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * clip_grad_value_(params, clip) + torch.optim.Adam.step() (point_neural_network_base.py:421-422)
  * for all parameters in ONE launch. table: DEVICE array of n entries; the

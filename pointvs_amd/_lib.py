@@ -94,6 +94,10 @@ _PROTOTYPES = {
                                                                       C.c_void_p]),
     'pvs_mean_pool_fwd': (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 2 + [C.c_void_p]),
     'pvs_mean_pool_bwd': (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p]),
+    'pvs_pool_head_fwd': (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_void_p]),
+    'pvs_pool_head_bwd': (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 4 + [C.c_void_p]),
+    'pvs_bce_logits_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'pvs_scale_by_device_scalar': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'pvs_segment_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32]),
     'pvs_segment_reduce_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

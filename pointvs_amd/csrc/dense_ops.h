@@ -6,7 +6,26 @@
 int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx, const float* W,
                       int swc, int swk, const float* b, const float* x2, int ldx2, const float* W2,
                       int swc2, int swk2, int N, int K, int K2, int C, bool accumulate, int epi = 0,
-                      const float* aux_in = nullptr, int ld_in = 0, float* aux_out = nullptr, int ld_out = 0);
+                      const float* aux_in = nullptr, int ld_in = 0, float* aux_out = nullptr, int ld_out = 0,
+                      const struct PvsLinearExt* ext = nullptr);
+// Extras of the MFMA linear (shapes of pvs_linear_epilogue_supported only; launches folded into a product that deals
+// the node rows to its lanes anyway):
+struct PvsLinearExt {
+    float* y1 = nullptr;          // column block 1 (outputs 32..63) -> y1[n*ldy1 + (c - 32)] instead of y[n*ldy + c]
+    int ldy1 = 0;
+    int acc1 = -1;                // accumulate flag of column block 1 (-1: the call's)
+    long long w_shift1 = 0;       // added to the weight offsets of column block 1 (a second slice of one weight matrix)
+    int bias_blocks = 8;          // column blocks, from 0, that take the bias
+    // per-row side jobs (valid rows):
+    float* zero_rows = nullptr;   // zero_rows[n*zero_ld + 0 .. zero_w) = 0   (zero_w % 8 == 0, 16-byte aligned rows)
+    int zero_w = 0, zero_ld = 0;
+    float* zero3 = nullptr;       // zero3[3n .. 3n+3) = 0
+    const float* copy3_src = nullptr;     // copy3_dst[3n + i] = copy3_src[3n + i]
+    float* copy3_dst = nullptr;
+    const float* scale3_src = nullptr;    // scale3_dst[3n + i] = scale3_src[3n + i] * scale3_by[n]
+    const float* scale3_by = nullptr;
+    float* scale3_dst = nullptr;
+};
 // elementwise epilogue on the product (only on the MFMA path: check first):
 //   1: aux_out = SiLU(y)   2: aux_out = aux_in + y   3: y *= SiLU'(aux_in)   4: aux_out = y
 enum { PVS_EPI_NONE = 0, PVS_EPI_SILU_OUT = 1, PVS_EPI_ADD_OUT = 2, PVS_EPI_MUL_SILU_GRAD = 3, PVS_EPI_COPY_OUT = 4 };

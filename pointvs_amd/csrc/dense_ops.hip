@@ -284,6 +284,112 @@ k_mean_pool_fwd(const float* __restrict__ h, const int32_t* __restrict__ gptr,
     }
 }
 
+// global_mean_pool + the first Linear of the head in one launch (one workgroup per graph): the pooled row stays in LDS
+// for the product; y[g, c] = b[c] + sum_k W[c, k] pooled[g, k], k ascending (the order of k_linear).
+__global__ void __launch_bounds__(kPoolThreads)
+k_pool_head_fwd(const float* __restrict__ h, const int32_t* __restrict__ gptr, const float* __restrict__ W,
+                const float* __restrict__ b, float* __restrict__ pooled, float* __restrict__ y, int width, int C) {
+    __shared__ float part[kPoolThreads];
+    __shared__ float pl[kPoolThreads];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int n0 = gptr[g], n1 = gptr[g + 1];
+    const int R = kPoolThreads / width;
+    const int c = tid % width, r = tid / width;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (r < R) {
+        int n = n0 + r;
+        for (; n + 3 * R < n1; n += 4 * R) {
+            a0 += h[(size_t)n * width + c];
+            a1 += h[(size_t)(n + R) * width + c];
+            a2 += h[(size_t)(n + 2 * R) * width + c];
+            a3 += h[(size_t)(n + 3 * R) * width + c];
+        }
+        for (; n < n1; n += R) a0 += h[(size_t)n * width + c];
+    }
+    part[tid] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (tid < width) {
+        float s = 0.f;
+        for (int rr = 0; rr < R; ++rr) s += part[rr * width + tid];
+        const int cnt = n1 - n0;
+        s = s / (float)(cnt > 1 ? cnt : 1);
+        pl[tid] = s;
+        pooled[(size_t)g * width + tid] = s;
+    }
+    __syncthreads();
+    for (int o = tid; o < C; o += kPoolThreads) {
+        float acc = b ? b[o] : 0.f;
+        const float* wr = W + (size_t)o * width;
+        for (int k = 0; k < width; ++k) acc = fmaf(pl[k], wr[k], acc);
+        y[(size_t)g * C + o] = acc;
+    }
+}
+
+// backward of the pair: blocks [0, node_blocks) write g_h[n, k] = (sum_c g_y[g(n), c] W[c, k]) / count(g(n)); the blocks
+// behind them the parameter gradients g_W[c, k] = sum_g g_y[g, c] pooled[g, k], g_b[c] = sum_g g_y[g, c] (g ascending)
+__global__ void __launch_bounds__(256)
+k_pool_head_bwd(const float* __restrict__ gy, const float* __restrict__ pooled, const float* __restrict__ W,
+                const int32_t* __restrict__ gptr, float* __restrict__ gh, float* __restrict__ gW,
+                float* __restrict__ gb, int B, int N, int width, int C, int node_blocks) {
+    if ((int)blockIdx.x >= node_blocks) {
+        const int o = ((int)blockIdx.x - node_blocks) * 256 + threadIdx.x;
+        if (o >= C * width) return;
+        const int c = o / width, k = o - c * width;
+        float s = 0.f, t = 0.f;
+        for (int g = 0; g < B; ++g) {
+            const float v = gy[(size_t)g * C + c];
+            s = fmaf(v, pooled[(size_t)g * width + k], s);
+            t += v;
+        }
+        gW[o] = s;
+        if (k == 0 && gb) gb[c] = t;
+        return;
+    }
+    if (!gh) return;
+    const long long total = (long long)N * width;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)node_blocks * 256) {
+        const int n = (int)(i / width), k = (int)(i % width);
+        int lo = 0, hi = B;  // largest g with gptr[g] <= n
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (gptr[mid] <= n) lo = mid; else hi = mid;
+        }
+        const int cnt = gptr[lo + 1] - gptr[lo];
+        float gp = 0.f;
+        for (int c = 0; c < C; ++c) gp = fmaf(gy[(size_t)lo * C + c], W[(size_t)c * width + k], gp);
+        gh[i] = gp / (float)(cnt > 1 ? cnt : 1);
+    }
+}
+
+// nn.BCEWithLogitsLoss() (mean reduction; point_neural_network_base.py:74, :365) in one launch: the loss and, kept for
+// the backward, d loss / d x = (sigmoid(x) - t) / n. One workgroup, fixed summation order.
+__global__ void __launch_bounds__(256)
+k_bce_logits_fwd(const float* __restrict__ x, const float* __restrict__ t, int n, float* __restrict__ loss,
+                 float* __restrict__ grad) {
+    __shared__ float part[256];
+    const int tid = threadIdx.x;
+    const float inv_n = 1.0f / (float)n;
+    float acc = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const float xi = x[i], ti = t[i];
+        acc += fmaxf(xi, 0.f) - xi * ti + log1pf(expf(-fabsf(xi)));
+        grad[i] = (1.0f / (1.0f + expf(-xi)) - ti) * inv_n;
+    }
+    part[tid] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) part[tid] += part[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) loss[0] = part[0] * inv_n;
+}
+
+__global__ void k_scale_by_device_scalar(const float* __restrict__ a, const float* __restrict__ scalar, int n,
+                                         float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] * scalar[0];
+}
+
 __global__ void k_mean_pool_bwd(const float* __restrict__ gp, const int32_t* __restrict__ gptr,
                                 float* __restrict__ gh, int B, int N, int width) {
     long long total = (long long)N * width;
@@ -310,7 +416,7 @@ k_linear_mfma(float* __restrict__ y, int ldy, const float* __restrict__ x, int l
               const float* __restrict__ x2, int ldx2, const float* __restrict__ W, int swc, int swk,
               const float* __restrict__ W2, int swc2, int swk2, const float* __restrict__ b, int N,
               int accumulate, int epi, const float* __restrict__ aux_in, int ld_in, float* __restrict__ aux_out,
-              int ld_out) {
+              int ld_out, PvsLinearExt ext) {
     // epi (elementwise epilogue on the accumulator, saves a pass over [N,C]):
     //   1: aux_out = SiLU(y)          2: aux_out = aux_in + y          3: y *= SiLU'(aux_in)
     //   4: aux_out = y
@@ -321,11 +427,13 @@ k_linear_mfma(float* __restrict__ y, int ldy, const float* __restrict__ x, int l
     const int k1 = 32 * kb1;
     for (int i = threadIdx.x; i < C * K; i += kThreads) {
         const int c = i / K, k = i % K;
-        Wn[c * LD + k] = k < k1 ? W[(size_t)c * swc + (size_t)k * swk]
+        const long long sh = (CB > 1 && c >= 32) ? ext.w_shift1 : 0;
+        Wn[c * LD + k] = k < k1 ? W[(long long)c * swc + (long long)k * swk + sh]
                                 : W2[(size_t)c * swc2 + (size_t)(k - k1) * swk2];
     }
-    for (int c = threadIdx.x; c < C; c += kThreads) bias[c] = b ? b[c] : 0.f;
+    for (int c = threadIdx.x; c < C; c += kThreads) bias[c] = (b && c < 32 * ext.bias_blocks) ? b[c] : 0.f;
     __syncthreads();
+    const bool side = ext.zero_rows || ext.zero3 || ext.copy3_dst || ext.scale3_dst;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 31, hh = lane >> 5;
     const int n_tiles = (N + 31) / 32;
@@ -344,15 +452,36 @@ k_linear_mfma(float* __restrict__ y, int ldy, const float* __restrict__ x, int l
                 v[bb][4 * g] = q.x; v[bb][4 * g + 1] = q.y; v[bb][4 * g + 2] = q.z; v[bb][4 * g + 3] = q.w;
             }
         }
+        if (side && valid) {      // the folded per-row launches
+            if (ext.zero_rows) {
+                float* zr = ext.zero_rows + (size_t)n * ext.zero_ld;
+                for (int q = 4 * hh; q < ext.zero_w; q += 8) *reinterpret_cast<float4*>(zr + q) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (hh == 0) {
+                if (ext.zero3) { ext.zero3[3 * n] = 0.f; ext.zero3[3 * n + 1] = 0.f; ext.zero3[3 * n + 2] = 0.f; }
+                if (ext.copy3_dst) {
+                    ext.copy3_dst[3 * n] = ext.copy3_src[3 * n]; ext.copy3_dst[3 * n + 1] = ext.copy3_src[3 * n + 1];
+                    ext.copy3_dst[3 * n + 2] = ext.copy3_src[3 * n + 2];
+                }
+                if (ext.scale3_dst) {
+                    const float by = ext.scale3_by[n];
+                    ext.scale3_dst[3 * n] = ext.scale3_src[3 * n] * by; ext.scale3_dst[3 * n + 1] = ext.scale3_src[3 * n + 1] * by;
+                    ext.scale3_dst[3 * n + 2] = ext.scale3_src[3 * n + 2] * by;
+                }
+            }
+        }
         f32x16 acc[CB];
-        float* dst = y + (size_t)nn * ldy;
+        float* dst0 = y + (size_t)nn * ldy;
+        float* dst1 = (CB > 1 && ext.y1) ? ext.y1 + (size_t)nn * ext.ldy1 - 32 : dst0;
+        const int acc_flag1 = ext.acc1 < 0 ? accumulate : ext.acc1;
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 bq = *reinterpret_cast<const float4*>(bias + 32 * cb + 8 * g + 4 * hh);
                 float4 init = bq;
-                if (accumulate) {
+                float* dst = cb == 1 ? dst1 : dst0;
+                if (cb == 1 ? acc_flag1 : accumulate) {
                     const float4 old = *reinterpret_cast<const float4*>(dst + 32 * cb + 8 * g + 4 * hh);
                     init.x += old.x; init.y += old.y; init.z += old.z; init.w += old.w;
                 }
@@ -366,6 +495,7 @@ k_linear_mfma(float* __restrict__ y, int ldy, const float* __restrict__ x, int l
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int off = 32 * cb + 8 * g + 4 * hh;
+                    float* dst = cb == 1 ? dst1 : dst0;
                     float4 r = make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
                     if (epi == 3) {
                         const float4 z = *reinterpret_cast<const float4*>(aux_in + (size_t)nn * ld_in + off);
@@ -581,8 +711,13 @@ bool pvs_linear_epilogue_supported(int ldy, int ldx, int ldx2, int K, int K2, in
 int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx, const float* W,
                       int swc, int swk, const float* b, const float* x2, int ldx2, const float* W2,
                       int swc2, int swk2, int N, int K, int K2, int C, bool accumulate, int epi,
-                      const float* aux_in, int ld_in, float* aux_out, int ld_out) {
+                      const float* aux_in, int ld_in, float* aux_out, int ld_out, const PvsLinearExt* ext) {
     PVS_REQUIRE(C >= 1, "linear: n_out %d unsupported", C);
+    PVS_REQUIRE(!ext || (pvs_linear_epilogue_supported(ldy, ldx, x2 ? ldx2 : 0, K, K2, C, y, x, x2) &&
+                         ext->zero_w % 8 == 0 && (ext->zero_ld & 3) == 0 && ((uintptr_t)ext->zero_rows & 15) == 0 &&
+                         (!ext->y1 || (C == 64 && (ext->ldy1 & 3) == 0 && ((uintptr_t)ext->y1 & 15) == 0))),
+                "linear: the extras need the MFMA path");
+    const PvsLinearExt ext_v = ext ? *ext : PvsLinearExt{};
     if (C > kThreads) {
         // more output channels than one pass holds (one per thread): chunks of the output dimension (the input
         // gradient of a layer whose input is wider than 256: edge_mlp.0 at hidden size 128 on the decomposed path)
@@ -632,7 +767,7 @@ int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx,
 #define PVS_LIN(KBV, CBV)                                                                          \
     k_linear_mfma<KBV, CBV><<<blocks_m, kThreads, lds_m, s>>>(y, ldy, x, ldx, K / 32, x2, ldx2, W, swc, \
                                                               swk, W2, swc2, swk2, b, N, accumulate ? 1 : 0, \
-                                                              epi, aux_in, ld_in, aux_out, ld_out)
+                                                              epi, aux_in, ld_in, aux_out, ld_out, ext_v)
         if (kb == 1 && cb == 1) PVS_LIN(1, 1);
         else if (kb == 2 && cb == 1) PVS_LIN(2, 1);
         else if (kb == 4 && cb == 1) PVS_LIN(4, 1);
@@ -848,6 +983,44 @@ extern "C" int pvs_mean_pool_bwd(const float* g_pooled, const int32_t* graph_ptr
     if (N <= 0) return 0;
     int blocks = grid_for((long long)N * width, 256);
     k_mean_pool_bwd<<<blocks, 256, 0, (hipStream_t)stream>>>(g_pooled, graph_ptr, g_h, B, N, width);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pvs_pool_head_fwd(const float* h, const int32_t* graph_ptr, const float* w, const float* b, float* pooled,
+                                 float* y, int32_t B, int32_t width, int32_t n_out, pvs_stream_t stream) {
+    PVS_REQUIRE(width >= 1 && width <= kPoolThreads && n_out >= 1, "pool_head: width %d / n_out %d unsupported", width,
+                n_out);
+    if (B <= 0) return 0;
+    k_pool_head_fwd<<<B, kPoolThreads, 0, (hipStream_t)stream>>>(h, graph_ptr, w, b, pooled, y, width, n_out);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pvs_pool_head_bwd(const float* g_y, const float* pooled, const float* w, const int32_t* graph_ptr,
+                                 float* g_h, float* g_w, float* g_b, int32_t B, int32_t N, int32_t width, int32_t n_out,
+                                 pvs_stream_t stream) {
+    PVS_REQUIRE(width >= 1 && n_out >= 1 && g_w, "pool_head_bwd: bad arguments");
+    const int node_blocks = (g_h && N > 0) ? grid_for((long long)N * width, 256) : 0;
+    const int w_blocks = (n_out * width + 255) / 256;
+    k_pool_head_bwd<<<node_blocks + w_blocks, 256, 0, (hipStream_t)stream>>>(g_y, pooled, w, graph_ptr, g_h, g_w, g_b, B,
+                                                                           N, width, n_out, node_blocks);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pvs_bce_logits_fwd(const float* x, const float* target, int32_t n, float* loss, float* grad,
+                                  pvs_stream_t stream) {
+    PVS_REQUIRE(n >= 1 && x && target && loss && grad, "bce_logits: bad arguments");
+    k_bce_logits_fwd<<<1, 256, 0, (hipStream_t)stream>>>(x, target, n, loss, grad);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pvs_scale_by_device_scalar(const float* a, const float* scalar, int32_t n, float* out,
+                                          pvs_stream_t stream) {
+    if (n <= 0) return 0;
+    k_scale_by_device_scalar<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(a, scalar, n, out);
     PVS_CHECK_LAUNCH();
     return 0;
 }

@@ -29,6 +29,7 @@ struct PvsEdgeFwdIO {
     float* smax;          // [N] softmax running max  (softmax only)
     float* ssum;          // [N] softmax denominator  (softmax only)
     float* m_scratch;     // [E,H] (H = 128 without m_out: the two launches of the edge forward hand the messages over) or NULL
+    bool init_done = false;   // Magg = 0 / x_out = x (or 0) already written by the caller (folded into the P/Q product)
 };
 
 struct PvsEdgeBwdIO {

@@ -348,7 +348,7 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     PVS_REQUIRE(w.n_attr <= PVS_MAX_EDGE_ATTR, "edge_attr classes %d > %d", w.n_attr,
                 PVS_MAX_EDGE_ATTR);
     // rows without edges are never flushed: M = 0, x_out = x
-    {
+    if (!io.init_done) {
         const long long threads = (long long)g.n_nodes * (H / 4);
         k_init_fwd<<<(int)((threads + 255) / 256), 256, 0, s>>>(io.Magg, (flags & PVS_UPDATE_COORDS) ? io.x : nullptr,
                                                                 io.x_out, g.n_nodes, H, (flags & kFwdRawXsum) ? 1 : 0);

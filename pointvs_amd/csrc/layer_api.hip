@@ -225,12 +225,36 @@ int node_mlp_forward(hipStream_t s, const Dims& m, const PvsLayerDesc* d, const 
     return 0;
 }
 
+// `init` (MFMA edge forward only): the edge kernel never flushes rows without edges, so Magg = 0 and x_out = x (0 for
+// raw sums) are written first - as side jobs of the P/Q product (the node rows are dealt to its lanes anyway) where the
+// MFMA linear takes the shape, else by the edge launcher's own small kernel (io->init_done stays false).
 int node_pre_forward(hipStream_t s, const Dims& m, const PvsLayerParams* p, const float* h,
-                     float* PQ) {
+                     float* PQ, PvsEdgeFwdIO* init = nullptr, uint32_t init_flags = 0) {
     const int H = m.H;
+    static const bool split_small = getenv("PVS_EGNN_SPLIT_SMALL") != nullptr;     // (the launches apart, for A/B)
+    PvsLinearExt e;
+    if (init) {
+        e.zero_rows = init->Magg; e.zero_w = H; e.zero_ld = H;
+        if (init_flags & kFwdRawXsumFlag) e.zero3 = init->x_out;
+        else if (init_flags & PVS_UPDATE_COORDS) { e.copy3_src = init->x; e.copy3_dst = init->x_out; }
+    }
+    const bool side_ok = init && !split_small && ((uintptr_t)init->Magg & 15) == 0;
+    if (H == 32 && !split_small && pvs_linear_epilogue_supported(2 * H, H, 0, H, 0, 2 * H, PQ, h, nullptr) &&
+        (!init || side_ok)) {
+        // P | Q in one launch: 64 outputs, the second column block on the Q slice of edge_mlp.0's weight, no bias
+        e.w_shift1 = (long long)m.off_q - 32LL * m.ld1;
+        e.bias_blocks = 1;
+        PVS_TRY(pvs_launch_linear(s, PQ, 2 * H, h, H, p->edge_w1, m.ld1, 1, p->edge_b1, nullptr, 0, nullptr, 0, 0, m.N,
+                                  H, 0, 2 * H, false, PVS_EPI_NONE, nullptr, 0, nullptr, 0, &e));
+        if (init) init->init_done = true;
+        return 0;
+    }
+    const bool ext_p = side_ok && pvs_linear_epilogue_supported(2 * H, H, 0, H, 0, H, PQ, h, nullptr);
     // P = W1[:, 0:H] h + b1 (row part), Q = W1[:, off_q:off_q+H] h (col part)
     PVS_TRY(pvs_launch_linear(s, PQ, 2 * H, h, H, p->edge_w1, m.ld1, 1, p->edge_b1, nullptr, 0,
-                              nullptr, 0, 0, m.N, H, 0, H, false));
+                              nullptr, 0, 0, m.N, H, 0, H, false, PVS_EPI_NONE, nullptr, 0, nullptr, 0,
+                              ext_p ? &e : nullptr));
+    if (ext_p) init->init_done = true;
     PVS_TRY(pvs_launch_linear(s, PQ + H, 2 * H, h, H, p->edge_w1 + m.off_q, m.ld1, 1, nullptr,
                               nullptr, 0, nullptr, 0, 0, m.N, H, 0, H, false));
     return 0;
@@ -285,11 +309,12 @@ extern "C" int pvs_egnn_layer_fwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     const PvsEdgeW ew = make_edge_w(m, p);
     const PvsNodeW nw = make_node_w(d, p);
 
-    PVS_TRY(node_pre_forward(s, m, p, h, sPQ));
     PvsEdgeFwdIO io;
     io.PQ = sPQ; io.x = x; io.m_prev = m_prev; io.Magg = Magg; io.x_out = x_out; io.m_out = m_out;
     io.att_out = att_out; io.smax = w.smax; io.ssum = w.ssum; io.m_scratch = w.m_scratch;
-    if (pvs_use_mfma() && pvs_edge_mfma_supported(H, d->flags))
+    const bool mfma_fwd = pvs_use_mfma() && pvs_edge_mfma_supported(H, d->flags);
+    PVS_TRY(node_pre_forward(s, m, p, h, sPQ, mfma_fwd ? &io : nullptr, d->flags));
+    if (mfma_fwd)
         PVS_TRY(pvs_launch_edge_fwd_mfma(s, H, *g, ew, d->flags | pvs_ablate_bits(), d->att_act, io));
     else
         PVS_TRY(pvs_launch_edge_fwd_v0(s, H, *g, ew, d->flags, d->att_act, io));
@@ -357,10 +382,10 @@ extern "C" int pvs_egnn_layer_edge_sums(const PvsLayerDesc* d, const PvsGraph* g
     float* att = arena.take<float>((size_t)(m.E > 0 ? m.E : 1));
     PVS_REQUIRE(arena.ok(), "pvs_egnn_layer_edge_sums: workspace too small (%zu < %zu)", workspace_bytes, arena.off);
     const PvsEdgeW ew = make_edge_w(m, p);
-    PVS_TRY(node_pre_forward(s, m, p, h, w.PQ));
     PvsEdgeFwdIO io;
     io.PQ = w.PQ; io.x = x; io.m_prev = nullptr; io.Magg = magg; io.x_out = xsum; io.m_out = nullptr;
     io.att_out = att; io.smax = w.smax; io.ssum = w.ssum; io.m_scratch = w.m_scratch;
+    PVS_TRY(node_pre_forward(s, m, p, h, w.PQ, &io, d->flags | kFwdRawXsumFlag));
     PVS_TRY(pvs_launch_edge_fwd_mfma(s, m.H, *g, ew, d->flags | kFwdRawXsumFlag, d->att_act, io));
     if (!(d->flags & PVS_UPDATE_COORDS))
         PVS_CHECK_HIP(hipMemsetAsync(xsum, 0, sizeof(float) * 3 * (size_t)m.N, s));
@@ -391,10 +416,10 @@ extern "C" int pvs_egnn_layer_fwd_partial(const PvsLayerDesc* d, const PvsGraph*
     float* so = sy1 + (size_t)m.N * H;
     const PvsEdgeW ew = make_edge_w(m, p);
     const PvsNodeW nw = make_node_w(d, p);
-    PVS_TRY(node_pre_forward(s, m, p, h, sPQ));
     PvsEdgeFwdIO io;
     io.PQ = sPQ; io.x = x; io.m_prev = nullptr; io.Magg = Magg; io.x_out = x_out; io.m_out = nullptr;
     io.att_out = att; io.smax = w.smax; io.ssum = w.ssum; io.m_scratch = w.m_scratch;
+    PVS_TRY(node_pre_forward(s, m, p, h, sPQ, &io, d->flags | kFwdRawXsumFlag));
     pvs_prof_set_fwd_tag(PVS_PROF_EDGE_FWD_PARTIAL);      // timed apart from the full-graph layers (bench.py)
     const int rc_partial = pvs_launch_edge_fwd_mfma(s, H, *g, ew, d->flags | kFwdRawXsumFlag, d->att_act, io);
     pvs_prof_set_fwd_tag(PVS_PROF_EDGE_FWD);
@@ -451,8 +476,13 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     const float* su = so + (size_t)N * H;      // u = SiLU(GN(y1)) kept by the forward
 
     // ---- node_model backward ----
-    PVS_TRY(pvs_node_out_bwd(s, H, g_h_out, so, h, nw, F, d->att_act, N, w.g_o, g_h, w.gl, w.t1,
-                             w.tg));
+    // (no residual, no node gate: g_o = g_h_out and the residual's part of g_h is zero - nothing to launch)
+    static const bool split_small = getenv("PVS_EGNN_SPLIT_SMALL") != nullptr;     // (the launches apart, for A/B)
+    const bool plain_out = !(F & PVS_RESIDUAL) && !natt && !split_small;
+    const float* g_o = plain_out ? g_h_out : w.g_o;
+    if (!plain_out)
+        PVS_TRY(pvs_node_out_bwd(s, H, g_h_out, so, h, nw, F, d->att_act, N, w.g_o, g_h, w.gl, w.t1,
+                                 w.tg));
     if (natt) {
         if (gr.node_att_w)
             PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.node_att_w, w.t1, H, nullptr, 0, nullptr,
@@ -468,15 +498,15 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     }
     // o = u Wn2^T + bn2
     // (without GraphNorm g_y1 = g_u * SiLU'(y1) rides on this product's epilogue)
-    const bool fuse_tail_bwd = !gn && pvs_linear_epilogue_supported(H, H, 0, H, 0, H, w.g_u, w.g_o, nullptr) &&
+    const bool fuse_tail_bwd = !gn && pvs_linear_epilogue_supported(H, H, 0, H, 0, H, w.g_u, g_o, nullptr) &&
                                ((uintptr_t)sy1 & 15) == 0;
-    PVS_TRY(pvs_launch_linear(s, w.g_u, H, w.g_o, H, p->node_w2, 1, H, nullptr, nullptr, 0, nullptr, 0,
+    PVS_TRY(pvs_launch_linear(s, w.g_u, H, g_o, H, p->node_w2, 1, H, nullptr, nullptr, 0, nullptr, 0,
                               0, N, H, 0, H, false, fuse_tail_bwd ? PVS_EPI_MUL_SILU_GRAD : PVS_EPI_NONE, sy1, H,
                               nullptr, 0));
     if (gr.node_w2 && !fused_wgrads)
-        PVS_TRY(pvs_launch_tsgemm_tn(s, gr.node_w2, H, w.g_o, H, su, H, N, H, H, w.dslabs, false));
+        PVS_TRY(pvs_launch_tsgemm_tn(s, gr.node_w2, H, g_o, H, su, H, N, H, H, w.dslabs, false));
     if (gr.node_b2 && !fused_wgrads)
-        PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.node_b2, w.g_o, H, nullptr, 0, nullptr, N, H,
+        PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.node_b2, g_o, H, nullptr, 0, nullptr, N, H,
                                      1.f, w.dslabs, false));
     // u = SiLU(GN(y1)) ; g_u becomes g_yn then g_y1 in place
     if (!fuse_tail_bwd) PVS_TRY(pvs_node_tail_bwd1(s, w.g_u, sy1, stats, nw, N, H, w.g_u));
@@ -491,10 +521,31 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     }
     float* g_y1 = w.g_u;
     // y1 = h Wn1[:, :H]^T + Magg Wn1[:, H:]^T + bn1
-    PVS_TRY(pvs_launch_linear(s, g_h, H, g_y1, H, p->node_w1, 1, 2 * H, nullptr, nullptr, 0, nullptr,
-                              0, 0, N, H, 0, H, true));
-    PVS_TRY(pvs_launch_linear(s, w.gM, H, g_y1, H, p->node_w1 + H, 1, 2 * H, nullptr, nullptr, 0,
-                              nullptr, 0, 0, N, H, 0, H, false));
+    // The per-node preparation of the edge backward (clear the row part of gPQ and gx_row - rows without edges are
+    // never written by the MFMA edge backward -, g_x_out / deg) rides on these products as side jobs of the node rows
+    // where the MFMA linear takes the shape; the softmax row dots need the finished gM and keep their own launch.
+    const bool mfma_bwd = pvs_use_mfma() && pvs_edge_bwd_mfma_supported(H, F, m.A);
+    PvsLinearExt prep;
+    if (mfma_bwd) { prep.zero_rows = w.gPQ; prep.zero_w = H; prep.zero_ld = 2 * H; prep.zero3 = w.gx_row; }
+    if (coord_bwd) { prep.scale3_src = g_x_out; prep.scale3_by = g->inv_deg; prep.scale3_dst = w.gxagg; }
+    const bool prep_side = !split_small && ((uintptr_t)w.gPQ & 15) == 0 &&
+                           pvs_linear_epilogue_supported(H, H, 0, H, 0, H, w.gM, g_y1, nullptr);
+    bool prep_done = false;
+    if (H == 32 && prep_side && pvs_linear_epilogue_supported(H, H, 0, H, 0, 2 * H, g_h, g_y1, nullptr)) {
+        // g_h (+)= and gM = in one launch: 64 outputs over the two halves of node_mlp.0's weight, the second column
+        // block to gM
+        prep.y1 = w.gM; prep.ldy1 = H; prep.acc1 = 0;
+        PVS_TRY(pvs_launch_linear(s, g_h, H, g_y1, H, p->node_w1, 1, 2 * H, nullptr, nullptr, 0, nullptr, 0, 0, N, H, 0,
+                                  2 * H, !plain_out, PVS_EPI_NONE, nullptr, 0, nullptr, 0, &prep));
+        prep_done = true;
+    } else {
+        PVS_TRY(pvs_launch_linear(s, g_h, H, g_y1, H, p->node_w1, 1, 2 * H, nullptr, nullptr, 0, nullptr,
+                                  0, 0, N, H, 0, H, !plain_out));
+        PVS_TRY(pvs_launch_linear(s, w.gM, H, g_y1, H, p->node_w1 + H, 1, 2 * H, nullptr, nullptr, 0,
+                                  nullptr, 0, 0, N, H, 0, H, false, PVS_EPI_NONE, nullptr, 0, nullptr, 0,
+                                  prep_side ? &prep : nullptr));
+        prep_done = prep_side;
+    }
     if (gr.node_w1 && !fused_wgrads) {
         PVS_TRY(pvs_launch_tsgemm_tn(s, gr.node_w1, 2 * H, g_y1, H, h, H, N, H, H, w.dslabs, false));
         PVS_TRY(pvs_launch_tsgemm_tn(s, gr.node_w1 + H, 2 * H, g_y1, H, Magg, H, N, H, H, w.dslabs,
@@ -505,11 +556,14 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
                                      1.f, w.dslabs, false));
 
     // ---- edge backward ----
-    const bool mfma_bwd = pvs_use_mfma() && pvs_edge_bwd_mfma_supported(H, F, m.A);
-    // (MFMA path: rows without edges are never written by the edge kernel: cleared here)
-    PVS_TRY(pvs_prep_edge_bwd(s, g_x_out, g->inv_deg, Magg, w.gM, N, H,
-                              coord_bwd ? w.gxagg : nullptr, (eatt && soft) ? w.softD : nullptr,
-                              mfma_bwd ? w.gPQ : nullptr, mfma_bwd ? w.gx_row : nullptr));
+    // (MFMA path: rows without edges are never written by the edge kernel: cleared here, unless done above)
+    if (prep_done)
+        PVS_TRY(pvs_prep_edge_bwd(s, g_x_out, g->inv_deg, Magg, w.gM, N, H, nullptr,
+                                  (eatt && soft) ? w.softD : nullptr, nullptr, nullptr));
+    else
+        PVS_TRY(pvs_prep_edge_bwd(s, g_x_out, g->inv_deg, Magg, w.gM, N, H,
+                                  coord_bwd ? w.gxagg : nullptr, (eatt && soft) ? w.softD : nullptr,
+                                  mfma_bwd ? w.gPQ : nullptr, mfma_bwd ? w.gx_row : nullptr));
     PvsEdgeBwdIO io;
     io.PQ = sPQ; io.x = x; io.m_prev = m_prev; io.att = att; io.gM = w.gM;
     io.gxagg = coord_bwd ? w.gxagg : nullptr;
@@ -546,7 +600,7 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     PvsNodeWgradOut node_out{};
     if (fused_wgrads) {
         PvsNodeWgradIn wi;
-        wi.g_o = w.g_o; wi.g_y1 = g_y1; wi.gPQ = w.gPQ; wi.u = su; wi.h = h; wi.Magg = Magg;
+        wi.g_o = g_o; wi.g_y1 = g_y1; wi.gPQ = w.gPQ; wi.u = su; wi.h = h; wi.Magg = Magg;
         PvsNodeWgradOut wo;
         wo.node_w2 = gr.node_w2; wo.node_w1 = gr.node_w1; wo.edge_w1 = gr.edge_w1;
         wo.node_b2 = gr.node_b2; wo.node_b1 = gr.node_b1; wo.edge_b1 = gr.edge_b1;

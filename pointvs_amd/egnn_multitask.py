@@ -57,7 +57,6 @@ class MultitaskSatorrasEGNN(SartorrasEGNN):
 
     def forward(self, graph):
         feats, pg, graph_ptr, n_graphs = self._embed_graph(graph)
-        pooled = self._pool(feats, graph_ptr, n_graphs)
         if 'classification' in self.model_task:
-            return self._run_head(self.feats_linear_layers_pose, pooled)
-        return self._run_head(self.feats_linear_layers_affinity, pooled)
+            return self._pool_and_head(self.feats_linear_layers_pose, feats, graph_ptr, n_graphs)
+        return self._pool_and_head(self.feats_linear_layers_affinity, feats, graph_ptr, n_graphs)

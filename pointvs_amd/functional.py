@@ -222,6 +222,83 @@ def mean_pool(h, graph_ptr):
     return _MeanPoolFn.apply(h, graph_ptr)
 
 
+class _PoolHeadFn(torch.autograd.Function):
+    """global_mean_pool + the head's first Linear in one launch, their backward in one launch
+    (pnn_geometric_base.py:29-36, egnn_multitask.py:158-166)."""
+
+    @staticmethod
+    def forward(ctx, h, graph_ptr, w, b):
+        h, w, b = _f32c(h), _f32c(w), _f32c(b)
+        _lib.require_hip(h, graph_ptr, w, b)
+        n_graphs, width, n_out = graph_ptr.numel() - 1, h.shape[1], w.shape[0]
+        pooled = torch.empty((n_graphs, width), dtype=torch.float32, device=h.device)
+        y = torch.empty((n_graphs, n_out), dtype=torch.float32, device=h.device)
+        _lib.check(_lib.lib().pvs_pool_head_fwd(_lib.ptr(h), _lib.ptr(graph_ptr), _lib.ptr(w), _lib.ptr(b),
+                                                _lib.ptr(pooled), _lib.ptr(y), n_graphs, width, n_out,
+                                                _stream(h.device)), 'pvs_pool_head_fwd')
+        ctx.save_for_backward(pooled, w)
+        ctx.graph_ptr, ctx.n, ctx.has_bias = graph_ptr, h.shape[0], b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        pooled, w = ctx.saved_tensors
+        g_y = _f32c(g_y)
+        n_graphs, width = pooled.shape
+        n_out = w.shape[0]
+        dev = g_y.device
+        g_h = torch.empty((ctx.n, width), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        g_w = torch.empty_like(w)
+        g_b = torch.empty((n_out,), dtype=torch.float32, device=dev) if ctx.has_bias else None
+        _lib.check(_lib.lib().pvs_pool_head_bwd(_lib.ptr(g_y), _lib.ptr(pooled), _lib.ptr(w), _lib.ptr(ctx.graph_ptr),
+                                                _lib.ptr(g_h), _lib.ptr(g_w), _lib.ptr(g_b), n_graphs, ctx.n, width,
+                                                n_out, _stream(dev)), 'pvs_pool_head_bwd')
+        return g_h, None, g_w, g_b
+
+
+POOL_HEAD_MAX_WIDTH = 1024
+
+
+def pool_head(h, graph_ptr, weight, bias=None):
+    """linear(mean_pool(h, graph_ptr), weight, bias) as one op (hidden widths up to POOL_HEAD_MAX_WIDTH)."""
+    return _PoolHeadFn.apply(h, graph_ptr, weight, bias)
+
+
+class _BceLogitsMeanFn(torch.autograd.Function):
+    """nn.BCEWithLogitsLoss() (mean) as one launch forward (loss + the gradient factor), one backward."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        shape = x.shape
+        x, target = _f32c(x).reshape(-1), _f32c(target).reshape(-1)
+        _lib.require_hip(x, target)
+        n = x.numel()
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x)
+        _lib.check(_lib.lib().pvs_bce_logits_fwd(_lib.ptr(x), _lib.ptr(target), n, _lib.ptr(loss), _lib.ptr(grad),
+                                                 _stream(x.device)), 'pvs_bce_logits_fwd')
+        ctx.save_for_backward(grad)
+        ctx.shape = shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        grad, = ctx.saved_tensors
+        g_loss = _f32c(g_loss)
+        out = torch.empty_like(grad)
+        _lib.check(_lib.lib().pvs_scale_by_device_scalar(_lib.ptr(grad), _lib.ptr(g_loss), grad.numel(), _lib.ptr(out),
+                                                         _stream(grad.device)), 'pvs_scale_by_device_scalar')
+        return out.reshape(ctx.shape), None
+
+
+def bce_with_logits_mean(y_pred, y_true):
+    if y_pred.shape != y_true.shape:
+        raise ValueError(f'Target size ({tuple(y_true.shape)}) must be the same as input size ({tuple(y_pred.shape)})')
+    if y_pred.numel() == 0:
+        raise ValueError('bce_with_logits_mean: empty input')
+    return _BceLogitsMeanFn.apply(y_pred, y_true)
+
+
 class _SegmentReduceFn(torch.autograd.Function):
     """unsorted_segment_sum / unsorted_segment_mean (egnn_satorras.py:332-347)."""
 

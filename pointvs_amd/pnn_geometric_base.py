@@ -6,6 +6,7 @@ Mirrors /root/reference/point_vs/models/geometric/pnn_geometric_base.py:
   PNNGeometricBase.unpack_graph              :55-58
   PygLinearPass                              :61-94
 """
+import os
 from abc import abstractmethod
 
 import torch
@@ -74,10 +75,25 @@ class PNNGeometricBase(PointNeuralNetworkBase):
             out = PF.linear(out, mod.weight, mod.bias) if isinstance(mod, nn.Linear) else mod(out)
         return out
 
+    @classmethod
+    def _pool_and_head(cls, head, feats, graph_ptr, n_graphs):
+        """head(pool(feats)) (:29-36). A head that starts with a Linear takes the pooling and that Linear as one
+        op (PF.pool_head: one launch forward, one backward)."""
+        mods = list(head)
+        if (not mods or not isinstance(mods[0], nn.Linear) or feats.size(1) > PF.POOL_HEAD_MAX_WIDTH
+                or os.environ.get('PVS_FUSED_HEAD') == '0'):       # (=0: the two ops apart, for A/B)
+            return cls._run_head(head, cls._pool(feats, graph_ptr, n_graphs))
+        if n_graphs == 1:
+            whole = torch.tensor([0, feats.size(0)], dtype=torch.int32, device=feats.device)
+            out = PF.pool_head(feats, whole, mods[0].weight, mods[0].bias).reshape(-1)
+        else:
+            out = PF.pool_head(feats, graph_ptr, mods[0].weight, mods[0].bias)
+        return cls._run_head(mods[1:], out)
+
     def forward(self, x):
         feats, _, graph_ptr, n_graphs = self._embed_graph(x)
         if self.feats_linear_layers is not None:
-            feats = self._run_head(self.feats_linear_layers, self._pool(feats, graph_ptr, n_graphs))
+            feats = self._pool_and_head(self.feats_linear_layers, feats, graph_ptr, n_graphs)
         return feats
 
     def unpack_input_data_and_predict(self, input_data):

@@ -21,6 +21,7 @@ import torch
 import yaml
 from torch import nn
 
+from . import functional as PF
 from .global_objects import DEVICE
 from .optim import FusedClipAdam
 
@@ -89,6 +90,9 @@ class PointNeuralNetworkBase(nn.Module):
 
     def get_loss(self, y_true, y_pred):
         if self.model_task == 'classification':
+            if (y_pred.is_cuda and y_pred.dtype == torch.float32      # nn.BCEWithLogitsLoss() as one launch each way
+                    and os.environ.get('PVS_FUSED_HEAD') != '0'):
+                return PF.bce_with_logits_mean(y_pred, y_true.to(device=y_pred.device, dtype=torch.float32))
             return self.bce(y_pred, y_true.to(y_pred.device))
         if self.model_task == 'regression':
             return self.regression_loss(y_pred, y_true.to(y_pred.device))

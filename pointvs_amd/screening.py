@@ -286,7 +286,7 @@ class ReceptorScreen:
                                                     need_coords=layer is not self.egnn[-1])
         if model.feats_linear_layers is None:
             return h
-        return model._run_head(model.feats_linear_layers, model._pool(h, self._graph_ptr, self.b))
+        return model._pool_and_head(model.feats_linear_layers, h, self._graph_ptr, self.b)
 
 
 class ScreeningSweep:

@@ -74,7 +74,7 @@ def test_forward_backward_match_reference(name):
     y_pred, _, _, _ = model.unpack_input_data_and_predict(make_batch(c))
     assert rel_err(y_pred.detach().cpu().numpy(), c.out['logits']) < TOL
     loss = model.get_loss(c.y_true.cuda(), y_pred)
-    assert abs(float(loss) - float(c.out['loss'])) < TOL * max(1.0, abs(float(c.out['loss'])))
+    assert abs(float(loss.detach()) - float(c.out['loss'])) < TOL * max(1.0, abs(float(c.out['loss'])))
     loss.backward()
     got_none = sorted(n for n, p in model.named_parameters() if p.grad is None)
     if c.grads:

@@ -310,6 +310,66 @@ def test_unsorted_segment_sum_and_mean():
         assert rel_err(d_gpu.grad.cpu().numpy(), d_ref.grad.numpy()) < 1e-6
 
 
+@pytest.mark.parametrize('width,n_out', [(32, 1), (64, 3), (100, 1), (128, 128), (1024, 2)])
+def test_pool_and_head_as_one_op(width, n_out):
+    """feats_linear_layers(global_mean_pool(feats, batch)) (pnn_geometric_base.py:29-36) as PF.pool_head - one launch
+    forward, one backward - against fp64 torch on CPU: ragged graphs, one empty graph, one single-node graph."""
+    from pointvs_amd import functional as PF
+    rng = np.random.default_rng(width + n_out)
+    counts = np.array([37, 0, 1, 500, 2000, 3, 64])
+    ptr = np.concatenate([[0], np.cumsum(counts)])
+    n = int(ptr[-1])
+    h = torch.from_numpy(rng.normal(size=(n, width)).astype(np.float32))
+    w = torch.from_numpy((rng.normal(size=(n_out, width)) / np.sqrt(width)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=(n_out,)).astype(np.float32))
+    up = torch.from_numpy(rng.normal(size=(len(counts), n_out)).astype(np.float32))
+    for bias in (b, None):
+        hg, wg = h.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+        bg = None if bias is None else bias.cuda().requires_grad_(True)
+        y = PF.pool_head(hg, torch.from_numpy(ptr).int().cuda(), wg, bg)
+        (y * up.cuda()).sum().backward()
+        hr, wr = h.double().requires_grad_(True), w.double().requires_grad_(True)
+        br = None if bias is None else bias.double().requires_grad_(True)
+        pooled = torch.stack([hr[ptr[g]:ptr[g + 1]].sum(0) / max(int(counts[g]), 1) for g in range(len(counts))])
+        yr = torch.nn.functional.linear(pooled, wr, br)
+        (yr * up.double()).sum().backward()
+        assert rel_err(y.detach().cpu().numpy(), yr.detach().numpy()) < 1e-6
+        assert rel_err(hg.grad.cpu().numpy(), hr.grad.numpy()) < 1e-6
+        assert rel_err(wg.grad.cpu().numpy(), wr.grad.numpy()) < 1e-6
+        if bias is not None:
+            assert rel_err(bg.grad.cpu().numpy(), br.grad.numpy()) < 1e-6
+        # the unfused pair gives the same values (same summation orders)
+        h2, w2 = h.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+        y2 = PF.linear(PF.mean_pool(h2, torch.from_numpy(ptr).int().cuda()), w2, None if bias is None else bias.cuda())
+        assert rel_err(y.detach().cpu().numpy(), y2.detach().cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize('n', [1, 32, 257, 5000])
+def test_bce_with_logits_as_one_op(n):
+    """nn.BCEWithLogitsLoss() (point_neural_network_base.py:74, :365) as PF.bce_with_logits_mean against torch in fp64,
+    logits from -90 to 90 (both tails of the stable form), hard and soft targets, an upstream gradient other than 1."""
+    from pointvs_amd import functional as PF
+    rng = np.random.default_rng(n)
+    x = torch.from_numpy(np.concatenate([rng.normal(size=n) * 3, [-90.0, 90.0, 0.0]])[:max(n, 1)].astype(np.float32))
+    if n >= 3:
+        x[:3] = torch.tensor([-90.0, 90.0, 0.0])
+    t = torch.from_numpy((rng.random(x.numel()) < 0.5).astype(np.float32))
+    t[::7] = 0.3
+    xg = x.cuda().requires_grad_(True)
+    loss = PF.bce_with_logits_mean(xg, t.cuda())
+    (2.5 * loss).backward()
+    xr = x.double().requires_grad_(True)
+    loss_ref = torch.nn.BCEWithLogitsLoss()(xr, t.double())
+    (2.5 * loss_ref).backward()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-6 * max(1.0, abs(float(loss_ref.detach())))
+    assert rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) < 1e-6
+    # the 2-D form the models produce ([B, 1] logits against [B, 1] labels), and a shape mismatch
+    l2 = PF.bce_with_logits_mean(x.cuda().reshape(-1, 1), t.cuda().reshape(-1, 1))
+    assert float(l2) == float(loss.detach())
+    with pytest.raises(ValueError):
+        PF.bce_with_logits_mean(x.cuda().reshape(-1, 1), t.cuda())
+
+
 def test_hipgraph_captured_step_matches_eager():
     """The whole training step (prepare + forward + loss + backward + clip + Adam) captured in a
     hipGraph and replayed gives the same parameters as the eager step (the C ABI allocates nothing
