@@ -163,10 +163,11 @@ namespace {
 
 // graph of edge e: one binary search per workgroup (for its first edge, shared through LDS), then a
 // short walk - consecutive edges belong to the same or the next few graphs
-__device__ __forceinline__ int graph_of_edge(const int32_t* __restrict__ edge_ptr, int n_graphs, int e, int E) {
+__device__ __forceinline__ int graph_of_edge(const int32_t* __restrict__ edge_ptr, int n_graphs, int e, int E,
+                                             int edges_per_thread = 1) {
     __shared__ int g_first;
     if (threadIdx.x == 0) {
-        const int e0 = min(blockIdx.x * blockDim.x, E - 1);
+        const int e0 = min((int)(blockIdx.x * blockDim.x) * edges_per_thread, E - 1);
         int lo = 0, hi = n_graphs;          // last g with edge_ptr[g] <= e0
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -180,40 +181,88 @@ __device__ __forceinline__ int graph_of_edge(const int32_t* __restrict__ edge_pt
     return g;
 }
 
+// One thread per PAIR of consecutive edges. The reference's format costs 40 bytes per edge here (int64 COO + int64
+// one-hot [E, 3]) against 9 written, so the pass is a stream of loads: VEC = 16-byte loads (two int64 per request:
+// rows, columns and the pair's 2A one-hot words; needs E even and 16-byte aligned arrays - the launcher checks).
+template <bool VEC>
 __global__ void k_extract_runs(const int64_t* __restrict__ ei, const int64_t* __restrict__ ea, int A, int N, int E,
                                int n_graphs, const int32_t* __restrict__ node_ptr, const int32_t* __restrict__ edge_ptr,
                                int32_t* __restrict__ row32, int32_t* __restrict__ col32, uint8_t* __restrict__ etype_in,
-                               int32_t* __restrict__ iota, int32_t* __restrict__ split, int32_t* __restrict__ status) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const int g = graph_of_edge(edge_ptr, n_graphs, min(e, E - 1), E);
-    if (e >= E) return;
-    int64_t r = ei[e], c = ei[(size_t)E + e];
-    int bad = 0;
-    if (r < 0 || r >= N || c < 0 || c >= N) { bad |= 1; r = 0; c = 0; }
-    if (r < node_ptr[g] || r >= node_ptr[g + 1] || c < node_ptr[g] || c >= node_ptr[g + 1]) bad |= 4;
-    // the tables themselves: they must cover exactly [0, E) and [0, N) (an edge list edited after collation with
-    // stale per-graph counts would otherwise be placed outside its rows' slots); monotone segments follow from
-    // the per-edge range checks above, because every edge is tested against the segment the walk assigns it
-    if (e < edge_ptr[g] || e >= edge_ptr[g + 1]) bad |= 4;
-    if (e == 0 && (edge_ptr[0] != 0 || edge_ptr[n_graphs] != E || node_ptr[0] != 0 || node_ptr[n_graphs] != N)) bad |= 4;
-    if (e > edge_ptr[g] && ei[e - 1] > r) {          // a descent inside the graph: the second run starts here
-        const int old = atomicMin(&split[g], e);
-        if (old != edge_ptr[g + 1]) bad |= 4;          // more than one descent: not two sorted runs
+                               int32_t* __restrict__ split, int32_t* __restrict__ status) {
+    const int e0 = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+    int g = graph_of_edge(edge_ptr, n_graphs, min(e0, E - 1), E, 2);
+    if (e0 >= E) return;
+    const int n_here = e0 + 1 < E ? 2 : 1;
+    int64_t rr[2], cc[2];
+    if (VEC) {
+        const longlong2 r2 = *reinterpret_cast<const longlong2*>(ei + e0);
+        const longlong2 c2 = *reinterpret_cast<const longlong2*>(ei + (size_t)E + e0);
+        rr[0] = r2.x; rr[1] = r2.y; cc[0] = c2.x; cc[1] = c2.y;
+    } else {
+        rr[0] = ei[e0]; cc[0] = ei[(size_t)E + e0];
+        rr[1] = n_here > 1 ? ei[e0 + 1] : 0; cc[1] = n_here > 1 ? ei[(size_t)E + e0 + 1] : 0;
     }
-    row32[e] = (int32_t)r;
-    col32[e] = (int32_t)c;
-    iota[e] = e;
+    int64_t prev = e0 > 0 ? ei[e0 - 1] : 0;      // (the neighbouring thread's line: a cache hit)
+    int hot[2] = {-1, -1}, attr_bad[2] = {0, 0};
     if (A > 0) {
-        int hot = -1, ones = 0, other = 0;
-        for (int a = 0; a < A; ++a) {
-            int64_t v = ea[(size_t)e * A + a];
-            if (v == 1) { ones++; hot = a; }
-            else if (v != 0) other = 1;
+        int ones[2] = {0, 0};
+        if (VEC) {       // the pair's 2A words as A 16-byte loads: word w belongs to edge w / A, class w % A
+            const longlong2* src = reinterpret_cast<const longlong2*>(ea + (size_t)e0 * A);
+            for (int q = 0; q < A; ++q) {
+                const longlong2 v = src[q];
+                const int w0 = 2 * q, w1 = 2 * q + 1;
+                const int ed0 = w0 >= A, ed1 = w1 >= A;
+                if (v.x == 1) { ones[ed0]++; hot[ed0] = w0 - ed0 * A; } else if (v.x != 0) attr_bad[ed0] = 1;
+                if (v.y == 1) { ones[ed1]++; hot[ed1] = w1 - ed1 * A; } else if (v.y != 0) attr_bad[ed1] = 1;
+            }
+        } else {
+            for (int i = 0; i < n_here; ++i)
+                for (int a = 0; a < A; ++a) {
+                    const int64_t v = ea[(size_t)(e0 + i) * A + a];
+                    if (v == 1) { ones[i]++; hot[i] = a; } else if (v != 0) attr_bad[i] = 1;
+                }
         }
-        if (ones != 1 || other) { bad |= 2; if (hot < 0) hot = 0; }
-        etype_in[e] = (uint8_t)hot;
+        for (int i = 0; i < 2; ++i) if (ones[i] != 1) attr_bad[i] = 1;
+    }
+    int bad = 0;
+    int32_t r32[2] = {0, 0}, c32[2] = {0, 0};
+    uint8_t ty[2] = {0, 0};
+    for (int i = 0; i < n_here; ++i) {
+        const int e = e0 + i;
+        while (g + 1 < n_graphs && edge_ptr[g + 1] <= e) ++g;
+        int64_t r = rr[i], c = cc[i];
+        if (r < 0 || r >= N || c < 0 || c >= N) { bad |= 1; r = 0; c = 0; }
+        if (r < node_ptr[g] || r >= node_ptr[g + 1] || c < node_ptr[g] || c >= node_ptr[g + 1]) bad |= 4;
+        // the tables themselves: they must cover exactly [0, E) and [0, N) (an edge list edited after collation with
+        // stale per-graph counts would otherwise be placed outside its rows' slots); monotone segments follow from
+        // the per-edge range checks above, because every edge is tested against the segment the walk assigns it
+        if (e < edge_ptr[g] || e >= edge_ptr[g + 1]) bad |= 4;
+        if (e == 0 && (edge_ptr[0] != 0 || edge_ptr[n_graphs] != E || node_ptr[0] != 0 || node_ptr[n_graphs] != N)) bad |= 4;
+        if (e > edge_ptr[g] && prev > rr[i]) {         // a descent inside the graph: the second run starts here
+            const int old = atomicMin(&split[g], e);
+            if (old != edge_ptr[g + 1]) bad |= 4;          // more than one descent: not two sorted runs
+        }
+        prev = rr[i];
+        r32[i] = (int32_t)r; c32[i] = (int32_t)c;
+        if (A > 0) {
+            if (attr_bad[i]) { bad |= 2; if (hot[i] < 0) hot[i] = 0; }
+            ty[i] = (uint8_t)hot[i];
+        }
+    }
+    if (n_here == 2) {
+        *reinterpret_cast<int2*>(row32 + e0) = make_int2(r32[0], r32[1]);
+        *reinterpret_cast<int2*>(col32 + e0) = make_int2(c32[0], c32[1]);
+        if (A > 0) *reinterpret_cast<uchar2*>(etype_in + e0) = make_uchar2(ty[0], ty[1]);
+    } else {
+        row32[e0] = r32[0]; col32[e0] = c32[0];
+        if (A > 0) etype_in[e0] = ty[0];
     }
     if (bad) atomicOr(status, bad);
+}
+
+__global__ void k_iota(int E, int32_t* iota) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < E) iota[p] = p;
 }
 
 __global__ void k_init_split(int n_graphs, const int32_t* __restrict__ edge_ptr, int32_t* __restrict__ split) {
@@ -548,8 +597,16 @@ extern "C" int pvs_graph_prepare_runs(const int64_t* edge_index, const int64_t* 
     k_init_split<<<(n_graphs + T - 1) / T, T, 0, stream>>>(n_graphs, edge_ptr, w.split);
     PVS_CHECK_LAUNCH();
     if (E > 0) {
-        k_extract_runs<<<(E + T - 1) / T, T, 0, stream>>>(edge_index, edge_attr, n_edge_attr, N, E, n_graphs, node_ptr,
-                                                          edge_ptr, w.row32, w.col32, w.etype_in, w.iota, w.split, status);
+        const bool vec = (E & 1) == 0 && (((uintptr_t)edge_index | (uintptr_t)edge_attr) & 15) == 0;
+        const int pairs = (E + 1) / 2;
+        if (vec)
+            k_extract_runs<true><<<(pairs + T - 1) / T, T, 0, stream>>>(edge_index, edge_attr, n_edge_attr, N, E, n_graphs,
+                                                                        node_ptr, edge_ptr, w.row32, w.col32, w.etype_in,
+                                                                        w.split, status);
+        else
+            k_extract_runs<false><<<(pairs + T - 1) / T, T, 0, stream>>>(edge_index, edge_attr, n_edge_attr, N, E, n_graphs,
+                                                                         node_ptr, edge_ptr, w.row32, w.col32, w.etype_in,
+                                                                         w.split, status);
         PVS_CHECK_LAUNCH();
     }
     k_run_starts<<<(N + T - 1) / T, T, 0, stream>>>(w.row32, N, E, n_graphs, status, node_ptr, edge_ptr, w.split, w.start_a,
@@ -597,6 +654,8 @@ extern "C" int pvs_graph_prepare_runs(const int64_t* edge_index, const int64_t* 
     if (E > 0) {
         size_t tb = w.sort_bytes;
         const int bits = key_bits(N > 1 ? N : 2);
+        k_iota<<<(E + 255) / 256, 256, 0, stream>>>(E, w.iota);
+        PVS_CHECK_LAUNCH();
         PVS_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(w.sort_tmp, tb, col, w.keys_tmp, w.iota, cedge, E, 0,
                                                          bits, stream));
     }
@@ -608,10 +667,6 @@ extern "C" int pvs_graph_prepare_runs(const int64_t* edge_index, const int64_t* 
 // CSC of an existing CSR (shared with the radius-graph builder): cedge = CSR positions grouped by
 // column, stable; colptr = offsets.
 namespace {
-__global__ void k_iota(int E, int32_t* iota) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < E) iota[p] = p;
-}
 }  // namespace
 
 size_t pvs_build_csc_workspace_bytes(int N, int E) {
