@@ -292,16 +292,20 @@ __global__ void k_run_starts(const int32_t* __restrict__ row32, int N, int E, in
         if (node_ptr[mid] <= n) lo = mid; else hi = mid;
     }
     const int g = lo;
-    auto lb = [&](int first, int last, int key) {     // first position in [first, last) with row >= key
-        while (first < last) {
-            const int mid = (first + last) >> 1;
-            if (row32[mid] < key) first = mid + 1; else last = mid;
-        }
-        return first;
-    };
+    // first position in a run with row >= n and with row >= n + 1, for both runs: FOUR binary searches advanced in
+    // lockstep (their loads are independent, so the node pays the latency of one descent, not of four in a row)
     const int a0 = edge_ptr[g], a1 = split[g], b1 = edge_ptr[g + 1];
-    const int sa = lb(a0, a1, n), sa_next = lb(sa, a1, n + 1);
-    const int sb = lb(a1, b1, n), sb_next = lb(sb, b1, n + 1);
+    int f0 = a0, l0 = a1, f1 = a0, l1 = a1, f2 = a1, l2 = b1, f3 = a1, l3 = b1;
+    while (f0 < l0 || f1 < l1 || f2 < l2 || f3 < l3) {
+        const int m0 = (f0 + l0) >> 1, m1 = (f1 + l1) >> 1, m2 = (f2 + l2) >> 1, m3 = (f3 + l3) >> 1;
+        const int v0 = f0 < l0 ? row32[m0] : 0, v1 = f1 < l1 ? row32[m1] : 0;
+        const int v2 = f2 < l2 ? row32[m2] : 0, v3 = f3 < l3 ? row32[m3] : 0;
+        if (f0 < l0) { if (v0 < n) f0 = m0 + 1; else l0 = m0; }
+        if (f1 < l1) { if (v1 < n + 1) f1 = m1 + 1; else l1 = m1; }
+        if (f2 < l2) { if (v2 < n) f2 = m2 + 1; else l2 = m2; }
+        if (f3 < l3) { if (v3 < n + 1) f3 = m3 + 1; else l3 = m3; }
+    }
+    const int sa = f0, sa_next = f1, sb = f2, sb_next = f3;
     start_a[n] = sa;
     start_b[n] = sb;
     cnt_a[n] = sa_next - sa;
