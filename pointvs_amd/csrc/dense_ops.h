@@ -32,6 +32,23 @@ enum { PVS_EPI_NONE = 0, PVS_EPI_SILU_OUT = 1, PVS_EPI_ADD_OUT = 2, PVS_EPI_MUL_
 bool pvs_linear_epilogue_supported(int ldy, int ldx, int ldx2, int K, int K2, int C, const void* y,
                                    const void* x, const void* x2);
 
+// The node MLP of a layer as one launch each way (H = 32, 64; layers without GraphNorm and without rezero / gated
+// residual; node attention (natt_w != NULL) and the plain residual are part of the chain):
+//   forward   y1 = [h | Magg] W1^T + b1, u = SiLU(y1), o = u W2^T + b2, a = act(natt_w . o + natt_b) (or 1),
+//             h_out = (residual ? h : 0) + a o;  natt_out[n] = a
+//   backward  g_o = g_hout a + g_l natt_w with g_l = act'(l) (g_hout . o)  [written with t1 = g_l o, gl = g_l when
+//             gated; = g_hout otherwise, nothing written], g_y1 = (g_o W2) * SiLU'(y1),
+//             g_h = (residual ? g_hout : 0) + g_y1 W1[:, :H], gM = g_y1 W1[:, H:]  (+ the row side jobs of `ext`)
+bool pvs_node_mlp_fused_supported(int H, const void* a, const void* b, const void* c, const void* d);
+int pvs_launch_node_mlp_fwd(hipStream_t s, int H, int N, const float* h, const float* Magg, const float* W1,
+                            const float* b1, const float* W2, const float* b2, bool residual, const float* natt_w,
+                            const float* natt_b, int att_act, float* y1, float* u, float* o, float* h_out,
+                            float* natt_out);
+int pvs_launch_node_mlp_bwd(hipStream_t s, int H, int N, const float* g_hout, const float* o, const float* y1,
+                            const float* W1, const float* W2, bool residual, const float* natt_w, const float* natt_b,
+                            int att_act, float* g_o, float* t1, float* gl, float* g_y1, float* g_h, float* gM,
+                            const PvsLinearExt* ext);
+
 // number of float slabs a column reduction / tsgemm over N rows needs: slabs * width floats
 int pvs_reduce_blocks(int N);
 int pvs_colreduce_blocks(int N);   // slabs of pvs_launch_colreduce: [pvs_colreduce_blocks(N)][C] (<= 4 x pvs_reduce_blocks)

@@ -249,6 +249,225 @@ k_reduce_slabs2(float* __restrict__ out_a, const float* __restrict__ slabs_a, in
     }
 }
 
+// ---- the node MLP of a layer as ONE launch each way (H = 32, 64; no GraphNorm, node gate or gated residual) ---------
+// Every node-level product is row-local, and a product's accumulator is already the B operand of the next one (X
+// layout), so the chain  y1 = [h | M] Wn1^T + b1 -> u = SiLU(y1) -> o = u Wn2^T + b2 -> h_out = (h +) o  runs per
+// 32-row tile without leaving the registers; y1, u, o are written for the backward as before. What these kernels save is
+// launches: a node-level launch at N = 64000 rows costs ~5 us before it moves a byte (profiles/r03_ab_small_launch_folding.txt).
+template <int HB>
+__global__ void __launch_bounds__(kThreads)
+k_node_mlp_fwd(const float* __restrict__ h, const float* __restrict__ Magg, const float* __restrict__ W1,
+               const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2, int N,
+               int residual, const float* __restrict__ natt_w, const float* __restrict__ natt_b, int att_act,
+               float* __restrict__ y1, float* __restrict__ u, float* __restrict__ o,
+               float* __restrict__ h_out, float* __restrict__ natt_out) {
+    constexpr int H = 32 * HB, LD1 = 2 * H + 1, LD2 = H + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* W1s = smem;                    // [H][2H + 1]
+    float* W2s = W1s + H * LD1;           // [H][H + 1]
+    float* bs = W2s + H * LD2;            // b1 | b2 | node attention weight
+    for (int i = threadIdx.x; i < H * 2 * H; i += kThreads) W1s[(i / (2 * H)) * LD1 + i % (2 * H)] = W1[i];
+    for (int i = threadIdx.x; i < H * H; i += kThreads) W2s[(i / H) * LD2 + i % H] = W2[i];
+    for (int i = threadIdx.x; i < 3 * H; i += kThreads)
+        bs[i] = i < H ? b1[i] : (i < 2 * H ? b2[i - H] : (natt_w ? natt_w[i - 2 * H] : 0.f));
+    __syncthreads();
+    const float bna = natt_w ? natt_b[0] : 0.f;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int n_tiles = (N + 31) / 32;
+    for (int tile = blockIdx.x * (kThreads / 64) + wv; tile < n_tiles; tile += gridDim.x * (kThreads / 64)) {
+        const int n = tile * 32 + j;
+        const bool valid = n < N;
+        const size_t row = (size_t)(valid ? n : N - 1) * H;
+        float v[2 * HB][16];
+#pragma unroll
+        for (int bb = 0; bb < 2 * HB; ++bb) {
+            const float* src = (bb < HB ? h + row + 32 * bb : Magg + row + 32 * (bb - HB));
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 q = *reinterpret_cast<const float4*>(src + 8 * g + 4 * hh);
+                v[bb][4 * g] = q.x; v[bb][4 * g + 1] = q.y; v[bb][4 * g + 2] = q.z; v[bb][4 * g + 3] = q.w;
+            }
+        }
+        f32x16 acc[HB];
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[cb][t] = bs[32 * cb + xch(t, hh)];
+        mfma_chain_rect<HB, 2 * HB, false>(W1s, lane, v, acc);
+        float uv[HB][16];
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int off = 32 * cb + 8 * g + 4 * hh;
+                const float4 yq = make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
+                const float4 uq = make_float4(pvs_silu(yq.x), pvs_silu(yq.y), pvs_silu(yq.z), pvs_silu(yq.w));
+                uv[cb][4 * g] = uq.x; uv[cb][4 * g + 1] = uq.y; uv[cb][4 * g + 2] = uq.z; uv[cb][4 * g + 3] = uq.w;
+                if (valid) {
+                    *reinterpret_cast<float4*>(y1 + row + off) = yq;
+                    *reinterpret_cast<float4*>(u + row + off) = uq;
+                }
+            }
+        f32x16 acc2[HB];
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc2[cb][t] = bs[H + 32 * cb + xch(t, hh)];
+        mfma_chain_rect<HB, HB, false>(W2s, lane, uv, acc2);
+        float a = 1.f;
+        if (natt_w) {        // node gate: o * act(w . o + b); the row's channels sit in this lane and in lane ^ 32
+            float part = 0.f;
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) part = fmaf(bs[2 * H + 32 * cb + xch(t, hh)], acc2[cb][t], part);
+            part += __shfl_xor(part, 32, 64);
+            a = pvs_att_act(att_act, part + bna);
+            if (valid && hh == 0 && natt_out) natt_out[n] = a;
+        }
+        if (valid) {
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int off = 32 * cb + 8 * g + 4 * hh;
+                    float4 r = make_float4(acc2[cb][4 * g], acc2[cb][4 * g + 1], acc2[cb][4 * g + 2], acc2[cb][4 * g + 3]);
+                    *reinterpret_cast<float4*>(o + row + off) = r;
+                    r.x *= a; r.y *= a; r.z *= a; r.w *= a;
+                    if (residual) { r.x += v[cb][4 * g]; r.y += v[cb][4 * g + 1]; r.z += v[cb][4 * g + 2]; r.w += v[cb][4 * g + 3]; }
+                    *reinterpret_cast<float4*>(h_out + row + off) = r;
+                }
+        }
+    }
+}
+
+// backward of the chain: g_y1 = (g_o Wn2) * SiLU'(y1) -> g_h (+)= g_y1 Wn1[:, :H], gM = g_y1 Wn1[:, H:], with the
+// per-row preparation of the edge backward as side jobs (PvsLinearExt: zero_rows / zero3 / scale3)
+template <int HB>
+__global__ void __launch_bounds__(kThreads)
+k_node_mlp_bwd(const float* __restrict__ g_hout, const float* __restrict__ o, const float* __restrict__ y1,
+               const float* __restrict__ W1, const float* __restrict__ W2, int N, int residual,
+               const float* __restrict__ natt_w, const float* __restrict__ natt_b, int att_act,
+               float* __restrict__ g_o, float* __restrict__ t1, float* __restrict__ gl, float* __restrict__ g_y1,
+               float* __restrict__ g_h, float* __restrict__ gM, PvsLinearExt ext) {
+    // In front of the chain, the output stage's backward (node_ops.hip: k_node_out_bwd for plain / residual / node-gated
+    // layers): with a node gate a = act(l), l = w . o + b:  g_o = g_hout a + g_l w,  g_l = act'(l) (g_hout . o), and
+    // t1 = g_l o, gl = g_l for the gate's weight gradients; the residual's share of g_h is g_hout itself.
+    constexpr int H = 32 * HB, LD = H + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* W2t = smem;                    // [H][H + 1]:   W2t[j][c] = Wn2[c][j]
+    float* W1t = W2t + H * LD;            // [2H][H + 1]:  W1t[j][c] = Wn1[c][j]
+    float* wna = W1t + 2 * H * LD;        // [H] node attention weight
+    for (int i = threadIdx.x; i < H * H; i += kThreads) { const int c = i / H, jj = i % H; W2t[jj * LD + c] = W2[i]; }
+    for (int i = threadIdx.x; i < H * 2 * H; i += kThreads) { const int c = i / (2 * H), jj = i % (2 * H); W1t[jj * LD + c] = W1[i]; }
+    for (int i = threadIdx.x; i < H; i += kThreads) wna[i] = natt_w ? natt_w[i] : 0.f;
+    __syncthreads();
+    const float bna = natt_w ? natt_b[0] : 0.f;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const bool side = ext.zero_rows || ext.zero3 || ext.scale3_dst;
+    const int n_tiles = (N + 31) / 32;
+    for (int tile = blockIdx.x * (kThreads / 64) + wv; tile < n_tiles; tile += gridDim.x * (kThreads / 64)) {
+        const int n = tile * 32 + j;
+        const bool valid = n < N;
+        const size_t row = (size_t)(valid ? n : N - 1) * H;
+        if (side && valid) {
+            if (ext.zero_rows) {
+                float* zr = ext.zero_rows + (size_t)n * ext.zero_ld;
+                for (int q = 4 * hh; q < ext.zero_w; q += 8) *reinterpret_cast<float4*>(zr + q) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (hh == 0) {
+                if (ext.zero3) { ext.zero3[3 * n] = 0.f; ext.zero3[3 * n + 1] = 0.f; ext.zero3[3 * n + 2] = 0.f; }
+                if (ext.scale3_dst) {
+                    const float by = ext.scale3_by[n];
+                    ext.scale3_dst[3 * n] = ext.scale3_src[3 * n] * by; ext.scale3_dst[3 * n + 1] = ext.scale3_src[3 * n + 1] * by;
+                    ext.scale3_dst[3 * n + 2] = ext.scale3_src[3 * n + 2] * by;
+                }
+            }
+        }
+        float v[HB][16], gres[HB][16];
+        load_x<HB>(g_hout + row, hh, v);
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) gres[cb][t] = residual ? v[cb][t] : 0.f;
+        if (natt_w) {
+            float ov[HB][16];
+            load_x<HB>(o + row, hh, ov);
+            float lp = 0.f, dp = 0.f;
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    lp = fmaf(wna[32 * cb + xch(t, hh)], ov[cb][t], lp);
+                    dp = fmaf(v[cb][t], ov[cb][t], dp);
+                }
+            lp += __shfl_xor(lp, 32, 64);
+            dp += __shfl_xor(dp, 32, 64);
+            const float l = lp + bna;
+            const float a = pvs_att_act(att_act, l);
+            const float g_l = pvs_att_act_grad(att_act, l, a) * dp;
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int off = 32 * cb + 8 * g + 4 * hh;
+                    float4 gq, tq;
+                    float* gp = &gq.x; float* tp = &tq.x;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int t = 4 * g + i;
+                        const float gv = fmaf(g_l, wna[off + i], v[cb][t] * a);
+                        tp[i] = g_l * ov[cb][t];
+                        v[cb][t] = gv;
+                        gp[i] = gv;
+                    }
+                    if (valid) {
+                        *reinterpret_cast<float4*>(g_o + row + off) = gq;
+                        *reinterpret_cast<float4*>(t1 + row + off) = tq;
+                    }
+                }
+            if (valid && hh == 0) gl[n] = g_l;
+        }
+        f32x16 acc[HB];
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[cb][t] = 0.f;
+        mfma_chain_rect<HB, HB, false>(W2t, lane, v, acc);
+        float gy[HB][16];
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int off = 32 * cb + 8 * g + 4 * hh;
+                const float4 z = *reinterpret_cast<const float4*>(y1 + row + off);
+                float4 r = make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
+                r.x *= pvs_silu_grad(z.x, pvs_sigmoid(z.x)); r.y *= pvs_silu_grad(z.y, pvs_sigmoid(z.y));
+                r.z *= pvs_silu_grad(z.z, pvs_sigmoid(z.z)); r.w *= pvs_silu_grad(z.w, pvs_sigmoid(z.w));
+                gy[cb][4 * g] = r.x; gy[cb][4 * g + 1] = r.y; gy[cb][4 * g + 2] = r.z; gy[cb][4 * g + 3] = r.w;
+                if (valid) *reinterpret_cast<float4*>(g_y1 + row + off) = r;
+            }
+        f32x16 acc2[2 * HB];
+#pragma unroll
+        for (int cb = 0; cb < 2 * HB; ++cb)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc2[cb][t] = cb < HB ? gres[cb < HB ? cb : 0][t] : 0.f;
+        mfma_chain_rect<2 * HB, HB, false>(W1t, lane, gy, acc2);
+        if (valid) {
+#pragma unroll
+            for (int cb = 0; cb < 2 * HB; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float* dst = (cb < HB ? g_h + row + 32 * cb : gM + row + 32 * (cb - HB)) + 8 * g + 4 * hh;
+                    *reinterpret_cast<float4*>(dst) =
+                        make_float4(acc2[cb][4 * g], acc2[cb][4 * g + 1], acc2[cb][4 * g + 2], acc2[cb][4 * g + 3]);
+                }
+        }
+    }
+}
+
 constexpr int kPoolThreads = 1024;
 // One workgroup per graph (and per chunk of 1024 channels); thread = (row slot, channel), 4 independent partial sums
 // per thread so that 4 * (1024 / width) rows are in flight; fixed summation order.
@@ -789,6 +1008,62 @@ int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx,
     int blocks = grid_for(N, NB * 4);
     k_linear<<<blocks, kThreads, lds, s>>>(y, ldy, x, ldx, W, swc, swk, b, x2, ldx2, W2, swc2, swk2,
                                            N, K, K2, C, accumulate ? 1 : 0, NB);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+bool pvs_node_mlp_fused_supported(int H, const void* a, const void* b, const void* c, const void* d) {
+    return (H == 32 || H == 64) && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0;
+}
+
+static int node_mlp_blocks(int N) {
+    const int rows_m = N >= 32768 ? 256 : 128;
+    int blocks = (N + rows_m - 1) / rows_m;
+    return blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
+}
+
+int pvs_launch_node_mlp_fwd(hipStream_t s, int H, int N, const float* h, const float* Magg, const float* W1,
+                            const float* b1, const float* W2, const float* b2, bool residual, const float* natt_w,
+                            const float* natt_b, int att_act, float* y1, float* u, float* o, float* h_out,
+                            float* natt_out) {
+    PVS_REQUIRE(pvs_node_mlp_fused_supported(H, h, Magg, y1, h_out) && (((uintptr_t)u | (uintptr_t)o) & 15) == 0,
+                "node_mlp_fwd: H = %d or the alignment is unsupported", H);
+    PVS_REQUIRE(!natt_w || natt_b, "node_mlp_fwd: node attention bias missing");
+    if (N <= 0) return 0;
+    const size_t lds = (size_t)(H * (2 * H + 1) + H * (H + 1) + 3 * H) * sizeof(float);
+    if (H == 32) {
+        k_node_mlp_fwd<1><<<node_mlp_blocks(N), kThreads, lds, s>>>(h, Magg, W1, b1, W2, b2, N, residual ? 1 : 0, natt_w,
+                                                                    natt_b, att_act, y1, u, o, h_out, natt_out);
+    } else {
+        PVS_CHECK_HIP(hipFuncSetAttribute((const void*)k_node_mlp_fwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_node_mlp_fwd<2><<<node_mlp_blocks(N), kThreads, lds, s>>>(h, Magg, W1, b1, W2, b2, N, residual ? 1 : 0, natt_w,
+                                                                    natt_b, att_act, y1, u, o, h_out, natt_out);
+    }
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+int pvs_launch_node_mlp_bwd(hipStream_t s, int H, int N, const float* g_hout, const float* o, const float* y1,
+                            const float* W1, const float* W2, bool residual, const float* natt_w, const float* natt_b,
+                            int att_act, float* g_o, float* t1, float* gl, float* g_y1, float* g_h, float* gM,
+                            const PvsLinearExt* ext) {
+    PVS_REQUIRE(pvs_node_mlp_fused_supported(H, g_hout, y1, g_y1, g_h) && ((uintptr_t)gM & 15) == 0,
+                "node_mlp_bwd: H = %d or the alignment is unsupported", H);
+    PVS_REQUIRE(!natt_w || (natt_b && o && g_o && t1 && gl && (((uintptr_t)o | (uintptr_t)g_o | (uintptr_t)t1) & 15) == 0),
+                "node_mlp_bwd: node attention needs o, g_o, t1, gl");
+    PVS_REQUIRE(!ext || (ext->zero_w % 8 == 0 && (ext->zero_ld & 3) == 0 && ((uintptr_t)ext->zero_rows & 15) == 0),
+                "node_mlp_bwd: bad side job");
+    if (N <= 0) return 0;
+    const PvsLinearExt e = ext ? *ext : PvsLinearExt{};
+    const size_t lds = (size_t)(3 * H * (H + 1) + H) * sizeof(float);
+    if (H == 32) {
+        k_node_mlp_bwd<1><<<node_mlp_blocks(N), kThreads, lds, s>>>(g_hout, o, y1, W1, W2, N, residual ? 1 : 0, natt_w, natt_b,
+                                                                    att_act, g_o, t1, gl, g_y1, g_h, gM, e);
+    } else {
+        PVS_CHECK_HIP(hipFuncSetAttribute((const void*)k_node_mlp_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_node_mlp_bwd<2><<<node_mlp_blocks(N), kThreads, lds, s>>>(g_hout, o, y1, W1, W2, N, residual ? 1 : 0, natt_w, natt_b,
+                                                                    att_act, g_o, t1, gl, g_y1, g_h, gM, e);
+    }
     PVS_CHECK_LAUNCH();
     return 0;
 }

@@ -211,6 +211,16 @@ int node_mlp_forward(hipStream_t s, const Dims& m, const PvsLayerDesc* d, const 
     const bool fuse_silu = can_epi && !(F & PVS_GRAPHNORM);
     const bool gated = (F & PVS_RESIDUAL) && (F & (PVS_REZERO | PVS_GATED_RESIDUAL));
     const bool fuse_out = can_epi && !(F & PVS_NODE_ATTENTION) && !gated;
+    static const bool split_small = getenv("PVS_EGNN_SPLIT_SMALL") != nullptr;     // (the launches apart, for A/B)
+    if (fuse_silu && !gated && !split_small && p->node_b1 && p->node_b2 &&
+        pvs_node_mlp_fused_supported(H, h, Magg, y1, h_out)) {
+        // no GraphNorm, no rezero / gated residual: the whole chain y1 -> u -> o -> (node gate) -> h_out in one launch
+        // (dense_ops.hip: k_node_mlp_fwd)
+        const bool natt = F & PVS_NODE_ATTENTION;
+        return pvs_launch_node_mlp_fwd(s, H, m.N, h, Magg, p->node_w1, p->node_b1, p->node_w2, p->node_b2,
+                                       (F & PVS_RESIDUAL) != 0, natt ? nw.natt_w : nullptr, natt ? nw.natt_b : nullptr,
+                                       d->att_act, y1, u, o, h_out, node_att_out);
+    }
     PVS_TRY(pvs_launch_linear(s, y1, H, h, H, p->node_w1, 2 * H, 1, p->node_b1, Magg, H,
                               p->node_w1 + H, 2 * H, 1, m.N, H, H, H, false,
                               fuse_silu ? PVS_EPI_SILU_OUT : PVS_EPI_NONE, nullptr, 0, u, H));
@@ -476,13 +486,26 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     const float* su = so + (size_t)N * H;      // u = SiLU(GN(y1)) kept by the forward
 
     // ---- node_model backward ----
-    // (no residual, no node gate: g_o = g_h_out and the residual's part of g_h is zero - nothing to launch)
     static const bool split_small = getenv("PVS_EGNN_SPLIT_SMALL") != nullptr;     // (the launches apart, for A/B)
+    const bool mfma_bwd = pvs_use_mfma() && pvs_edge_bwd_mfma_supported(H, F, m.A);
+    // Layers without GraphNorm and without rezero / gated residual: the output stage (node gate, residual), g_y1 and
+    // [g_h | gM] as ONE launch that also carries the per-node preparation of the edge backward (dense_ops.hip:
+    // k_node_mlp_bwd). Without a node gate g_o is g_h_out itself and nothing is written for it.
+    const bool chain_bwd = !gn && !gates && !split_small && pvs_node_mlp_fused_supported(H, g_h_out, sy1, w.g_u, g_h) &&
+                           (((uintptr_t)w.gM | (uintptr_t)w.gPQ | (uintptr_t)so | (uintptr_t)w.g_o | (uintptr_t)w.t1) & 15) == 0;
+    // (no residual, no node gate: g_o = g_h_out and the residual's part of g_h is zero - nothing to launch either way)
     const bool plain_out = !(F & PVS_RESIDUAL) && !natt && !split_small;
-    const float* g_o = plain_out ? g_h_out : w.g_o;
-    if (!plain_out)
+    const float* g_o = (plain_out || (chain_bwd && !natt)) ? g_h_out : w.g_o;
+    if (!plain_out && !chain_bwd)
         PVS_TRY(pvs_node_out_bwd(s, H, g_h_out, so, h, nw, F, d->att_act, N, w.g_o, g_h, w.gl, w.t1,
                                  w.tg));
+    PvsLinearExt prep;
+    if (mfma_bwd) { prep.zero_rows = w.gPQ; prep.zero_w = H; prep.zero_ld = 2 * H; prep.zero3 = w.gx_row; }
+    if (coord_bwd) { prep.scale3_src = g_x_out; prep.scale3_by = g->inv_deg; prep.scale3_dst = w.gxagg; }
+    if (chain_bwd)
+        PVS_TRY(pvs_launch_node_mlp_bwd(s, H, N, g_h_out, so, sy1, p->node_w1, p->node_w2, (F & PVS_RESIDUAL) != 0,
+                                        natt ? nw.natt_w : nullptr, natt ? nw.natt_b : nullptr, d->att_act, w.g_o, w.t1,
+                                        w.gl, w.g_u, g_h, w.gM, &prep));
     if (natt) {
         if (gr.node_att_w)
             PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.node_att_w, w.t1, H, nullptr, 0, nullptr,
@@ -500,16 +523,17 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     // (without GraphNorm g_y1 = g_u * SiLU'(y1) rides on this product's epilogue)
     const bool fuse_tail_bwd = !gn && pvs_linear_epilogue_supported(H, H, 0, H, 0, H, w.g_u, g_o, nullptr) &&
                                ((uintptr_t)sy1 & 15) == 0;
-    PVS_TRY(pvs_launch_linear(s, w.g_u, H, g_o, H, p->node_w2, 1, H, nullptr, nullptr, 0, nullptr, 0,
-                              0, N, H, 0, H, false, fuse_tail_bwd ? PVS_EPI_MUL_SILU_GRAD : PVS_EPI_NONE, sy1, H,
-                              nullptr, 0));
+    if (!chain_bwd)
+        PVS_TRY(pvs_launch_linear(s, w.g_u, H, g_o, H, p->node_w2, 1, H, nullptr, nullptr, 0, nullptr, 0,
+                                  0, N, H, 0, H, false, fuse_tail_bwd ? PVS_EPI_MUL_SILU_GRAD : PVS_EPI_NONE, sy1, H,
+                                  nullptr, 0));
     if (gr.node_w2 && !fused_wgrads)
         PVS_TRY(pvs_launch_tsgemm_tn(s, gr.node_w2, H, g_o, H, su, H, N, H, H, w.dslabs, false));
     if (gr.node_b2 && !fused_wgrads)
         PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.node_b2, g_o, H, nullptr, 0, nullptr, N, H,
                                      1.f, w.dslabs, false));
     // u = SiLU(GN(y1)) ; g_u becomes g_yn then g_y1 in place
-    if (!fuse_tail_bwd) PVS_TRY(pvs_node_tail_bwd1(s, w.g_u, sy1, stats, nw, N, H, w.g_u));
+    if (!fuse_tail_bwd && !chain_bwd) PVS_TRY(pvs_node_tail_bwd1(s, w.g_u, sy1, stats, nw, N, H, w.g_u));
     if (gn) {
         PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, w.S1, w.g_u, H, nullptr, 0, nullptr, N, H, 1.f,
                                      w.dslabs, false));
@@ -524,14 +548,12 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     // The per-node preparation of the edge backward (clear the row part of gPQ and gx_row - rows without edges are
     // never written by the MFMA edge backward -, g_x_out / deg) rides on these products as side jobs of the node rows
     // where the MFMA linear takes the shape; the softmax row dots need the finished gM and keep their own launch.
-    const bool mfma_bwd = pvs_use_mfma() && pvs_edge_bwd_mfma_supported(H, F, m.A);
-    PvsLinearExt prep;
-    if (mfma_bwd) { prep.zero_rows = w.gPQ; prep.zero_w = H; prep.zero_ld = 2 * H; prep.zero3 = w.gx_row; }
-    if (coord_bwd) { prep.scale3_src = g_x_out; prep.scale3_by = g->inv_deg; prep.scale3_dst = w.gxagg; }
     const bool prep_side = !split_small && ((uintptr_t)w.gPQ & 15) == 0 &&
                            pvs_linear_epilogue_supported(H, H, 0, H, 0, H, w.gM, g_y1, nullptr);
     bool prep_done = false;
-    if (H == 32 && prep_side && pvs_linear_epilogue_supported(H, H, 0, H, 0, 2 * H, g_h, g_y1, nullptr)) {
+    if (chain_bwd) {
+        prep_done = true;       // (launched above)
+    } else if (H == 32 && prep_side && pvs_linear_epilogue_supported(H, H, 0, H, 0, 2 * H, g_h, g_y1, nullptr)) {
         // g_h (+)= and gM = in one launch: 64 outputs over the two halves of node_mlp.0's weight, the second column
         // block to gM
         prep.y1 = w.gM; prep.ldy1 = H; prep.acc1 = 0;
