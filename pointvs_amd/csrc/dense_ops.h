@@ -79,16 +79,19 @@ int pvs_launch_reduce_slabs2(hipStream_t s, float* out_a, const float* slabs_a, 
 struct PvsNodeWgradIn {
     const float *g_o, *g_y1, *gPQ;   // [N,H], [N,H], [N,2H] (P part | Q part)
     const float *u, *h, *Magg;       // [N,H] each
+    const float *t1 = nullptr;       // [N,H] g_l * o of the node gate, or NULL
+    const float *gl = nullptr;       // [N]   g_l of the node gate, or NULL
 };
 struct PvsNodeWgradOut {
     float *node_w2, *node_w1, *edge_w1;     // required
     float *node_b2, *node_b1, *edge_b1;     // NULL to skip
     int ld1, off_q, perm;                   // edge_w1 row stride, column of the Q block, P/Q share columns
+    float *natt_w = nullptr, *natt_b = nullptr;   // node gate: column sums of t1 [H] and the sum of gl [1], or NULL
 };
 // reduced sums layout (per 32x32 sub-block (bo, bi) of the H x H products): 5 products x [32][32],
-// then 3 bias vectors x [32] (valid for bi == 0)
+// then 5 column-sum vectors x [32] (valid for bi == 0): three biases, the node gate's weight, its bias (element 0 of bo == 0)
 #define PVS_WG_PRODUCTS 5
-#define PVS_WG_BIAS 3
+#define PVS_WG_BIAS 5
 #define PVS_WG_SLAB (PVS_WG_PRODUCTS * 1024 + PVS_WG_BIAS * 32)
 // scatter of the reduced sums into the gradient tensors (device side, for fusing into another small kernel)
 __device__ __forceinline__ void pvs_node_wgrads_scatter(const float* __restrict__ gsum, const PvsNodeWgradOut& out,
@@ -121,5 +124,7 @@ __device__ __forceinline__ void pvs_node_wgrads_scatter(const float* __restrict_
         if (out.node_b2) out.node_b2[c] = b[0];
         if (out.node_b1) out.node_b1[c] = b[32];
         if (out.edge_b1) out.edge_b1[c] = b[64];
+        if (out.natt_w) out.natt_w[c] = b[96];
+        if (out.natt_b && c == 0) out.natt_b[0] = b[128];
     }
 }

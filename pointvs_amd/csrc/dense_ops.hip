@@ -838,10 +838,22 @@ k_node_wgrads(float* __restrict__ slabs, PvsNodeWgradIn in, int N) {
     for (int p = 0; p < kWgProducts; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-    float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f;
+    float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f, bs4 = 0.f;
+    const bool gate_sums = in.t1 != nullptr && bi == 0;      // node gate: column sums of t1, sum of gl
+    const float* T1 = in.t1 + 32 * bo + j;
     constexpr int UN = 4;
     for (int n0 = r0 + wv * 2 * UN; n0 < r1; n0 += kThreads / 64 * 2 * UN) {
         float a0[UN], a1[UN], a2[UN], a3[UN], b0[UN], b1[UN], b2[UN];
+        if (gate_sums) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int n = n0 + 2 * u + hh;
+                if (n < r1) {
+                    bs3 += T1[(size_t)n * H];
+                    if (bo == 0 && j == 0) bs4 += in.gl[n];
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int n = n0 + 2 * u + hh;
@@ -866,6 +878,7 @@ k_node_wgrads(float* __restrict__ slabs, PvsNodeWgradIn in, int N) {
         }
     }
     bs0 += __shfl_xor(bs0, 32, 64); bs1 += __shfl_xor(bs1, 32, 64); bs2 += __shfl_xor(bs2, 32, 64);
+    bs3 += __shfl_xor(bs3, 32, 64); bs4 += __shfl_xor(bs4, 32, 64);
     for (int i = threadIdx.x; i < kWgSlab; i += kThreads) red[i] = 0.f;
     __syncthreads();
     for (int turn = 0; turn < kThreads / 64; ++turn) {   // fixed wave order
@@ -881,6 +894,8 @@ k_node_wgrads(float* __restrict__ slabs, PvsNodeWgradIn in, int N) {
                 red[kWgProducts * 1024 + j] += bs0;
                 red[kWgProducts * 1024 + 32 + j] += bs1;
                 red[kWgProducts * 1024 + 64 + j] += bs2;
+                red[kWgProducts * 1024 + 96 + j] += bs3;
+                red[kWgProducts * 1024 + 128 + j] += bs4;
             }
         }
         __syncthreads();

@@ -506,7 +506,10 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
         PVS_TRY(pvs_launch_node_mlp_bwd(s, H, N, g_h_out, so, sy1, p->node_w1, p->node_w2, (F & PVS_RESIDUAL) != 0,
                                         natt ? nw.natt_w : nullptr, natt ? nw.natt_b : nullptr, d->att_act, w.g_o, w.t1,
                                         w.gl, w.g_u, g_h, w.gM, &prep));
-    if (natt) {
+    // (the node gate's weight gradients - column sums of t1, sum of gl - ride on the fused weight-gradient pass when
+    // it runs: two column reductions and their slab reductions less per layer)
+    const bool gate_in_wgrads = natt && fused_wgrads && !split_small && gr.node_att_w && gr.node_att_b;
+    if (natt && !gate_in_wgrads) {
         if (gr.node_att_w)
             PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.node_att_w, w.t1, H, nullptr, 0, nullptr,
                                          N, H, 1.f, w.dslabs, false));
@@ -627,6 +630,7 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
         wo.node_w2 = gr.node_w2; wo.node_w1 = gr.node_w1; wo.edge_w1 = gr.edge_w1;
         wo.node_b2 = gr.node_b2; wo.node_b1 = gr.node_b1; wo.edge_b1 = gr.edge_b1;
         wo.ld1 = m.ld1; wo.off_q = m.off_q; wo.perm = m.perm ? 1 : 0;
+        if (gate_in_wgrads) { wi.t1 = w.t1; wi.gl = w.gl; wo.natt_w = gr.node_att_w; wo.natt_b = gr.node_att_b; }
         PVS_TRY(pvs_launch_node_wgrads(s, H, N, wi, wo, w.wslabs, /*scatter=*/false, &node_gsum));
         node_out = wo;
     }
