@@ -38,13 +38,13 @@ BASE_KW = dict(dim_input=12, k=32, dim_output=1, num_layers=3, residual=False, e
 
 # one entry per kernel family / instantiation that a model can dispatch
 FAMILIES = {
-    'default': dict(),                                                     # k_edge_bwd_bf16<1,false,false>
-    'h32_att': dict(edge_attention=True, node_attention=True, residual=True),     # <1,false,true>
-    'h32_edgeres': dict(edge_residual=True, tanh=True),                    # <1,true,false>
+    'default': dict(),                                                     # k_edge_bwd_f16<0,false>
+    'h32_att': dict(edge_attention=True, node_attention=True, residual=True),     # <0,true>
+    'h32_edgeres': dict(edge_residual=True, tanh=True),                    # <1,false>
     'h32_edgeres_att': dict(edge_residual=True, edge_attention=True),
     'h32_softmax_gn': dict(edge_attention=True, softmax_attention=True, graphnorm=True, node_attention=True,
                            residual=True),
-    'h64': dict(k=64),                                                     # k_edge_bwd_h64<false,false>
+    'h64': dict(k=64),                                                     # k_edge_bwd_h64<0,false>
     'h64_att': dict(k=64, edge_attention=True, node_attention=True),       # cfg3's layers
     'h64_edgeres_att': dict(k=64, edge_residual=True, edge_attention=True, tanh=True),
     'generic_h16': dict(k=16, normalize=True),                             # edge_v0 kernels
