@@ -249,6 +249,32 @@ k_reduce_slabs2(float* __restrict__ out_a, const float* __restrict__ slabs_a, in
     }
 }
 
+// The folded per-row launches (PvsLinearExt side jobs) for the 32 rows of a tile, by one wave: every store instruction
+// covers whole rows' worth of consecutive bytes (a lane-per-row loop writes 16-byte pieces 128+ bytes apart and costs
+// more than the launch it replaces).
+__device__ __forceinline__ void pvs_tile_side_jobs(const PvsLinearExt& ext, int row0, int N, int lane) {
+    if (ext.zero_rows) {
+        const int zq = ext.zero_w >> 2;
+        for (int idx = lane; idx < 32 * zq; idx += 64) {
+            const int row = idx / zq, q = idx - row * zq;
+            if (row0 + row < N)
+                *reinterpret_cast<float4*>(ext.zero_rows + (size_t)(row0 + row) * ext.zero_ld + 4 * q) =
+                    make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (ext.zero3 || ext.copy3_dst || ext.scale3_dst) {
+        for (int idx = lane; idx < 96; idx += 64) {
+            const int n = row0 + idx / 3;
+            if (n < N) {
+                const size_t o = (size_t)3 * row0 + idx;
+                if (ext.zero3) ext.zero3[o] = 0.f;
+                if (ext.copy3_dst) ext.copy3_dst[o] = ext.copy3_src[o];
+                if (ext.scale3_dst) ext.scale3_dst[o] = ext.scale3_src[o] * ext.scale3_by[n];
+            }
+        }
+    }
+}
+
 // ---- the node MLP of a layer as ONE launch each way (H = 32, 64; no GraphNorm, node gate or gated residual) ---------
 // Every node-level product is row-local, and a product's accumulator is already the B operand of the next one (X
 // layout), so the chain  y1 = [h | M] Wn1^T + b1 -> u = SiLU(y1) -> o = u Wn2^T + b2 -> h_out = (h +) o  runs per
@@ -372,20 +398,7 @@ k_node_mlp_bwd(const float* __restrict__ g_hout, const float* __restrict__ o, co
         const int n = tile * 32 + j;
         const bool valid = n < N;
         const size_t row = (size_t)(valid ? n : N - 1) * H;
-        if (side && valid) {
-            if (ext.zero_rows) {
-                float* zr = ext.zero_rows + (size_t)n * ext.zero_ld;
-                for (int q = 4 * hh; q < ext.zero_w; q += 8) *reinterpret_cast<float4*>(zr + q) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (hh == 0) {
-                if (ext.zero3) { ext.zero3[3 * n] = 0.f; ext.zero3[3 * n + 1] = 0.f; ext.zero3[3 * n + 2] = 0.f; }
-                if (ext.scale3_dst) {
-                    const float by = ext.scale3_by[n];
-                    ext.scale3_dst[3 * n] = ext.scale3_src[3 * n] * by; ext.scale3_dst[3 * n + 1] = ext.scale3_src[3 * n + 1] * by;
-                    ext.scale3_dst[3 * n + 2] = ext.scale3_src[3 * n + 2] * by;
-                }
-            }
-        }
+        if (side) pvs_tile_side_jobs(ext, tile * 32, N, lane);
         float v[HB][16], gres[HB][16];
         load_x<HB>(g_hout + row, hh, v);
 #pragma unroll
@@ -565,17 +578,40 @@ k_pool_head_bwd(const float* __restrict__ gy, const float* __restrict__ pooled, 
         return;
     }
     if (!gh) return;
-    const long long total = (long long)N * width;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)node_blocks * 256) {
-        const int n = (int)(i / width), k = (int)(i % width);
+    auto graph_of = [&](int n) {
         int lo = 0, hi = B;  // largest g with gptr[g] <= n
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (gptr[mid] <= n) lo = mid; else hi = mid;
         }
-        const int cnt = gptr[lo + 1] - gptr[lo];
+        return lo;
+    };
+    if ((width & 3) == 0 && ((uintptr_t)gh & 15) == 0) {      // one thread per 16 bytes of a row: one search per quad
+        const int qpr = width >> 2;
+        const long long total = (long long)N * qpr;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)node_blocks * 256) {
+            const int n = (int)(i / qpr), k = 4 * (int)(i % qpr);
+            const int g = graph_of(n);
+            const int cnt = gptr[g + 1] - gptr[g];
+            float4 gp = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int c = 0; c < C; ++c) {
+                const float v = gy[(size_t)g * C + c];
+                const float* wr = W + (size_t)c * width + k;
+                gp.x = fmaf(v, wr[0], gp.x); gp.y = fmaf(v, wr[1], gp.y);
+                gp.z = fmaf(v, wr[2], gp.z); gp.w = fmaf(v, wr[3], gp.w);
+            }
+            const float d = (float)(cnt > 1 ? cnt : 1);
+            *reinterpret_cast<float4*>(gh + (size_t)n * width + k) = make_float4(gp.x / d, gp.y / d, gp.z / d, gp.w / d);
+        }
+        return;
+    }
+    const long long total = (long long)N * width;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)node_blocks * 256) {
+        const int n = (int)(i / width), k = (int)(i % width);
+        const int g = graph_of(n);
+        const int cnt = gptr[g + 1] - gptr[g];
         float gp = 0.f;
-        for (int c = 0; c < C; ++c) gp = fmaf(gy[(size_t)lo * C + c], W[(size_t)c * width + k], gp);
+        for (int c = 0; c < C; ++c) gp = fmaf(gy[(size_t)g * C + c], W[(size_t)c * width + k], gp);
         gh[i] = gp / (float)(cnt > 1 ? cnt : 1);
     }
 }
@@ -671,24 +707,7 @@ k_linear_mfma(float* __restrict__ y, int ldy, const float* __restrict__ x, int l
                 v[bb][4 * g] = q.x; v[bb][4 * g + 1] = q.y; v[bb][4 * g + 2] = q.z; v[bb][4 * g + 3] = q.w;
             }
         }
-        if (side && valid) {      // the folded per-row launches
-            if (ext.zero_rows) {
-                float* zr = ext.zero_rows + (size_t)n * ext.zero_ld;
-                for (int q = 4 * hh; q < ext.zero_w; q += 8) *reinterpret_cast<float4*>(zr + q) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (hh == 0) {
-                if (ext.zero3) { ext.zero3[3 * n] = 0.f; ext.zero3[3 * n + 1] = 0.f; ext.zero3[3 * n + 2] = 0.f; }
-                if (ext.copy3_dst) {
-                    ext.copy3_dst[3 * n] = ext.copy3_src[3 * n]; ext.copy3_dst[3 * n + 1] = ext.copy3_src[3 * n + 1];
-                    ext.copy3_dst[3 * n + 2] = ext.copy3_src[3 * n + 2];
-                }
-                if (ext.scale3_dst) {
-                    const float by = ext.scale3_by[n];
-                    ext.scale3_dst[3 * n] = ext.scale3_src[3 * n] * by; ext.scale3_dst[3 * n + 1] = ext.scale3_src[3 * n + 1] * by;
-                    ext.scale3_dst[3 * n + 2] = ext.scale3_src[3 * n + 2] * by;
-                }
-            }
-        }
+        if (side) pvs_tile_side_jobs(ext, tile * 32, N, lane);      // the folded per-row launches
         f32x16 acc[CB];
         float* dst0 = y + (size_t)nn * ldy;
         float* dst1 = (CB > 1 && ext.y1) ? ext.y1 + (size_t)nn * ext.ldy1 - 32 : dst0;
@@ -1291,7 +1310,7 @@ extern "C" int pvs_pool_head_bwd(const float* g_y, const float* pooled, const fl
                                  float* g_h, float* g_w, float* g_b, int32_t B, int32_t N, int32_t width, int32_t n_out,
                                  pvs_stream_t stream) {
     PVS_REQUIRE(width >= 1 && n_out >= 1 && g_w, "pool_head_bwd: bad arguments");
-    const int node_blocks = (g_h && N > 0) ? grid_for((long long)N * width, 256) : 0;
+    const int node_blocks = (g_h && N > 0) ? grid_for((long long)N * ((width & 3) == 0 ? width / 4 : width), 256) : 0;
     const int w_blocks = (n_out * width + 255) / 256;
     k_pool_head_bwd<<<node_blocks + w_blocks, 256, 0, (hipStream_t)stream>>>(g_y, pooled, w, graph_ptr, g_h, g_w, g_b, B,
                                                                            N, width, n_out, node_blocks);

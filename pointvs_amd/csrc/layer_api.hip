@@ -259,12 +259,11 @@ int node_pre_forward(hipStream_t s, const Dims& m, const PvsLayerParams* p, cons
         if (init) init->init_done = true;
         return 0;
     }
-    const bool ext_p = side_ok && pvs_linear_epilogue_supported(2 * H, H, 0, H, 0, H, PQ, h, nullptr);
     // P = W1[:, 0:H] h + b1 (row part), Q = W1[:, off_q:off_q+H] h (col part)
+    // (H = 64: the clears stay with the edge launcher's k_init_fwd - 6 us against 11 us as side jobs of this product,
+    // profiles/r03_ab_small_launch_folding.txt)
     PVS_TRY(pvs_launch_linear(s, PQ, 2 * H, h, H, p->edge_w1, m.ld1, 1, p->edge_b1, nullptr, 0,
-                              nullptr, 0, 0, m.N, H, 0, H, false, PVS_EPI_NONE, nullptr, 0, nullptr, 0,
-                              ext_p ? &e : nullptr));
-    if (ext_p) init->init_done = true;
+                              nullptr, 0, 0, m.N, H, 0, H, false));
     PVS_TRY(pvs_launch_linear(s, PQ + H, 2 * H, h, H, p->edge_w1 + m.off_q, m.ld1, 1, nullptr,
                               nullptr, 0, nullptr, 0, 0, m.N, H, 0, H, false));
     return 0;

@@ -310,7 +310,7 @@ def test_unsorted_segment_sum_and_mean():
         assert rel_err(d_gpu.grad.cpu().numpy(), d_ref.grad.numpy()) < 1e-6
 
 
-@pytest.mark.parametrize('width,n_out', [(32, 1), (64, 3), (100, 1), (128, 128), (1024, 2)])
+@pytest.mark.parametrize('width,n_out', [(32, 1), (64, 3), (100, 1), (33, 2), (128, 128), (1024, 2)])
 def test_pool_and_head_as_one_op(width, n_out):
     """feats_linear_layers(global_mean_pool(feats, batch)) (pnn_geometric_base.py:29-36) as PF.pool_head - one launch
     forward, one backward - against fp64 torch on CPU: ragged graphs, one empty graph, one single-node graph."""

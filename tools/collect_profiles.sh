@@ -11,7 +11,7 @@ cp $src/bench_cfg2_skip.json $dst/${tag}_bench_cfg2_skip_dead_coords.json
 cp $src/bench_cfg2_gpus2_gloo_shared_gpu.json $dst/${tag}_bench_cfg2_gpus2_gloo_shared_gpu.json
 for c in cfg2 cfg3 cfg5; do
   cp $src/prof_$c.json $dst/${tag}_profiled_bench_$c.json
-  f=$(ls $src/prof_$c/*/*kernel_stats.csv | head -1); cp $f $dst/${tag}_bench_${c}_kernel_stats.csv
+  f=$(ls -t $src/prof_$c/*/*kernel_stats.csv | head -1); cp $f $dst/${tag}_bench_${c}_kernel_stats.csv
 done
 cp $src/pmc_sq_summary.txt $dst/${tag}_cfg2_pmc_sq.txt
 cp $src/pmc_sq_cfg3_summary.txt $dst/${tag}_cfg3_pmc_sq.txt
