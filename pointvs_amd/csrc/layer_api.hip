@@ -211,7 +211,7 @@ int node_mlp_forward(hipStream_t s, const Dims& m, const PvsLayerDesc* d, const 
     const bool fuse_silu = can_epi && !(F & PVS_GRAPHNORM);
     const bool gated = (F & PVS_RESIDUAL) && (F & (PVS_REZERO | PVS_GATED_RESIDUAL));
     const bool fuse_out = can_epi && !(F & PVS_NODE_ATTENTION) && !gated;
-    static const bool split_small = getenv("PVS_EGNN_SPLIT_SMALL") != nullptr;     // (the launches apart, for A/B)
+    const bool split_small = getenv("PVS_EGNN_SPLIT_SMALL") != nullptr;     // (the launches apart, for A/B)
     if (fuse_silu && !gated && !split_small && p->node_b1 && p->node_b2 &&
         pvs_node_mlp_fused_supported(H, h, Magg, y1, h_out)) {
         // no GraphNorm, no rezero / gated residual: the whole chain y1 -> u -> o -> (node gate) -> h_out in one launch
@@ -241,7 +241,7 @@ int node_mlp_forward(hipStream_t s, const Dims& m, const PvsLayerDesc* d, const 
 int node_pre_forward(hipStream_t s, const Dims& m, const PvsLayerParams* p, const float* h,
                      float* PQ, PvsEdgeFwdIO* init = nullptr, uint32_t init_flags = 0) {
     const int H = m.H;
-    static const bool split_small = getenv("PVS_EGNN_SPLIT_SMALL") != nullptr;     // (the launches apart, for A/B)
+    const bool split_small = getenv("PVS_EGNN_SPLIT_SMALL") != nullptr;     // (the launches apart, for A/B)
     PvsLinearExt e;
     if (init) {
         e.zero_rows = init->Magg; e.zero_w = H; e.zero_ld = H;
@@ -485,7 +485,7 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     const float* su = so + (size_t)N * H;      // u = SiLU(GN(y1)) kept by the forward
 
     // ---- node_model backward ----
-    static const bool split_small = getenv("PVS_EGNN_SPLIT_SMALL") != nullptr;     // (the launches apart, for A/B)
+    const bool split_small = getenv("PVS_EGNN_SPLIT_SMALL") != nullptr;     // (the launches apart, for A/B)
     const bool mfma_bwd = pvs_use_mfma() && pvs_edge_bwd_mfma_supported(H, F, m.A);
     // Layers without GraphNorm and without rezero / gated residual: the output stage (node gate, residual), g_y1 and
     // [g_h | gM] as ONE launch that also carries the per-node preparation of the edge backward (dense_ops.hip:

@@ -559,8 +559,9 @@ def test_point_vs_entry_runs_the_readme_sequence_on_synthetic_graphs(tmp_path):
 @pytest.mark.parametrize('seed', range(8))
 def test_kernel_families_agree_on_random_configurations(seed):
     """Fuzz: random layer flags, hidden size, graph shape (isolated nodes, E not a multiple of the
-    tile, several graphs) - the default MFMA kernels (split fp16 / bf16 products), the exact-fp32-MFMA family
-    (PVS_EGNN_BF16X3=0) and the generic kernels give the same outputs and gradients."""
+    tile, several graphs) - the default MFMA kernels (split fp16 / bf16 products; node-level launches folded), the
+    exact-fp32-MFMA family (PVS_EGNN_BF16X3=0), the default kernels with every node-level launch apart
+    (PVS_EGNN_SPLIT_SMALL=1, PVS_FUSED_HEAD=0) and the generic kernels give the same outputs and gradients."""
     rng = np.random.default_rng(1000 + seed)
     flags = dict(
         k=int(rng.choice([32, 64])), num_layers=int(rng.integers(1, 4)),
@@ -581,8 +582,9 @@ def test_kernel_families_agree_on_random_configurations(seed):
     e = int(rng.integers(1, 40)) * n + int(rng.integers(0, 31))
     g = random_graph(n, e, seed=seed, n_graphs=int(rng.integers(1, 5)))
     runs = {}
-    for name, env in (('mfma', {}), ('fp32', {'PVS_EGNN_BF16X3': '0'}), ('generic', {'PVS_EGNN_KERNELS': 'generic'})):
-        for k_ in ('PVS_EGNN_BF16X3', 'PVS_EGNN_KERNELS'):
+    for name, env in (('mfma', {}), ('fp32', {'PVS_EGNN_BF16X3': '0'}), ('generic', {'PVS_EGNN_KERNELS': 'generic'}),
+                      ('split', {'PVS_EGNN_SPLIT_SMALL': '1', 'PVS_FUSED_HEAD': '0'})):
+        for k_ in ('PVS_EGNN_BF16X3', 'PVS_EGNN_KERNELS', 'PVS_EGNN_SPLIT_SMALL', 'PVS_FUSED_HEAD'):
             os.environ.pop(k_, None)
         os.environ.update(env)
         try:
@@ -591,13 +593,43 @@ def test_kernel_families_agree_on_random_configurations(seed):
             for k_ in env:
                 os.environ.pop(k_, None)
     y_ref, g_ref = runs['generic']
-    for name in ('mfma', 'fp32'):
+    for name in ('mfma', 'fp32', 'split'):      # ('split': the node-level launches of a layer one by one, as in round 2)
         y, grads = runs[name]
         assert rel_err(y, y_ref) < TOL, (name, flags)
         for pname in g_ref:
             assert (g_ref[pname] is None) == (grads[pname] is None), (name, pname)
             if g_ref[pname] is not None:
                 assert rel_err(grads[pname], g_ref[pname]) < 3 * TOL, (name, pname, flags)
+
+
+@pytest.mark.parametrize('changes', [dict(), dict(k=64), dict(residual=True), dict(k=64, residual=True, node_attention=True,
+                                                                           edge_attention=True)])
+def test_folded_node_level_launches_equal_the_separate_ones(changes, monkeypatch):
+    """Round 3 folded the node-level launches of a layer (P|Q as one product carrying the forward's clears, the node
+    MLP as one kernel each way, no output-stage launches, the gate's weight gradients inside the weight-gradient pass).
+    The products keep their MFMA order, so plain layers give the SAME BITS either way; with a node gate the row dot
+    products are summed in another order (1e-6). The head + loss as fused ops change summation orders too."""
+    model, _ = make_model(seed=5, num_layers=3, **changes)
+    g = random_graph(1500, 40000, seed=9, n_graphs=3)
+    y_a, g_a = gpu_run(model, g)
+    monkeypatch.setenv('PVS_EGNN_SPLIT_SMALL', '1')
+    y_b, g_b = gpu_run(model, g)
+    gated = changes.get('node_attention', False)
+    for name, a, b in [('logits', y_a, y_b)] + [(n, g_a[n], g_b[n]) for n in g_a]:
+        assert (a is None) == (b is None), name
+        if a is None:
+            continue
+        if gated:
+            assert rel_err(a, b) < 1e-6, name
+        else:
+            assert np.array_equal(np.asarray(a), np.asarray(b)), name
+    # and the head + loss as separate ops (other summation orders)
+    monkeypatch.setenv('PVS_FUSED_HEAD', '0')
+    y_c, g_c = gpu_run(model, g)
+    assert rel_err(y_a, y_c) < 1e-6
+    for n in g_a:
+        if g_a[n] is not None:
+            assert rel_err(g_a[n], g_c[n]) < 1e-5, n
 
 
 def test_fused_clip_adam_matches_torch_adam():
