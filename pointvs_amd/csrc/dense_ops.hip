@@ -1069,7 +1069,11 @@ int pvs_launch_node_mlp_fwd(hipStream_t s, int H, int N, const float* h, const f
         k_node_mlp_fwd<1><<<node_mlp_blocks(N), kThreads, lds, s>>>(h, Magg, W1, b1, W2, b2, N, residual ? 1 : 0, natt_w,
                                                                     natt_b, att_act, y1, u, o, h_out, natt_out);
     } else {
-        PVS_CHECK_HIP(hipFuncSetAttribute((const void*)k_node_mlp_fwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        static bool raised = false;      // (more than 48 KB of dynamic LDS: once per process)
+        if (!raised) {
+            PVS_CHECK_HIP(hipFuncSetAttribute((const void*)k_node_mlp_fwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            raised = true;
+        }
         k_node_mlp_fwd<2><<<node_mlp_blocks(N), kThreads, lds, s>>>(h, Magg, W1, b1, W2, b2, N, residual ? 1 : 0, natt_w,
                                                                     natt_b, att_act, y1, u, o, h_out, natt_out);
     }
@@ -1094,7 +1098,11 @@ int pvs_launch_node_mlp_bwd(hipStream_t s, int H, int N, const float* g_hout, co
         k_node_mlp_bwd<1><<<node_mlp_blocks(N), kThreads, lds, s>>>(g_hout, o, y1, W1, W2, N, residual ? 1 : 0, natt_w, natt_b,
                                                                     att_act, g_o, t1, gl, g_y1, g_h, gM, e);
     } else {
-        PVS_CHECK_HIP(hipFuncSetAttribute((const void*)k_node_mlp_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        static bool raised = false;
+        if (!raised) {
+            PVS_CHECK_HIP(hipFuncSetAttribute((const void*)k_node_mlp_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            raised = true;
+        }
         k_node_mlp_bwd<2><<<node_mlp_blocks(N), kThreads, lds, s>>>(g_hout, o, y1, W1, W2, N, residual ? 1 : 0, natt_w, natt_b,
                                                                     att_act, g_o, t1, gl, g_y1, g_h, gM, e);
     }
