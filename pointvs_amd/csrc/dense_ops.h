@@ -67,6 +67,59 @@ int pvs_launch_colreduce(hipStream_t s, int mode, float* out, const float* A, in
 int pvs_launch_reduce_slabs(hipStream_t s, float* out, int ldo, int inner, const float* slabs,
                             int n_slabs, int width, bool accumulate);
 
+// Sum over slabs of 32 consecutive outputs by one 256-thread workgroup (the one reduction order of every slab
+// reduction in the library): thread (sl = tid >> 5, ol = tid & 31) adds slabs sl, sl + 8, ... of output o0 + ol in four
+// independent partial sums; the eight partials are then added in order. Valid in the threads with sl == 0.
+__device__ __forceinline__ float pvs_slab_sum32(const float* __restrict__ slabs, int n_slabs, int width, int o,
+                                                float (*part)[33]) {
+    const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    float s = 0.f;
+    if (o < width) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int gidx = sl;
+        for (; gidx + 24 < n_slabs; gidx += 32) {
+            a0 += slabs[(size_t)gidx * width + o];
+            a1 += slabs[(size_t)(gidx + 8) * width + o];
+            a2 += slabs[(size_t)(gidx + 16) * width + o];
+            a3 += slabs[(size_t)(gidx + 24) * width + o];
+        }
+        for (; gidx < n_slabs; gidx += 8) a0 += slabs[(size_t)gidx * width + o];
+        s = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();            // (part may still be read from a previous call)
+    part[sl][ol] = s;
+    __syncthreads();
+    float t = 0.f;
+    if (sl == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += part[k][ol];
+    }
+    return t;
+}
+
+// the two-set slab reduction of a layer's backward as a job description (pvs_launch_reduce_slabs2, or extra workgroups
+// of the weight-gradient pass: independent work in one launch)
+struct PvsReduce2Args {
+    float* out_a = nullptr;
+    const float* slabs_a = nullptr;
+    int n_a = 0, width_a = 0, skip_lo = 0, skip_hi = 0;
+    float* out_b = nullptr;
+    const float* slabs_b = nullptr;
+    int n_b = 0, width_b = 0;
+    __host__ __device__ int blocks_a() const { return (width_a + 31) / 32; }
+    __host__ __device__ int blocks() const { return out_a ? (width_a + 31) / 32 + (width_b + 31) / 32 : 0; }
+};
+// workgroup `block` (of args.blocks()) of that reduction
+__device__ __forceinline__ void pvs_reduce2_block(const PvsReduce2Args& a, int block, float (*part)[33]) {
+    const bool is_a = block < a.blocks_a();
+    const float* slabs = is_a ? a.slabs_a : a.slabs_b;
+    float* out = is_a ? a.out_a : a.out_b;
+    const int n_slabs = is_a ? a.n_a : a.n_b, width = is_a ? a.width_a : a.width_b;
+    const int o = (block - (is_a ? 0 : a.blocks_a())) * 32 + (threadIdx.x & 31);
+    const float t = pvs_slab_sum32(slabs, n_slabs, width, o, part);
+    if ((threadIdx.x >> 5) == 0 && o < width && !(is_a && o >= a.skip_lo && o < a.skip_hi)) out[o] = t;
+}
+
 // out_a[o] = sum_g slabs_a[g*width_a + o] except o in [skip_lo, skip_hi); out_b[o] = sum_g slabs_b[g*width_b + o]
 int pvs_launch_reduce_slabs2(hipStream_t s, float* out_a, const float* slabs_a, int n_a, int width_a, int skip_lo,
                              int skip_hi, float* out_b, const float* slabs_b, int n_b, int width_b);
@@ -100,8 +153,13 @@ int pvs_node_wgrads_supported(int H);
 size_t pvs_node_wgrads_slab_floats(int N, int H);
 // scatter = false: stop after the slab reduction; *gsum_out then points at the reduced sums for a later
 // pvs_node_wgrads_scatter
+// extra != NULL: the launch also carries that (independent) two-set slab reduction as additional workgroups.
+// slabs_out != NULL: stop after the product kernel; *slabs_out describes the per-row-block partials for a kernel
+// that reduces and scatters them itself (pvs_node_wgrads_reduce_scatter32).
+struct PvsNodeWgradSlabs { const float* slabs = nullptr; int n_slabs = 0, width = 0; };
 int pvs_launch_node_wgrads(hipStream_t s, int H, int N, const PvsNodeWgradIn& in, const PvsNodeWgradOut& out,
-                           float* slabs, bool scatter = true, const float** gsum_out = nullptr);
+                           float* slabs, bool scatter = true, const float** gsum_out = nullptr,
+                           const PvsReduce2Args* extra = nullptr, PvsNodeWgradSlabs* slabs_out = nullptr);
 
 __device__ __forceinline__ void pvs_node_wgrads_scatter(const float* __restrict__ gsum, const PvsNodeWgradOut& out,
                                                         int H, int tid, int stride) {
@@ -127,4 +185,41 @@ __device__ __forceinline__ void pvs_node_wgrads_scatter(const float* __restrict_
         if (out.natt_w) out.natt_w[c] = b[96];
         if (out.natt_b && c == 0) out.natt_b[0] = b[128];
     }
+}
+
+// Reduce 32 consecutive entries [o0, o0 + 32) of the node weight-gradient slabs and write them where
+// pvs_node_wgrads_scatter would (same sums, same order: the scatter is a permutation, except that with shared P / Q
+// columns two entries add up). 256 threads; o0 % 32 == 0, so the 32 entries share product and sub-block.
+__device__ __forceinline__ void pvs_node_wgrads_reduce_scatter32(const PvsNodeWgradSlabs& ns, const PvsNodeWgradOut& out,
+                                                                 int H, int o0, float (*part)[33]) {
+    const int HB = H / 32;
+    const int sub = o0 / PVS_WG_SLAB, r0 = o0 - sub * PVS_WG_SLAB;      // block-uniform
+    const int bo = sub / HB, bi = sub - bo * HB;
+    const int ol = threadIdx.x & 31;
+    const bool writer = (threadIdx.x >> 5) == 0;
+    if (o0 >= ns.width) return;
+    if (r0 < PVS_WG_PRODUCTS * 1024) {
+        const int prod = r0 / 1024;
+        if (prod == 4 && out.perm) return;                               // added into the P entry below
+        float t = pvs_slab_sum32(ns.slabs, ns.n_slabs, ns.width, o0 + ol, part);
+        if (prod == 3 && out.perm) t += pvs_slab_sum32(ns.slabs, ns.n_slabs, ns.width, o0 + 1024 + ol, part);
+        if (!writer) return;
+        const int c = 32 * bo + (r0 % 1024) / 32, k = 32 * bi + ol;
+        if (prod == 0) out.node_w2[(size_t)c * H + k] = t;
+        else if (prod == 1) out.node_w1[(size_t)c * 2 * H + k] = t;
+        else if (prod == 2) out.node_w1[(size_t)c * 2 * H + H + k] = t;
+        else if (prod == 3) out.edge_w1[(size_t)c * out.ld1 + k] = t;
+        else out.edge_w1[(size_t)c * out.ld1 + out.off_q + k] = t;
+        return;
+    }
+    if (bi != 0) return;                                                 // column-sum vectors live in the bi == 0 slabs
+    const int vec = (r0 - PVS_WG_PRODUCTS * 1024) / 32;
+    const float t = pvs_slab_sum32(ns.slabs, ns.n_slabs, ns.width, o0 + ol, part);
+    if (!writer) return;
+    const int c = 32 * bo + ol;
+    if (vec == 0) { if (out.node_b2) out.node_b2[c] = t; }
+    else if (vec == 1) { if (out.node_b1) out.node_b1[c] = t; }
+    else if (vec == 2) { if (out.edge_b1) out.edge_b1[c] = t; }
+    else if (vec == 3) { if (out.natt_w) out.natt_w[c] = t; }
+    else if (vec == 4) { if (out.natt_b && c == 0) out.natt_b[0] = t; }
 }

@@ -215,38 +215,9 @@ k_reduce_slabs(float* __restrict__ out, int ldo, int inner, const float* __restr
 // Two slab reductions in one launch (the edge kernel's slabs and the column gather's slabs of one
 // layer backward): blocks [0, blocks_a) do A, the rest B; A leaves [skip_lo, skip_hi) to B.
 __global__ void __launch_bounds__(kThreads)
-k_reduce_slabs2(float* __restrict__ out_a, const float* __restrict__ slabs_a, int n_a, int width_a, int blocks_a,
-                int skip_lo, int skip_hi, float* __restrict__ out_b, const float* __restrict__ slabs_b, int n_b,
-                int width_b) {
+k_reduce_slabs2(PvsReduce2Args args) {
     __shared__ float part[8][33];
-    const bool is_a = (int)blockIdx.x < blocks_a;
-    const float* slabs = is_a ? slabs_a : slabs_b;
-    float* out = is_a ? out_a : out_b;
-    const int n_slabs = is_a ? n_a : n_b, width = is_a ? width_a : width_b;
-    const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int o = ((int)blockIdx.x - (is_a ? 0 : blocks_a)) * 32 + ol;
-    float s = 0.f;
-    if (o < width)
-    {   // four independent partial sums per lane (loads in flight), combined in a fixed order
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int gidx = sl;
-        for (; gidx + 24 < n_slabs; gidx += 32) {
-            a0 += slabs[(size_t)gidx * width + o];
-            a1 += slabs[(size_t)(gidx + 8) * width + o];
-            a2 += slabs[(size_t)(gidx + 16) * width + o];
-            a3 += slabs[(size_t)(gidx + 24) * width + o];
-        }
-        for (; gidx < n_slabs; gidx += 8) a0 += slabs[(size_t)gidx * width + o];
-        s = (a0 + a1) + (a2 + a3);
-    }
-    part[sl][ol] = s;
-    __syncthreads();
-    if (sl == 0 && o < width && !(is_a && o >= skip_lo && o < skip_hi)) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += part[k][ol];
-        out[o] = t;
-    }
+    pvs_reduce2_block(args, (int)blockIdx.x, part);
 }
 
 // The folded per-row launches (PvsLinearExt side jobs) for the 32 rows of a tile, by one wave: every store instruction
@@ -837,9 +808,13 @@ constexpr int kWgRowsPerBlock = 256;
 
 template <int HB>
 __global__ void __launch_bounds__(kThreads)
-k_node_wgrads(float* __restrict__ slabs, PvsNodeWgradIn in, int N) {
+k_node_wgrads(float* __restrict__ slabs, PvsNodeWgradIn in, int N, int row_blocks, PvsReduce2Args extra) {
     constexpr int H = 32 * HB;
     __shared__ float red[kWgSlab];
+    if ((int)blockIdx.x >= row_blocks) {      // the workgroups behind the row blocks: an independent slab reduction
+        if (blockIdx.y == 0) pvs_reduce2_block(extra, (int)blockIdx.x - row_blocks, reinterpret_cast<float(*)[33]>(red));
+        return;
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 31, hh = lane >> 5;
     const int bo = blockIdx.y / HB, bi = blockIdx.y % HB;
@@ -1120,9 +1095,10 @@ int pvs_launch_reduce_slabs(hipStream_t s, float* out, int ldo, int inner, const
 
 int pvs_launch_reduce_slabs2(hipStream_t s, float* out_a, const float* slabs_a, int n_a, int width_a, int skip_lo,
                              int skip_hi, float* out_b, const float* slabs_b, int n_b, int width_b) {
-    const int ba = (width_a + 31) / 32, bb = (width_b + 31) / 32;
-    k_reduce_slabs2<<<ba + bb, kThreads, 0, s>>>(out_a, slabs_a, n_a, width_a, ba, skip_lo, skip_hi, out_b, slabs_b,
-                                                 n_b, width_b);
+    PvsReduce2Args a;
+    a.out_a = out_a; a.slabs_a = slabs_a; a.n_a = n_a; a.width_a = width_a; a.skip_lo = skip_lo; a.skip_hi = skip_hi;
+    a.out_b = out_b; a.slabs_b = slabs_b; a.n_b = n_b; a.width_b = width_b;
+    k_reduce_slabs2<<<a.blocks(), kThreads, 0, s>>>(a);
     PVS_CHECK_LAUNCH();
     return 0;
 }
@@ -1204,15 +1180,21 @@ size_t pvs_node_wgrads_slab_floats(int N, int H) {
 }
 
 int pvs_launch_node_wgrads(hipStream_t s, int H, int N, const PvsNodeWgradIn& in, const PvsNodeWgradOut& out,
-                           float* slabs, bool scatter, const float** gsum_out) {
+                           float* slabs, bool scatter, const float** gsum_out, const PvsReduce2Args* extra,
+                           PvsNodeWgradSlabs* slabs_out) {
     PVS_REQUIRE(pvs_node_wgrads_supported(H), "node_wgrads: H = %d unsupported", H);
     PVS_REQUIRE(out.node_w2 && out.node_w1 && out.edge_w1, "node_wgrads: NULL weight gradient");
     const int hb = H / 32, rb = wg_row_blocks(N);
     const int width = hb * hb * kWgSlab;
     float* gsum = slabs + (size_t)rb * width;
-    if (hb == 1) k_node_wgrads<1><<<dim3(rb, 1), kThreads, 0, s>>>(slabs, in, N);
-    else k_node_wgrads<2><<<dim3(rb, 4), kThreads, 0, s>>>(slabs, in, N);
+    const PvsReduce2Args ex = extra ? *extra : PvsReduce2Args{};
+    if (hb == 1) k_node_wgrads<1><<<dim3(rb + ex.blocks(), 1), kThreads, 0, s>>>(slabs, in, N, rb, ex);
+    else k_node_wgrads<2><<<dim3(rb + ex.blocks(), 4), kThreads, 0, s>>>(slabs, in, N, rb, ex);
     PVS_CHECK_LAUNCH();
+    if (slabs_out) {
+        slabs_out->slabs = slabs; slabs_out->n_slabs = rb; slabs_out->width = width;
+        return 0;
+    }
     k_reduce_slabs<<<(width + 31) / 32, kThreads, 0, s>>>(gsum, width, width, slabs, rb, width, 1.0f, 0);
     PVS_CHECK_LAUNCH();
     if (gsum_out) *gsum_out = gsum;

@@ -161,12 +161,20 @@ size_t carve_bwd(PvsArena& a, const Dims& m, BwdWs* w) {
 }
 
 // scatter the reduced edge-kernel slab into the parameter gradients
-__global__ void k_finalize_edge_grads(const float* __restrict__ gsum, PvsSlabLayout L, int H, int A,
-                                      int ld1, int off_rho, PvsLayerGrads gr, int has_coord,
-                                      int has_att, int has_gate, const float* __restrict__ node_gsum,
-                                      PvsNodeWgradOut node_out) {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int stride = gridDim.x * blockDim.x;
+// The first `node_blocks` workgroups (if any) reduce the node-level weight-gradient slabs, 32 entries each, straight
+// into the gradient tensors (no reduced copy in between, no launch of its own); the others scatter the edge sums.
+__global__ void __launch_bounds__(256)
+k_finalize_edge_grads(const float* __restrict__ gsum, PvsSlabLayout L, int H, int A,
+                      int ld1, int off_rho, PvsLayerGrads gr, int has_coord,
+                      int has_att, int has_gate, const float* __restrict__ node_gsum,
+                      PvsNodeWgradOut node_out, PvsNodeWgradSlabs node_slabs, int node_blocks) {
+    if ((int)blockIdx.x < node_blocks) {
+        __shared__ float part[8][33];
+        pvs_node_wgrads_reduce_scatter32(node_slabs, node_out, H, 32 * (int)blockIdx.x, part);
+        return;
+    }
+    const int tid = ((int)blockIdx.x - node_blocks) * blockDim.x + threadIdx.x;
+    const int stride = ((int)gridDim.x - node_blocks) * blockDim.x;
     // (the node-level weight gradients' reduced sums, when they were left for this kernel to scatter)
     if (node_gsum) pvs_node_wgrads_scatter(node_gsum, node_out, H, tid, stride);
     for (int i = tid; i < H * H; i += stride) {
@@ -607,12 +615,19 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
         PVS_TRY(pvs_launch_node_gather(s, H, *g, false, w.gz1, w.gd, w.gx_row, g_x_out, w.gPQ, g_x,
                                        w.nslabs, 0, N, &n_nslabs));
     }
-    if (mfma_bwd) {
-        // g_wrho / g_wattr come from the node gather: its slab layout [wrho | wattr0 | wattr1 | wattr2]
-        // == gsum[L.wrho .. L.wrho + 4H), which the edge slabs leave alone (one launch for both)
+    // g_wrho / g_wattr come from the node gather: its slab layout [wrho | wattr0 | wattr1 | wattr2]
+    // == gsum[L.wrho .. L.wrho + 4H), which the edge slabs leave alone (one reduction for both). With the fused
+    // weight-gradient pass below that reduction rides on ITS launch as extra workgroups (independent work), and the
+    // pass's own slab reduction on the finalize launch: three launches at the end of a layer instead of five.
+    PvsReduce2Args edge_red;
+    edge_red.out_a = w.gsum; edge_red.slabs_a = w.eslabs; edge_red.n_a = n_slabs; edge_red.width_a = L.total;
+    edge_red.skip_lo = L.wrho; edge_red.skip_hi = L.wrho + 4 * H;
+    edge_red.out_b = w.gsum + L.wrho; edge_red.slabs_b = w.nslabs; edge_red.n_b = n_nslabs; edge_red.width_b = 4 * H;
+    const bool tail_folded = mfma_bwd && fused_wgrads && !split_small;
+    if (mfma_bwd && !tail_folded) {
         PVS_TRY(pvs_launch_reduce_slabs2(s, w.gsum, w.eslabs, n_slabs, L.total, L.wrho, L.wrho + 4 * H,
                                          w.gsum + L.wrho, w.nslabs, n_nslabs, 4 * H));
-    } else {
+    } else if (!mfma_bwd) {
         PVS_TRY(pvs_launch_reduce_slabs(s, w.gsum, L.total, L.total, w.eslabs, n_slabs, L.total, false));
     }
 
@@ -621,6 +636,7 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     PVS_TRY(pvs_launch_linear(s, g_h, H, w.gPQ, 2 * H, p->edge_w1, 1, m.ld1, nullptr, w.gPQ + H, 2 * H,
                               p->edge_w1 + m.off_q, 1, m.ld1, N, H, H, H, true));
     const float* node_gsum = nullptr;
+    PvsNodeWgradSlabs node_slabs;
     PvsNodeWgradOut node_out{};
     if (fused_wgrads) {
         PvsNodeWgradIn wi;
@@ -630,7 +646,10 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
         wo.node_b2 = gr.node_b2; wo.node_b1 = gr.node_b1; wo.edge_b1 = gr.edge_b1;
         wo.ld1 = m.ld1; wo.off_q = m.off_q; wo.perm = m.perm ? 1 : 0;
         if (gate_in_wgrads) { wi.t1 = w.t1; wi.gl = w.gl; wo.natt_w = gr.node_att_w; wo.natt_b = gr.node_att_b; }
-        PVS_TRY(pvs_launch_node_wgrads(s, H, N, wi, wo, w.wslabs, /*scatter=*/false, &node_gsum));
+        if (tail_folded)
+            PVS_TRY(pvs_launch_node_wgrads(s, H, N, wi, wo, w.wslabs, /*scatter=*/false, nullptr, &edge_red, &node_slabs));
+        else
+            PVS_TRY(pvs_launch_node_wgrads(s, H, N, wi, wo, w.wslabs, /*scatter=*/false, &node_gsum));
         node_out = wo;
     }
     if (gr.edge_w1 && !fused_wgrads) {
@@ -642,10 +661,10 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     if (gr.edge_b1 && !fused_wgrads)
         PVS_TRY(pvs_launch_colreduce(s, PVS_COL_SUM_A, gr.edge_b1, w.gPQ, 2 * H, nullptr, 0, nullptr,
                                      N, H, 1.f, w.dslabs, false));
-    k_finalize_edge_grads<<<H * H / 256 > 4 ? H * H / 256 : 4, 256, 0, s>>>(w.gsum, L, H, m.A, m.ld1, m.off_rho, gr,
-                                            coord_bwd ? 1 : 0, eatt ? 1 : 0,
-                                            (eres && (F & (PVS_REZERO | PVS_GATED_RESIDUAL))) ? 1 : 0,
-                                            node_gsum, node_out);
+    const int node_blocks = node_slabs.slabs ? (node_slabs.width + 31) / 32 : 0;
+    k_finalize_edge_grads<<<node_blocks + (H * H / 256 > 4 ? H * H / 256 : 4), 256, 0, s>>>(
+        w.gsum, L, H, m.A, m.ld1, m.off_rho, gr, coord_bwd ? 1 : 0, eatt ? 1 : 0,
+        (eres && (F & (PVS_REZERO | PVS_GATED_RESIDUAL))) ? 1 : 0, node_gsum, node_out, node_slabs, node_blocks);
     PVS_CHECK_LAUNCH();
     return 0;
 }
