@@ -157,9 +157,14 @@ size_t pvs_node_wgrads_slab_floats(int N, int H);
 // slabs_out != NULL: stop after the product kernel; *slabs_out describes the per-row-block partials for a kernel
 // that reduces and scatters them itself (pvs_node_wgrads_reduce_scatter32).
 struct PvsNodeWgradSlabs { const float* slabs = nullptr; int n_slabs = 0, width = 0; };
+// gh_job != NULL: the launch also computes g_h[n, :] += gPQ[n, 0:H] W1[:, 0:H] + gPQ[n, H:2H] W1[:, off_q:off_q+H]
+// (W1 = edge_mlp.0's weight, row stride ld1) - the product of this point of the backward that does not depend on the
+// weight gradients - as further workgroups.
+struct PvsGhJob { float* g_h = nullptr; const float* gPQ = nullptr; const float* W1 = nullptr; int ld1 = 0, off_q = 0, blocks = 0; };
 int pvs_launch_node_wgrads(hipStream_t s, int H, int N, const PvsNodeWgradIn& in, const PvsNodeWgradOut& out,
                            float* slabs, bool scatter = true, const float** gsum_out = nullptr,
-                           const PvsReduce2Args* extra = nullptr, PvsNodeWgradSlabs* slabs_out = nullptr);
+                           const PvsReduce2Args* extra = nullptr, PvsNodeWgradSlabs* slabs_out = nullptr,
+                           const PvsGhJob* gh_job = nullptr);
 
 __device__ __forceinline__ void pvs_node_wgrads_scatter(const float* __restrict__ gsum, const PvsNodeWgradOut& out,
                                                         int H, int tid, int stride) {

@@ -636,18 +636,20 @@ __global__ void k_mean_pool_bwd(const float* __restrict__ gp, const int32_t* __r
 // Rows (nodes) sit on the lanes: the X-layout operand of the products is read straight from the
 // row-major input (16-byte pieces), the weights are staged once per block in LDS (natural, padded
 // rows), the accumulator is stored back as rows. 32 rows per wave-tile.
+// The product as a workgroup-level routine (workgroup `block` of `n_blocks`, its weights staged in `smem`:
+// 32 CB (32 KB + 1) + 32 CB floats): k_linear_mfma is this routine alone; the weight-gradient pass of a layer's backward
+// carries it as one of its workgroup roles (independent work in one launch).
 template <int KB, int CB>
-__global__ void __launch_bounds__(kThreads)
-k_linear_mfma(float* __restrict__ y, int ldy, const float* __restrict__ x, int ldx, int kb1,
+__device__ __forceinline__ void linear_mfma_block(float* __restrict__ smem, int block, int n_blocks,
+              float* __restrict__ y, int ldy, const float* __restrict__ x, int ldx, int kb1,
               const float* __restrict__ x2, int ldx2, const float* __restrict__ W, int swc, int swk,
               const float* __restrict__ W2, int swc2, int swk2, const float* __restrict__ b, int N,
               int accumulate, int epi, const float* __restrict__ aux_in, int ld_in, float* __restrict__ aux_out,
-              int ld_out, PvsLinearExt ext) {
+              int ld_out, const PvsLinearExt& ext) {
     // epi (elementwise epilogue on the accumulator, saves a pass over [N,C]):
     //   1: aux_out = SiLU(y)          2: aux_out = aux_in + y          3: y *= SiLU'(aux_in)
     //   4: aux_out = y
     constexpr int K = 32 * KB, C = 32 * CB, LD = K + 1;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wn = smem;
     float* bias = smem + C * LD;
     const int k1 = 32 * kb1;
@@ -663,7 +665,7 @@ k_linear_mfma(float* __restrict__ y, int ldy, const float* __restrict__ x, int l
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 31, hh = lane >> 5;
     const int n_tiles = (N + 31) / 32;
-    for (int tile = blockIdx.x * (kThreads / 64) + wv; tile < n_tiles; tile += gridDim.x * (kThreads / 64)) {
+    for (int tile = block * (kThreads / 64) + wv; tile < n_tiles; tile += n_blocks * (kThreads / 64)) {
         const int n = tile * 32 + j;
         const bool valid = n < N;
         const int nn = valid ? n : N - 1;
@@ -725,6 +727,18 @@ k_linear_mfma(float* __restrict__ y, int ldy, const float* __restrict__ x, int l
                 }
         }
     }
+}
+
+template <int KB, int CB>
+__global__ void __launch_bounds__(kThreads)
+k_linear_mfma(float* __restrict__ y, int ldy, const float* __restrict__ x, int ldx, int kb1,
+              const float* __restrict__ x2, int ldx2, const float* __restrict__ W, int swc, int swk,
+              const float* __restrict__ W2, int swc2, int swk2, const float* __restrict__ b, int N,
+              int accumulate, int epi, const float* __restrict__ aux_in, int ld_in, float* __restrict__ aux_out,
+              int ld_out, PvsLinearExt ext) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    linear_mfma_block<KB, CB>(smem, (int)blockIdx.x, (int)gridDim.x, y, ldy, x, ldx, kb1, x2, ldx2, W, swc, swk, W2, swc2,
+                              swk2, b, N, accumulate, epi, aux_in, ld_in, aux_out, ld_out, ext);
 }
 
 // MFMA weight-gradient product for 32-aligned shapes: out[c][k] = sum_n A[n][c] * B[n][k].
@@ -808,11 +822,23 @@ constexpr int kWgRowsPerBlock = 256;
 
 template <int HB>
 __global__ void __launch_bounds__(kThreads)
-k_node_wgrads(float* __restrict__ slabs, PvsNodeWgradIn in, int N, int row_blocks, PvsReduce2Args extra) {
+k_node_wgrads(float* __restrict__ slabs, PvsNodeWgradIn in, int N, int row_blocks, PvsReduce2Args extra,
+              PvsGhJob gh) {
     constexpr int H = 32 * HB;
-    __shared__ float red[kWgSlab];
-    if ((int)blockIdx.x >= row_blocks) {      // the workgroups behind the row blocks: an independent slab reduction
-        if (blockIdx.y == 0) pvs_reduce2_block(extra, (int)blockIdx.x - row_blocks, reinterpret_cast<float(*)[33]>(red));
+    // (sized for the product role's weights: 32 HB (64 HB + 1) + 32 HB floats at HB = 2)
+    constexpr int kRedWords = kWgSlab > H * (2 * H + 1) + H ? kWgSlab : H * (2 * H + 1) + H;
+    __shared__ __attribute__((aligned(16))) float red[kRedWords];
+    if ((int)blockIdx.x >= row_blocks) {
+        // the workgroups behind the row blocks carry the two other jobs of this point of a layer's backward, both
+        // independent of the weight gradients: the edge-slab reduction, and g_h += [gP | gQ] W1 (the product that the
+        // next layer's backward waits for)
+        if (blockIdx.y != 0) return;
+        const int b = (int)blockIdx.x - row_blocks;
+        if (b < extra.blocks()) { pvs_reduce2_block(extra, b, reinterpret_cast<float(*)[33]>(red)); return; }
+        if (gh.blocks > 0)
+            linear_mfma_block<2 * HB, HB>(red, b - extra.blocks(), gh.blocks, gh.g_h, H, gh.gPQ, 2 * H, HB, gh.gPQ + H,
+                                          2 * H, gh.W1, 1, gh.ld1, gh.W1 + gh.off_q, 1, gh.ld1, nullptr, N, 1, 0,
+                                          nullptr, 0, nullptr, 0, PvsLinearExt{});
         return;
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1181,15 +1207,22 @@ size_t pvs_node_wgrads_slab_floats(int N, int H) {
 
 int pvs_launch_node_wgrads(hipStream_t s, int H, int N, const PvsNodeWgradIn& in, const PvsNodeWgradOut& out,
                            float* slabs, bool scatter, const float** gsum_out, const PvsReduce2Args* extra,
-                           PvsNodeWgradSlabs* slabs_out) {
+                           PvsNodeWgradSlabs* slabs_out, const PvsGhJob* gh_job) {
     PVS_REQUIRE(pvs_node_wgrads_supported(H), "node_wgrads: H = %d unsupported", H);
     PVS_REQUIRE(out.node_w2 && out.node_w1 && out.edge_w1, "node_wgrads: NULL weight gradient");
     const int hb = H / 32, rb = wg_row_blocks(N);
     const int width = hb * hb * kWgSlab;
     float* gsum = slabs + (size_t)rb * width;
     const PvsReduce2Args ex = extra ? *extra : PvsReduce2Args{};
-    if (hb == 1) k_node_wgrads<1><<<dim3(rb + ex.blocks(), 1), kThreads, 0, s>>>(slabs, in, N, rb, ex);
-    else k_node_wgrads<2><<<dim3(rb + ex.blocks(), 4), kThreads, 0, s>>>(slabs, in, N, rb, ex);
+    PvsGhJob gh = gh_job ? *gh_job : PvsGhJob{};
+    if (gh_job) {
+        PVS_REQUIRE(((uintptr_t)gh.g_h | (uintptr_t)gh.gPQ) % 16 == 0, "node_wgrads: the g_h job needs 16-byte aligned rows");
+        const int rows_m = N >= 32768 ? 256 : 128;
+        gh.blocks = (N + rows_m - 1) / rows_m;
+        if (gh.blocks > 1024) gh.blocks = 1024;
+    }
+    if (hb == 1) k_node_wgrads<1><<<dim3(rb + ex.blocks() + gh.blocks, 1), kThreads, 0, s>>>(slabs, in, N, rb, ex, gh);
+    else k_node_wgrads<2><<<dim3(rb + ex.blocks() + gh.blocks, 4), kThreads, 0, s>>>(slabs, in, N, rb, ex, gh);
     PVS_CHECK_LAUNCH();
     if (slabs_out) {
         slabs_out->slabs = slabs; slabs_out->n_slabs = rb; slabs_out->width = width;

@@ -633,8 +633,11 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
 
     // ---- first edge-MLP layer at node level: P = W1a h + b1, Q = W1b h ----
     // g_h += g_P W1a + g_Q W1b: one launch with the two (input, weight) pairs
-    PVS_TRY(pvs_launch_linear(s, g_h, H, w.gPQ, 2 * H, p->edge_w1, 1, m.ld1, nullptr, w.gPQ + H, 2 * H,
-                              p->edge_w1 + m.off_q, 1, m.ld1, N, H, H, H, true));
+    // (with the folded tail it is a role of the weight-gradient launch below)
+    const bool gh_folded = tail_folded && (((uintptr_t)g_h | (uintptr_t)w.gPQ) & 15) == 0;
+    if (!gh_folded)
+        PVS_TRY(pvs_launch_linear(s, g_h, H, w.gPQ, 2 * H, p->edge_w1, 1, m.ld1, nullptr, w.gPQ + H, 2 * H,
+                                  p->edge_w1 + m.off_q, 1, m.ld1, N, H, H, H, true));
     const float* node_gsum = nullptr;
     PvsNodeWgradSlabs node_slabs;
     PvsNodeWgradOut node_out{};
@@ -646,8 +649,11 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
         wo.node_b2 = gr.node_b2; wo.node_b1 = gr.node_b1; wo.edge_b1 = gr.edge_b1;
         wo.ld1 = m.ld1; wo.off_q = m.off_q; wo.perm = m.perm ? 1 : 0;
         if (gate_in_wgrads) { wi.t1 = w.t1; wi.gl = w.gl; wo.natt_w = gr.node_att_w; wo.natt_b = gr.node_att_b; }
+        PvsGhJob ghj;
+        ghj.g_h = g_h; ghj.gPQ = w.gPQ; ghj.W1 = p->edge_w1; ghj.ld1 = m.ld1; ghj.off_q = m.off_q;
         if (tail_folded)
-            PVS_TRY(pvs_launch_node_wgrads(s, H, N, wi, wo, w.wslabs, /*scatter=*/false, nullptr, &edge_red, &node_slabs));
+            PVS_TRY(pvs_launch_node_wgrads(s, H, N, wi, wo, w.wslabs, /*scatter=*/false, nullptr, &edge_red, &node_slabs,
+                                           gh_folded ? &ghj : nullptr));
         else
             PVS_TRY(pvs_launch_node_wgrads(s, H, N, wi, wo, w.wslabs, /*scatter=*/false, &node_gsum));
         node_out = wo;
