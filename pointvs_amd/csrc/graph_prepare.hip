@@ -265,8 +265,10 @@ __global__ void k_iota(int E, int32_t* iota) {
     if (p < E) iota[p] = p;
 }
 
-__global__ void k_init_split(int n_graphs, const int32_t* __restrict__ edge_ptr, int32_t* __restrict__ split) {
+__global__ void k_init_split(int n_graphs, const int32_t* __restrict__ edge_ptr, int32_t* __restrict__ split,
+                             int32_t* __restrict__ status) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) *status = 0;                           // (instead of a memset launch of its own)
     if (g < n_graphs) split[g] = edge_ptr[g + 1];      // no descent: the second run is empty
 }
 
@@ -596,9 +598,8 @@ extern "C" int pvs_graph_prepare_runs(const int64_t* edge_index, const int64_t* 
     carve_runs(arena, N, E, n_graphs, max_graph_nodes, &w);
     PVS_REQUIRE(arena.ok(), "pvs_graph_prepare_runs: workspace too small (%zu < %zu)", workspace_bytes, arena.off);
     PvsProfScope prof(stream, PVS_PROF_PREPARE);
-    PVS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), stream));
     const int T = 256;
-    k_init_split<<<(n_graphs + T - 1) / T, T, 0, stream>>>(n_graphs, edge_ptr, w.split);
+    k_init_split<<<(n_graphs + T - 1) / T > 0 ? (n_graphs + T - 1) / T : 1, T, 0, stream>>>(n_graphs, edge_ptr, w.split, status);
     PVS_CHECK_LAUNCH();
     if (E > 0) {
         const bool vec = (E & 1) == 0 && (((uintptr_t)edge_index | (uintptr_t)edge_attr) & 15) == 0;

@@ -63,17 +63,26 @@ class FusedClipAdam(torch.optim.Adam):
                     cap = max(n, 64)
                     self._ring = [[torch.empty((cap, 5), dtype=torch.int64).pin_memory(),
                                    torch.empty((cap, 5), dtype=torch.int64, device=dev), None] for _ in range(8)]
-                slot = self._ring[self._slot]
-                self._slot = (self._slot + 1) % len(self._ring)
-                if slot[2] is not None:
-                    slot[2].synchronize()
-                table_host, table_dev = slot[0], slot[1]
                 rows = [[p.data_ptr(), p.grad.data_ptr(), s['exp_avg'].data_ptr(), s['exp_avg_sq'].data_ptr(),
                          p.numel()] for p, s in items]
-                table_host[:n] = torch.tensor(rows, dtype=torch.int64)
-                table_dev[:n].copy_(table_host[:n], non_blocking=True)
-                slot[2] = torch.cuda.Event()
-                slot[2].record(torch.cuda.current_stream(dev))
+                last = getattr(self, '_last_table', None)
+                if last is not None and last[0] == rows and last[1].device == dev:
+                    # the same addresses as in the previous step (the caching allocator hands the gradients the same
+                    # blocks step after step): the table already on the device is this step's table - no upload
+                    table_dev = last[1]
+                else:
+                    slot = self._ring[self._slot]
+                    self._slot = (self._slot + 1) % len(self._ring)
+                    if slot[2] is not None:
+                        slot[2].synchronize()
+                    table_host, table_dev = slot[0], slot[1]
+                    table_host[:n] = torch.tensor(rows, dtype=torch.int64)
+                    table_dev[:n].copy_(table_host[:n], non_blocking=True)
+                    slot[2] = torch.cuda.Event()
+                    slot[2].record(torch.cuda.current_stream(dev))
+                    # (a ring slot is rewritten only after len(ring) - 1 other uploads, i.e. after this entry stopped
+                    # being `_last_table`; several step groups per call simply miss each other)
+                    self._last_table = (rows, table_dev)
                 _lib.check(lib.pvs_adam_clip_step(
                     _lib.ptr(table_dev), n, float(group['lr']), float(beta1), float(beta2),
                     float(group['eps']), float(group['weight_decay']), 1.0 - beta1 ** step, 1.0 - beta2 ** step,
