@@ -14,7 +14,9 @@ struct PvsLinearExt {
     float* y1 = nullptr;          // column block 1 (outputs 32..63) -> y1[n*ldy1 + (c - 32)] instead of y[n*ldy + c]
     int ldy1 = 0;
     int acc1 = -1;                // accumulate flag of column block 1 (-1: the call's)
-    long long w_shift1 = 0;       // added to the weight offsets of column block 1 (a second slice of one weight matrix)
+    long long w_shift1 = 0;       // added to the weight offsets of the column blocks from `shift_block` on (a second slice of one weight matrix)
+    int shift_block = 1;
+    int groups = 1;               // launch the product as `groups` groups of workgroups (grid.y), each with its own C / groups output columns
     int bias_blocks = 8;          // column blocks, from 0, that take the bias
     // per-row side jobs (valid rows):
     float* zero_rows = nullptr;   // zero_rows[n*zero_ld + 0 .. zero_w) = 0   (zero_w % 8 == 0, 16-byte aligned rows)

@@ -653,15 +653,21 @@ __device__ __forceinline__ void linear_mfma_block(float* __restrict__ smem, int 
     float* Wn = smem;
     float* bias = smem + C * LD;
     const int k1 = 32 * kb1;
+    // blockIdx.y = group of CB column blocks (ext.groups > 1: a product with 32 CB groups outputs as `groups` sets of
+    // workgroups that run side by side - P | Q at H = 64)
+    const int c0 = (int)blockIdx.y * C;
+    y += c0;
+    if (aux_in) aux_in += c0;
+    if (aux_out) aux_out += c0;
     for (int i = threadIdx.x; i < C * K; i += kThreads) {
         const int c = i / K, k = i % K;
-        const long long sh = (CB > 1 && c >= 32) ? ext.w_shift1 : 0;
-        Wn[c * LD + k] = k < k1 ? W[(long long)c * swc + (long long)k * swk + sh]
-                                : W2[(size_t)c * swc2 + (size_t)(k - k1) * swk2];
+        const long long sh = (c0 + c >= 32 * ext.shift_block) ? ext.w_shift1 : 0;
+        Wn[c * LD + k] = k < k1 ? W[(long long)(c0 + c) * swc + (long long)k * swk + sh]
+                                : W2[(size_t)(c0 + c) * swc2 + (size_t)(k - k1) * swk2];
     }
-    for (int c = threadIdx.x; c < C; c += kThreads) bias[c] = (b && c < 32 * ext.bias_blocks) ? b[c] : 0.f;
+    for (int c = threadIdx.x; c < C; c += kThreads) bias[c] = (b && c0 + c < 32 * ext.bias_blocks) ? b[c0 + c] : 0.f;
     __syncthreads();
-    const bool side = ext.zero_rows || ext.zero3 || ext.copy3_dst || ext.scale3_dst;
+    const bool side = blockIdx.y == 0 && (ext.zero_rows || ext.zero3 || ext.copy3_dst || ext.scale3_dst);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 31, hh = lane >> 5;
     const int n_tiles = (N + 31) / 32;
@@ -967,6 +973,33 @@ int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx,
                       int swc2, int swk2, int N, int K, int K2, int C, bool accumulate, int epi,
                       const float* aux_in, int ld_in, float* aux_out, int ld_out, const PvsLinearExt* ext) {
     PVS_REQUIRE(C >= 1, "linear: n_out %d unsupported", C);
+    if (ext && ext->groups > 1) {
+        // `groups` sets of workgroups, each the product for its own C / groups output columns (one launch, grid.y)
+        const int G = ext->groups, Cg = C / G;
+        PVS_REQUIRE(C % G == 0 && epi == 0 && !ext->y1 && !x2 && K2 == 0 &&
+                    pvs_linear_epilogue_supported(ldy, ldx, 0, K, 0, Cg, y, x, nullptr),
+                    "linear: grouped launch of %d x %d outputs unsupported", G, Cg);
+        if (N <= 0) return 0;
+        const int rows_g = N >= 32768 ? 256 : 128;
+        int blocks_g = (N + rows_g - 1) / rows_g;
+        if (blocks_g > 1024) blocks_g = 1024;
+        const size_t lds_g = (size_t)(Cg * (K + 1) + Cg) * sizeof(float);
+        const PvsLinearExt e = *ext;
+#define PVS_LIN_G(KBV, CBV)                                                                                        \
+        k_linear_mfma<KBV, CBV><<<dim3(blocks_g, G), kThreads, lds_g, s>>>(y, ldy, x, ldx, K / 32, nullptr, 0, W, swc, swk, \
+                                                                           nullptr, 0, 0, b, N, accumulate ? 1 : 0, 0,  \
+                                                                           nullptr, 0, nullptr, 0, e)
+        const int kbg = K / 32, cbg = Cg / 32;
+        if (kbg == 1 && cbg == 1) PVS_LIN_G(1, 1);
+        else if (kbg == 2 && cbg == 1) PVS_LIN_G(2, 1);
+        else if (kbg == 4 && cbg == 1) PVS_LIN_G(4, 1);
+        else if (kbg == 1 && cbg == 2) PVS_LIN_G(1, 2);
+        else if (kbg == 2 && cbg == 2) PVS_LIN_G(2, 2);
+        else PVS_LIN_G(4, 2);
+#undef PVS_LIN_G
+        PVS_CHECK_LAUNCH();
+        return 0;
+    }
     PVS_REQUIRE(!ext || (pvs_linear_epilogue_supported(ldy, ldx, x2 ? ldx2 : 0, K, K2, C, y, x, x2) &&
                          ext->zero_w % 8 == 0 && (ext->zero_ld & 3) == 0 && ((uintptr_t)ext->zero_rows & 15) == 0 &&
                          (!ext->y1 || (C == 64 && (ext->ldy1 & 3) == 0 && ((uintptr_t)ext->y1 & 15) == 0))),
