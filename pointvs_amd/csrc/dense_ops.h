@@ -17,6 +17,7 @@ struct PvsLinearExt {
     long long w_shift1 = 0;       // added to the weight offsets of the column blocks from `shift_block` on (a second slice of one weight matrix)
     int shift_block = 1;
     int groups = 1;               // launch the product as `groups` groups of workgroups (grid.y), each with its own C / groups output columns
+    int side_group = 0;           // 1: the side jobs below get a group of workgroups of their own (grid.y = groups) instead of riding on group 0
     int bias_blocks = 8;          // column blocks, from 0, that take the bias
     // per-row side jobs (valid rows):
     float* zero_rows = nullptr;   // zero_rows[n*zero_ld + 0 .. zero_w) = 0   (zero_w % 8 == 0, 16-byte aligned rows)

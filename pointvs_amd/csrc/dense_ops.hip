@@ -655,6 +655,12 @@ __device__ __forceinline__ void linear_mfma_block(float* __restrict__ smem, int 
     const int k1 = 32 * kb1;
     // blockIdx.y = group of CB column blocks (ext.groups > 1: a product with 32 CB groups outputs as `groups` sets of
     // workgroups that run side by side - P | Q at H = 64)
+    if (ext.side_group && (int)blockIdx.y == ext.groups) {      // the group that only does the per-row side jobs
+        const int n_tiles_s = (N + 31) / 32;
+        for (int tile = block * (kThreads / 64) + (threadIdx.x >> 6); tile < n_tiles_s; tile += n_blocks * (kThreads / 64))
+            pvs_tile_side_jobs(ext, tile * 32, N, threadIdx.x & 63);
+        return;
+    }
     const int c0 = (int)blockIdx.y * C;
     y += c0;
     if (aux_in) aux_in += c0;
@@ -667,7 +673,7 @@ __device__ __forceinline__ void linear_mfma_block(float* __restrict__ smem, int 
     }
     for (int c = threadIdx.x; c < C; c += kThreads) bias[c] = (b && c0 + c < 32 * ext.bias_blocks) ? b[c0 + c] : 0.f;
     __syncthreads();
-    const bool side = blockIdx.y == 0 && (ext.zero_rows || ext.zero3 || ext.copy3_dst || ext.scale3_dst);
+    const bool side = blockIdx.y == 0 && !ext.side_group && (ext.zero_rows || ext.zero3 || ext.copy3_dst || ext.scale3_dst);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 31, hh = lane >> 5;
     const int n_tiles = (N + 31) / 32;
@@ -977,6 +983,7 @@ int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx,
         // `groups` sets of workgroups, each the product for its own C / groups output columns (one launch, grid.y)
         const int G = ext->groups, Cg = C / G;
         PVS_REQUIRE(C % G == 0 && epi == 0 && !ext->y1 && !x2 && K2 == 0 &&
+                    ext->zero_w % 4 == 0 && (ext->zero_ld & 3) == 0 && ((uintptr_t)ext->zero_rows & 15) == 0 &&
                     pvs_linear_epilogue_supported(ldy, ldx, 0, K, 0, Cg, y, x, nullptr),
                     "linear: grouped launch of %d x %d outputs unsupported", G, Cg);
         if (N <= 0) return 0;
@@ -986,7 +993,7 @@ int pvs_launch_linear(hipStream_t s, float* y, int ldy, const float* x, int ldx,
         const size_t lds_g = (size_t)(Cg * (K + 1) + Cg) * sizeof(float);
         const PvsLinearExt e = *ext;
 #define PVS_LIN_G(KBV, CBV)                                                                                        \
-        k_linear_mfma<KBV, CBV><<<dim3(blocks_g, G), kThreads, lds_g, s>>>(y, ldy, x, ldx, K / 32, nullptr, 0, W, swc, swk, \
+        k_linear_mfma<KBV, CBV><<<dim3(blocks_g, G + (e.side_group ? 1 : 0)), kThreads, lds_g, s>>>(y, ldy, x, ldx, K / 32, nullptr, 0, W, swc, swk, \
                                                                            nullptr, 0, 0, b, N, accumulate ? 1 : 0, 0,  \
                                                                            nullptr, 0, nullptr, 0, e)
         const int kbg = K / 32, cbg = Cg / 32;

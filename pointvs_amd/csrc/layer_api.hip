@@ -269,13 +269,15 @@ int node_pre_forward(hipStream_t s, const Dims& m, const PvsLayerParams* p, cons
     }
     if (H == 64 && !split_small && pvs_linear_epilogue_supported(2 * H, H, 0, H, 0, H, PQ, h, nullptr)) {
         // H = 64: P and Q as two groups of workgroups of ONE launch (64 outputs each; the second group on the Q slice of
-        // the weight, no bias). The clears stay with the edge launcher's k_init_fwd (6 us against 11 us as side jobs,
-        // profiles/r03_ab_small_launch_folding.txt).
-        PvsLinearExt g2;
-        g2.groups = 2; g2.shift_block = 2; g2.bias_blocks = 2;
+        // the weight, no bias), the forward's clears as a third group (as side jobs of the P workgroups they cost 11 us
+        // against 6 for a launch of their own, profiles/r03_ab_small_launch_folding.txt).
+        PvsLinearExt g2 = side_ok ? e : PvsLinearExt{};      // (with the forward's clears as a third group of their own)
+        g2.groups = 2; g2.shift_block = 2; g2.bias_blocks = 2; g2.side_group = side_ok ? 1 : 0;
         g2.w_shift1 = (long long)m.off_q - 64LL * m.ld1;
-        return pvs_launch_linear(s, PQ, 2 * H, h, H, p->edge_w1, m.ld1, 1, p->edge_b1, nullptr, 0, nullptr, 0, 0, m.N, H, 0,
-                                 2 * H, false, PVS_EPI_NONE, nullptr, 0, nullptr, 0, &g2);
+        PVS_TRY(pvs_launch_linear(s, PQ, 2 * H, h, H, p->edge_w1, m.ld1, 1, p->edge_b1, nullptr, 0, nullptr, 0, 0, m.N, H, 0,
+                                  2 * H, false, PVS_EPI_NONE, nullptr, 0, nullptr, 0, &g2));
+        if (side_ok) init->init_done = true;
+        return 0;
     }
     // P = W1[:, 0:H] h + b1 (row part), Q = W1[:, off_q:off_q+H] h (col part)
     PVS_TRY(pvs_launch_linear(s, PQ, 2 * H, h, H, p->edge_w1, m.ld1, 1, p->edge_b1, nullptr, 0,
