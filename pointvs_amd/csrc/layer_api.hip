@@ -259,9 +259,12 @@ int node_pre_forward(hipStream_t s, const Dims& m, const PvsLayerParams* p, cons
     const bool side_ok = init && !split_small && ((uintptr_t)init->Magg & 15) == 0;
     if (H == 32 && !split_small && pvs_linear_epilogue_supported(2 * H, H, 0, H, 0, 2 * H, PQ, h, nullptr) &&
         (!init || side_ok)) {
-        // P | Q in one launch: 64 outputs, the second column block on the Q slice of edge_mlp.0's weight, no bias
+        // P | Q in one launch: 64 outputs, the second column block (group) on the Q slice of edge_mlp.0's weight, no bias
         e.w_shift1 = (long long)m.off_q - 32LL * m.ld1;
         e.bias_blocks = 1;
+        // (as two groups of one-column-block workgroups, the clears as a third group: 12 us against 15-16 for
+        // workgroups twice as long that also do the clears)
+        e.groups = 2; e.side_group = init ? 1 : 0;
         PVS_TRY(pvs_launch_linear(s, PQ, 2 * H, h, H, p->edge_w1, m.ld1, 1, p->edge_b1, nullptr, 0, nullptr, 0, 0, m.N,
                                   H, 0, 2 * H, false, PVS_EPI_NONE, nullptr, 0, nullptr, 0, &e));
         if (init) init->init_done = true;
