@@ -243,9 +243,11 @@ int node_mlp_forward(hipStream_t s, const Dims& m, const PvsLayerDesc* d, const 
     return 0;
 }
 
+// P and Q of a layer as ONE launch where the MFMA linear takes the shape (H = 32, 64): two groups of workgroups, one per
+// 32- or 64-column half of the output, the second on the Q slice of edge_mlp.0's weight.
 // `init` (MFMA edge forward only): the edge kernel never flushes rows without edges, so Magg = 0 and x_out = x (0 for
-// raw sums) are written first - as side jobs of the P/Q product (the node rows are dealt to its lanes anyway) where the
-// MFMA linear takes the shape, else by the edge launcher's own small kernel (io->init_done stays false).
+// raw sums) are written first - by a third group of workgroups of that launch, else by the edge launcher's own small
+// kernel (io->init_done stays false).
 int node_pre_forward(hipStream_t s, const Dims& m, const PvsLayerParams* p, const float* h,
                      float* PQ, PvsEdgeFwdIO* init = nullptr, uint32_t init_flags = 0) {
     const int H = m.H;
