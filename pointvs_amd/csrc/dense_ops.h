@@ -57,8 +57,11 @@ int pvs_reduce_blocks(int N);
 int pvs_colreduce_blocks(int N);   // slabs of pvs_launch_colreduce: [pvs_colreduce_blocks(N)][C] (<= 4 x pvs_reduce_blocks)
 
 // out[c*ldo + k] (=|+=) sum_n A[n*lda + c] * B[n*ldb + k]   (weight gradients), C*K <= 8192
+// colsum_out != NULL (narrow right operand only, pvs_tsgemm_colsum_supported): colsum_out[c] = sum_n A[n*lda + c] out of
+// the same pass (a ones column in the zero padding of B)
+bool pvs_tsgemm_colsum_supported(int N, int C, int K);
 int pvs_launch_tsgemm_tn(hipStream_t s, float* out, int ldo, const float* A, int lda, const float* B,
-                         int ldb, int N, int C, int K, float* slabs, bool accumulate);
+                         int ldb, int N, int C, int K, float* slabs, bool accumulate, float* colsum_out = nullptr);
 
 enum { PVS_COL_SUM_A = 0, PVS_COL_SUM_AB = 1, PVS_COL_SUMSQ_SHIFT = 2 };
 // out[c] (=|+=) scale * sum_n f(A[n*lda+c], B[n*ldb+c] | shift[c])

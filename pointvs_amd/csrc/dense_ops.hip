@@ -182,7 +182,9 @@ k_colreduce4(int mode, float* __restrict__ slabs, const float* __restrict__ A, i
 // added in lane order: a fixed summation tree, so the result is reproducible.
 __global__ void __launch_bounds__(kThreads)
 k_reduce_slabs(float* __restrict__ out, int ldo, int inner, const float* __restrict__ slabs,
-               int n_slabs, int width, float scale, int accumulate, int inner_valid = 1 << 30) {
+               int n_slabs, int width, float scale, int accumulate, int inner_valid = 1 << 30,
+               float* __restrict__ extra_col = nullptr) {
+    // extra_col: entry (row, inner_valid) of every row goes to extra_col[row] (the column sums of a ones column)
     __shared__ float part[8][33];
     const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int o = blockIdx.x * 32 + ol;
@@ -202,13 +204,13 @@ k_reduce_slabs(float* __restrict__ out, int ldo, int inner, const float* __restr
     }
     part[sl][ol] = s;
     __syncthreads();
-    if (sl == 0 && o < width && (o % inner) < inner_valid) {
+    if (sl == 0 && o < width && ((o % inner) < inner_valid || (extra_col && (o % inner) == inner_valid))) {
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += part[k][ol];
         t *= scale;
-        float* dst = out + (size_t)(o / inner) * ldo + (o % inner);
-        *dst = accumulate ? *dst + t : t;
+        float* dst = (o % inner) < inner_valid ? out + (size_t)(o / inner) * ldo + (o % inner) : extra_col + o / inner;
+        *dst = (accumulate && (o % inner) < inner_valid) ? *dst + t : t;
     }
 }
 
@@ -763,8 +765,10 @@ typedef f32x16 f32x16_t;
 template <int CB, int KB>
 __global__ void __launch_bounds__(kThreads)
 k_tsgemm_mfma(float* __restrict__ slabs, const float* __restrict__ A, int lda,
-              const float* __restrict__ B, int ldb, int N, int rows_per_block, int kvalid) {
-    // kvalid: number of real columns of B (< 32*KB: the rest of the block is zero; slab stays padded)
+              const float* __restrict__ B, int ldb, int N, int rows_per_block, int kvalid, int ones_col = 0) {
+    // kvalid: number of real columns of B (< 32*KB: the rest of the block is zero; slab stays padded).
+    // ones_col: column kvalid of the padded B is 1 for every row, so column kvalid of the product is the column sums of A
+    // (a bias gradient out of the same pass)
     __shared__ float red[CB * KB * 1024];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 31, hh = lane >> 5;
@@ -787,7 +791,9 @@ k_tsgemm_mfma(float* __restrict__ slabs, const float* __restrict__ A, int lda,
 #pragma unroll
             for (int a = 0; a < CB; ++a) av[u][a] = ok ? A[(size_t)n * lda + 32 * a + j] : 0.f;
 #pragma unroll
-            for (int b = 0; b < KB; ++b) bv[u][b] = (ok && 32 * b + j < kvalid) ? B[(size_t)n * ldb + 32 * b + j] : 0.f;
+            for (int b = 0; b < KB; ++b)
+                bv[u][b] = (ok && 32 * b + j < kvalid) ? B[(size_t)n * ldb + 32 * b + j]
+                                                       : ((ok && ones_col && 32 * b + j == kvalid) ? 1.f : 0.f);
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u)
@@ -1169,8 +1175,11 @@ int pvs_launch_reduce_slabs2(hipStream_t s, float* out_a, const float* slabs_a, 
     return 0;
 }
 
+bool pvs_tsgemm_colsum_supported(int N, int C, int K) { return C % 32 == 0 && C <= 64 && K < 32 && N >= 1024; }
+
 int pvs_launch_tsgemm_tn(hipStream_t s, float* out, int ldo, const float* A, int lda, const float* B,
-                         int ldb, int N, int C, int K, float* slabs, bool accumulate) {
+                         int ldb, int N, int C, int K, float* slabs, bool accumulate, float* colsum_out) {
+    PVS_REQUIRE(!colsum_out || pvs_tsgemm_colsum_supported(N, C, K), "tsgemm: column sums need the narrow MFMA path");
     const int CK = C * K;
     PVS_REQUIRE(C <= 32 * kThreads, "tsgemm: %d x %d outputs unsupported", C, K);
     if (C % 64 == 0 && K % 64 == 0 && (C > 64 || K > 64)) {
@@ -1218,11 +1227,12 @@ int pvs_launch_tsgemm_tn(hipStream_t s, float* out, int ldo, const float* A, int
     if (C % 32 == 0 && C <= 64 && K < 32 && N >= 1024) {
         // narrow right operand (the input embedding: K = 12 atom features): zero-padded to one
         // 32-column MFMA block; the slabs keep the padded [C][32] layout, the reduction skips the pad
-        if (C == 32) k_tsgemm_mfma<1, 1><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb, K);
-        else k_tsgemm_mfma<2, 1><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb, K);
+        const int ones = colsum_out ? 1 : 0;      // (column K of the padded right operand = 1: column sums of A for free)
+        if (C == 32) k_tsgemm_mfma<1, 1><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb, K, ones);
+        else k_tsgemm_mfma<2, 1><<<blocks, kThreads, 0, s>>>(slabs, A, lda, B, ldb, N, rpb, K, ones);
         PVS_CHECK_LAUNCH();
         k_reduce_slabs<<<(C * 32 + 31) / 32, kThreads, 0, s>>>(out, ldo, 32, slabs, blocks, C * 32, 1.0f,
-                                                              accumulate ? 1 : 0, K);
+                                                              accumulate ? 1 : 0, K, colsum_out);
         PVS_CHECK_LAUNCH();
         return 0;
     }
@@ -1328,11 +1338,12 @@ extern "C" int pvs_linear_bwd(const float* x, const float* w, const float* g_y, 
                                0, K, false);
         if (rc) return rc;
     }
+    const bool bias_in_product = g_w && g_b && pvs_tsgemm_colsum_supported(N, C, K);
     if (g_w) {
-        rc = pvs_launch_tsgemm_tn(s, g_w, K, g_y, C, x, K, N, C, K, slabs, false);
+        rc = pvs_launch_tsgemm_tn(s, g_w, K, g_y, C, x, K, N, C, K, slabs, false, bias_in_product ? g_b : nullptr);
         if (rc) return rc;
     }
-    if (g_b) {
+    if (g_b && !bias_in_product) {
         rc = pvs_launch_colreduce(s, PVS_COL_SUM_A, g_b, g_y, C, nullptr, 0, nullptr, N, C, 1.0f,
                                   slabs, false);
         if (rc) return rc;
