@@ -95,6 +95,13 @@ __device__ __forceinline__ void wgrad_tile_f16(const unsigned short* __restrict_
     }
 }
 
+// timing-only ablations (tools/variant_obj.sh builds; never in the shipped library)
+#ifdef PVS_ABL_F_NOWGRAD
+#define F16_WGRAD(...) ((void)0)
+#else
+#define F16_WGRAD(...) wgrad_tile_f16(__VA_ARGS__)
+#endif
+
 struct F16Cfg {
     static constexpr int kThreadsPerBlock = 512;                          // two waves per SIMD
     static constexpr int kWavesPerBlock = kThreadsPerBlock / 64;
@@ -416,7 +423,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gm[r] = accg[r] * kg;
                 pvs_wave_lds_sync();                                  // the m and g_zc images are complete
-                wgrad_tile_f16(GI, MI, ones0, lane, inv_sg * inv_sm, inv_sg, gWc1, gB);   // gWc1 += g_zc (x) m ; g_bc1 += sum_e g_zc
+                F16_WGRAD(GI, MI, ones0, lane, inv_sg * inv_sm, inv_sg, gWc1, gB);   // gWc1 += g_zc (x) m ; g_bc1 += sum_e g_zc
                 load_row_terms();
             } else {
                 load_row_terms();
@@ -458,7 +465,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             for (int r = 0; r < 16; ++r) ga1[r] = 0.f;
             chain_f16<true>(W2i, lane, pb, ga1);
             pvs_wave_lds_sync();                                      // the a1 and g_z2 images are complete
-            wgrad_tile_f16(GI, A1I, ones1, lane, inv_sg2 * inv_sa1, inv_sg2, gW2, gB);
+            F16_WGRAD(GI, A1I, ones1, lane, inv_sg2 * inv_sa1, inv_sg2, gW2, gB);
             float g_z1[1][16];
             const float k1g = inv_sg2 * inv_sw2;
 #pragma unroll
@@ -488,11 +495,13 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 *reinterpret_cast<float4*>(T1 + j * Cfg::kTS + 8 * gq + 4 * hh) =
                     make_float4(g_z1[0][4 * gq], g_z1[0][4 * gq + 1], g_z1[0][4 * gq + 2], g_z1[0][4 * gq + 3]);
             pvs_wave_lds_sync();
+#ifndef PVS_ABL_F_NOREDUCE
             reduce_rows_tile<1>(T1, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
                                 [&](int rl, int q, const float4& v) {
                                     if (e0 + rl < e_this_end)   // streamed once: non-temporal
                                         pvs_store_nt(io.gz1 + (size_t)(e0 + rl) * H + 4 * q, v);
                                 });
+#endif
             I = In;
             e0 = e_this_end;
             t_end = n_end;

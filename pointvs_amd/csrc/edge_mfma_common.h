@@ -522,6 +522,26 @@ __device__ __forceinline__ float pvs_tile_scale_blocks(const float (&v)[HB][16],
     return pvs_f16_scale(pvs_wave_max_u32(__float_as_uint(m)), inv);
 }
 
+// PER-EDGE scale of an operand of a CHAIN product (round 4). Z = W V has one column per edge, so a scale may differ
+// from edge to edge: column e of (W s_w)(V s_e) is s_w s_e Z[:, e], and in the X / D layouts a lane holds exactly one
+// edge's column - the accumulator is descaled with the lane's own 1 / s_e. Every edge then keeps 22 bits relative to
+// ITS OWN largest channel, however large its tile-mates are (with one scale per tile an edge 2^-20 of a tile-mate kept
+// ~18 bits), and the scale costs less than the wave-wide maximum: the two halves of the wave hold the two channel
+// halves of the same 32 edges, so one v_permlane32_swap pairs them up. (The weight-gradient products sum over the
+// EDGE index and need one scale per tile: the backward kernels keep pvs_tile_scale.)
+__device__ __forceinline__ unsigned pvs_pair_halves_max_u32(unsigned v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // r[0]: lanes j of both halves, r[1]: lanes 32 + j
+    return max(r[0], r[1]);
+}
+
+template <int HB>
+__device__ __forceinline__ float pvs_edge_scale_blocks(const float (&v)[HB][16], float* inv) {
+    float m = pvs_absmax16(v[0]);
+#pragma unroll
+    for (int b = 1; b < HB; ++b) m = fmaxf(m, pvs_absmax16(v[b]));
+    return pvs_f16_scale(pvs_pair_halves_max_u32(__float_as_uint(m)), inv);
+}
+
 // largest |W[i]| of an n-element array as fp32 bits, over the whole workgroup (slot: one LDS word, zeroed
 // by the caller before a barrier; call from every thread, read *slot after the next barrier)
 __device__ __forceinline__ void pvs_block_absmax(const float* __restrict__ W, int n, unsigned* slot) {

@@ -18,7 +18,8 @@
 
 namespace {
 
-// F16X2 (round 3): the two chain products as three-term fp16 products with tile scales (edge_mfma_common.h)
+// F16X2 (round 3): the two chain products as three-term fp16 products with power-of-two operand scales - per EDGE
+// since round 4 (pvs_edge_scale_blocks, edge_mfma_common.h)
 // instead of six-term bf16 products: half the MFMAs, 2 instead of 5.5 VALU instructions per split value.
 // MODE (H = 128, where two split weight matrices do not fit in LDS beside the waves' tiles: the layer's edge forward runs
 // as two launches): 0 everything; 1 everything but the coordinate branch, with only W2 staged - the messages go to
@@ -179,7 +180,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                 if constexpr (!F16X2) load_tab<HB>(b2t, hh, bias);
                 if constexpr (F16X2) {
                     float inv_s;
-                    const float s_a = pvs_tile_scale_blocks<HB>(a1, &inv_s);
+                    const float s_a = pvs_edge_scale_blocks<HB>(a1, &inv_s);      // (per edge: one column of the product)
 #pragma unroll
                     for (int b = 0; b < HB; ++b)
 #pragma unroll
@@ -236,7 +237,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                 float q[HB][16];
                 if constexpr (F16X2) {
                     float inv_s;
-                    const float s_m = pvs_tile_scale_blocks<HB>(m, &inv_s);
+                    const float s_m = pvs_edge_scale_blocks<HB>(m, &inv_s);
 #pragma unroll
                     for (int b = 0; b < HB; ++b)
 #pragma unroll

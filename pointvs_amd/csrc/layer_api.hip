@@ -149,7 +149,7 @@ size_t carve_bwd(PvsArena& a, const Dims& m, BwdWs* w) {
     t.dslabs = a.take<float>((size_t)pvs_reduce_blocks(m.N) * m.H * m.H);
     t.S1 = a.take<float>(m.H);
     t.S2 = a.take<float>(m.H);
-    t.coefs = a.take<float>(3 * (size_t)m.H);
+    t.coefs = a.take<float>(4 * (size_t)m.H);
     t.gvec = a.take<float>(m.H);
     t.nslabs = a.take<float>((size_t)2048 * 4 * m.H);      // one [4H] slab per workgroup of the column gather
     t.nsum = a.take<float>(4 * (size_t)m.H);
@@ -193,7 +193,9 @@ k_finalize_edge_grads(const float* __restrict__ gsum, PvsSlabLayout L, int H, in
         }
     }
     if (tid == 0) {
-        if (has_att && gr.att_b) gr.att_b[0] = gsum[L.ba];
+        // (softmax attention, has_att == 2: a softmax does not see a shift of its logits, so the gradient of the logit
+        // bias is zero IDENTICALLY; the sum of the per-edge logit gradients only leaves its rounding residue there)
+        if (has_att && gr.att_b) gr.att_b[0] = has_att == 2 ? 0.f : gsum[L.ba];
         if (has_gate && gr.edge_gate) gr.edge_gate[0] = gsum[L.gate];
     }
 }
@@ -684,8 +686,10 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
                                      N, H, 1.f, w.dslabs, false));
     const int node_blocks = node_slabs.slabs ? (node_slabs.width + 31) / 32 : 0;
     k_finalize_edge_grads<<<node_blocks + (H * H / 256 > 4 ? H * H / 256 : 4), 256, 0, s>>>(
-        w.gsum, L, H, m.A, m.ld1, m.off_rho, gr, coord_bwd ? 1 : 0, eatt ? 1 : 0,
+        w.gsum, L, H, m.A, m.ld1, m.off_rho, gr, coord_bwd ? 1 : 0, eatt ? (soft ? 2 : 1) : 0,
         (eres && (F & (PVS_REZERO | PVS_GATED_RESIDUAL))) ? 1 : 0, node_gsum, node_out, node_slabs, node_blocks);
     PVS_CHECK_LAUNCH();
+    // GraphNorm: node_mlp.0.bias from the closed form of k_gn_bwd_coefs instead of the column sum of g_y1
+    if (gn && gr.node_b1) PVS_TRY(pvs_copy_small(s, w.coefs + 3 * H, gr.node_b1, H));
     return 0;
 }

@@ -25,7 +25,8 @@ int pvs_node_out_bwd(hipStream_t s, int H, const float* g_hout, const float* o, 
 // g_yn = g_u * SiLU'(yn)
 int pvs_node_tail_bwd1(hipStream_t s, const float* g_u, const float* y1, const float* stats,
                        const PvsNodeW& w, int N, int H, float* g_yn);
-// graphnorm backward: S1 = sum g_yn, S2 = sum g_yn*y1 (both [H]) -> param grads + coefs[3H]
+// graphnorm backward: S1 = sum g_yn, S2 = sum g_yn*y1 (both [H]) -> param grads + coefs[4H]
+// (coefs[3H..4H) = the gradient of the bias in front of the norm in closed form)
 int pvs_graphnorm_bwd_coefs(hipStream_t s, const float* S1, const float* S2, const float* stats,
                             const PvsNodeW& w, int N, int H, float* g_w, float* g_b, float* g_ms,
                             float* coefs);
@@ -37,4 +38,5 @@ int pvs_prep_edge_bwd(hipStream_t s, const float* g_x_out, const float* inv_deg,
                       const float* gM, int N, int H, float* gxagg, float* softD, float* zero_gPQ,
                       float* zero_gx_row);
 // out[0] = sum_i v[i]
+int pvs_copy_small(hipStream_t s, const float* src, float* dst, int n);
 int pvs_sum_vec(hipStream_t s, const float* v, int n, float* out);

@@ -266,6 +266,16 @@ __global__ void k_gn_bwd_coefs(const float* S1, const float* S2raw, const float*
     coefs[c] = gw * rstd;
     coefs[H + c] = 2.0f * g_var / (float)N;
     coefs[2 * H + c] = g_mean / (float)N;
+    // The gradient of the bias in front of the norm (node_mlp.0.bias) = sum_n g_y1[n] in closed form: the three terms of
+    // k_node_tail_bwd2 summed over the nodes are  gw rstd s1 + (2 g_var / N) sum_cc + g_mean = sum_gc (1 - ms).  At the
+    // initial mean_scale = 1 it is zero IDENTICALLY (the norm removes any shift of its input); the column sum of N
+    // rounded g_y1 values leaves 1e-6 of their magnitude there instead (round 4: strict per-tensor parity).
+    coefs[3 * H + c] = sum_gc * (1.0f - ms);
+}
+
+__global__ void k_copy_small(const float* __restrict__ src, float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
 }
 
 __global__ void k_node_tail_bwd2(const float* __restrict__ g_yn, const float* __restrict__ y1,
@@ -414,6 +424,12 @@ int pvs_prep_edge_bwd(hipStream_t s, const float* g_x_out, const float* inv_deg,
     const long long threads = (long long)N * (H / 4);
     k_prep_edge_bwd<<<(int)((threads + 255) / 256), 256, 0, s>>>(g_x_out, inv_deg, Magg, gM, N, H, gxagg, softD,
                                                                  zero_gPQ, zero_gx_row);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+int pvs_copy_small(hipStream_t s, const float* src, float* dst, int n) {
+    k_copy_small<<<(n + 255) / 256, 256, 0, s>>>(src, dst, n);
     PVS_CHECK_LAUNCH();
     return 0;
 }

@@ -28,3 +28,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Keep the strict-parity margins of a GPU session (copied to profiles/rNN_parity_margins.txt)."""
+    try:
+        from tests._golden import margins_report
+        text = margins_report()
+        if text:
+            out = ROOT / 'gpurun_out'
+            out.mkdir(exist_ok=True)
+            (out / 'parity_margins.txt').write_text(text)
+    except Exception as exc:   # a report must never turn a green session red
+        print(f'parity margins not written: {exc}')

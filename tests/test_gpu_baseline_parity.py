@@ -5,6 +5,9 @@ Bound (measured there on exactly this shape): per tensor
     err(gpu32 vs oracle64) <= max(1e-5, 2 * err(oracle32 vs oracle64)),   err = max|a-b| / max(1, max|b|)
 i.e. the relative 1e-5 of BASELINE.json, or twice the reference's own fp32 noise where a tensor's
 fp32 evaluation is itself further than that from the fp64 value (activations reach 1e3 at random init).
+Since round 4 every per-layer tensor and every gradient is ALSO held to the strict per-tensor form of
+tests/_golden.py (no max(1, .): a 5e-8 gradient tensor is compared at its own magnitude):
+    max|gpu - ref64| <= 1e-5 * max|ref64| + 4 * max|oracle32 - ref64| + 1e-12 * largest gradient.
 
   cfg2  one graph of configs[1]: 2000 atoms, r = 10 A (E ~ 3.2e5), 3 layers, 32 channels
   cfg3  one graph of configs[2]: r = 6 A, 12 layers, 64 channels, edge + node attention
@@ -17,7 +20,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests._golden import rel_err
+from tests._golden import CaseLog, assert_strict, grad_floor, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -65,9 +68,11 @@ def test_baseline_graph_matches_fp64_oracle(cfg_name, graph_id):
     trace = {}
     with torch.no_grad():
         model.embed_prepared(pg, feats, coords, trace=trace)
+    log = CaseLog(f'{cfg_name}_graph{graph_id}')
     for name, ref64 in t64.items():
         got = trace[name].detach().cpu().numpy()
         assert rel_err(got, ref64) <= _bound(t32[name], ref64), f'{cfg_name} {name}'
+        assert_strict(got, ref64, t32[name], f'{log.case} {name}', log=log)
 
     model.zero_grad()
     y_pred, _, _, _ = model.unpack_input_data_and_predict(gd)
@@ -75,12 +80,15 @@ def test_baseline_graph_matches_fp64_oracle(cfg_name, graph_id):
     loss = model.get_loss(y_true.cuda(), y_pred)
     assert abs(float(loss.detach()) - loss64) <= max(TOL, 2 * abs(loss32 - loss64)) * max(1.0, abs(loss64))
     loss.backward()
+    floor = grad_floor(g64)
     for pname, p in model.named_parameters():
         if p.grad is None:
             assert g64[pname] is None, pname
             continue
         got = p.grad.detach().cpu().numpy()
         assert rel_err(got, g64[pname]) <= _bound(g32[pname], g64[pname]), f'{cfg_name} grad {pname}'
+        assert_strict(got, g64[pname], g32[pname], f'{log.case} grad {pname}', floor=floor, log=log)
+    log.finish()
 
 
 def test_baseline_batch_gradients_are_the_mean_of_per_graph_oracle_gradients():
@@ -106,11 +114,15 @@ def test_baseline_batch_gradients_are_the_mean_of_per_graph_oracle_gradients():
     y_pred, y_true, _, _ = model.unpack_input_data_and_predict(gb)
     model.get_loss(y_true.cuda(), y_pred).backward()
     assert rel_err(y_pred.detach().cpu().numpy(), np.concatenate(logits64)) <= TOL
+    log, floor = CaseLog('cfg2_batch4'), grad_floor(mean64)
     for pname, p in model.named_parameters():
         if p.grad is None:
             assert pname not in mean64, pname
             continue
         assert rel_err(p.grad.detach().cpu().numpy(), mean64[pname]) <= _bound(mean32[pname], mean64[pname]), pname
+        assert_strict(p.grad.detach().cpu().numpy(), mean64[pname], mean32[pname], f'{log.case} grad {pname}',
+                      floor=floor, log=log)
+    log.finish()
 
 
 @pytest.mark.parametrize('flags', [dict(), dict(edge_attention=True, node_attention=True)])
