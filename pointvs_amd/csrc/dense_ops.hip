@@ -838,31 +838,36 @@ constexpr int kWgProducts = PVS_WG_PRODUCTS, kWgBias = PVS_WG_BIAS;
 constexpr int kWgSlab = PVS_WG_SLAB;   // floats per (row block, sub-block)
 constexpr int kWgRowsPerBlock = 256;
 
-template <int HB>
+// GH: the g_h product role is compiled in (H = 32). At H = 64 that role needs 208 registers - two waves per SIMD for
+// the WHOLE kernel, half of the weight-gradient row blocks waiting for a slot - so there it is a launch of its own.
+template <int HB, bool GH>
 __global__ void __launch_bounds__(kThreads)
 k_node_wgrads(float* __restrict__ slabs, PvsNodeWgradIn in, int N, int row_blocks, PvsReduce2Args extra,
               PvsGhJob gh) {
     constexpr int H = 32 * HB;
     // (sized for the product role's weights: 32 HB (64 HB + 1) + 32 HB floats at HB = 2)
-    constexpr int kRedWords = kWgSlab > H * (2 * H + 1) + H ? kWgSlab : H * (2 * H + 1) + H;
+    constexpr int kRedWords = (!GH || kWgSlab > H * (2 * H + 1) + H) ? kWgSlab : H * (2 * H + 1) + H;
     __shared__ __attribute__((aligned(16))) float red[kRedWords];
-    if ((int)blockIdx.x >= row_blocks) {
-        // the workgroups behind the row blocks carry the two other jobs of this point of a layer's backward, both
-        // independent of the weight gradients: the edge-slab reduction, and g_h += [gP | gQ] W1 (the product that the
-        // next layer's backward waits for)
+    // The first workgroups carry the two other jobs of this point of a layer's backward, both independent of the weight
+    // gradients: the edge-slab reduction, and g_h += [gP | gQ] W1 (the product that the next layer's backward waits
+    // for). FIRST in dispatch order (round 4): behind the row blocks they only started when those had drained - the
+    // launch took the SUM of the three jobs' times (cfg3: 81 + 14 + 31 us = 132 us per launch).
+    const int n_extra = extra.blocks() + (GH ? gh.blocks : 0);
+    if ((int)blockIdx.x < n_extra) {
         if (blockIdx.y != 0) return;
-        const int b = (int)blockIdx.x - row_blocks;
+        const int b = (int)blockIdx.x;
         if (b < extra.blocks()) { pvs_reduce2_block(extra, b, reinterpret_cast<float(*)[33]>(red)); return; }
-        if (gh.blocks > 0)
+        if constexpr (GH)
             linear_mfma_block<2 * HB, HB>(red, b - extra.blocks(), gh.blocks, gh.g_h, H, gh.gPQ, 2 * H, HB, gh.gPQ + H,
                                           2 * H, gh.W1, 1, gh.ld1, gh.W1 + gh.off_q, 1, gh.ld1, nullptr, N, 1, 0,
                                           nullptr, 0, nullptr, 0, PvsLinearExt{});
         return;
     }
+    const int rbi = (int)blockIdx.x - n_extra;          // row block
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 31, hh = lane >> 5;
     const int bo = blockIdx.y / HB, bi = blockIdx.y % HB;
-    const int r0 = blockIdx.x * kWgRowsPerBlock;
+    const int r0 = rbi * kWgRowsPerBlock;
     const int r1 = min(N, r0 + kWgRowsPerBlock);
     const float* A0 = in.g_o + 32 * bo + j;
     const float* A1 = in.g_y1 + 32 * bo + j;
@@ -880,40 +885,46 @@ k_node_wgrads(float* __restrict__ slabs, PvsNodeWgradIn in, int N, int row_block
     const bool gate_sums = in.t1 != nullptr && bi == 0;      // node gate: column sums of t1, sum of gl
     const float* T1 = in.t1 + 32 * bo + j;
     constexpr int UN = 4;
-    for (int n0 = r0 + wv * 2 * UN; n0 < r1; n0 += kThreads / 64 * 2 * UN) {
-        float a0[UN], a1[UN], a2[UN], a3[UN], b0[UN], b1[UN], b2[UN];
-        if (gate_sums) {
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int n = n0 + 2 * u + hh;
-                if (n < r1) {
-                    bs3 += T1[(size_t)n * H];
-                    if (bo == 0 && j == 0) bs4 += in.gl[n];
-                }
-            }
-        }
+    // Two operand buffers: the rows of step k + 1 are in flight while the products of step k issue (round 4). A wave
+    // used to run load - wait - 20 MFMAs eight times over, the whole HBM / L2 latency exposed every time: 81 us per
+    // launch at H = 64 for 2.6 GFLOP and 115 MB.
+    struct Rows { float a0[UN], a1[UN], a2[UN], a3[UN], b0[UN], b1[UN], b2[UN], t1[UN], gl[UN]; };
+    auto fetch = [&](int n0, Rows& R) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int n = n0 + 2 * u + hh;
             const bool ok = n < r1;
             const size_t nh = (size_t)n * H, n2h = (size_t)n * 2 * H;
-            a0[u] = ok ? A0[nh] : 0.f;
-            a1[u] = ok ? A1[nh] : 0.f;
-            a2[u] = ok ? A2[n2h] : 0.f;
-            a3[u] = ok ? A3[n2h] : 0.f;
-            b0[u] = ok ? B0[nh] : 0.f;
-            b1[u] = ok ? B1[nh] : 0.f;
-            b2[u] = ok ? B2[nh] : 0.f;
+            R.a0[u] = ok ? A0[nh] : 0.f;
+            R.a1[u] = ok ? A1[nh] : 0.f;
+            R.a2[u] = ok ? A2[n2h] : 0.f;
+            R.a3[u] = ok ? A3[n2h] : 0.f;
+            R.b0[u] = ok ? B0[nh] : 0.f;
+            R.b1[u] = ok ? B1[nh] : 0.f;
+            R.b2[u] = ok ? B2[nh] : 0.f;
+            R.t1[u] = (gate_sums && ok) ? T1[nh] : 0.f;
+            R.gl[u] = (gate_sums && ok && bo == 0 && j == 0) ? in.gl[n] : 0.f;
         }
+    };
+    auto products = [&](const Rows& R) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b2[u], acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[u], b1[u], acc[3], 0, 0, 0);
-            acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[u], b1[u], acc[4], 0, 0, 0);
-            bs0 += a0[u]; bs1 += a1[u]; bs2 += a2[u];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(R.a0[u], R.b0[u], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(R.a1[u], R.b1[u], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(R.a1[u], R.b2[u], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(R.a2[u], R.b1[u], acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(R.a3[u], R.b1[u], acc[4], 0, 0, 0);
+            bs0 += R.a0[u]; bs1 += R.a1[u]; bs2 += R.a2[u]; bs3 += R.t1[u]; bs4 += R.gl[u];
         }
+    };
+    constexpr int kStep = kThreads / 64 * 2 * UN;        // rows per step of the workgroup
+    Rows Ra, Rb;
+    fetch(r0 + wv * 2 * UN, Ra);
+    for (int n0 = r0 + wv * 2 * UN; n0 < r1; n0 += 2 * kStep) {      // (same row order as the single-buffer loop)
+        fetch(n0 + kStep, Rb);
+        products(Ra);
+        fetch(n0 + 2 * kStep, Ra);
+        products(Rb);
     }
     bs0 += __shfl_xor(bs0, 32, 64); bs1 += __shfl_xor(bs1, 32, 64); bs2 += __shfl_xor(bs2, 32, 64);
     bs3 += __shfl_xor(bs3, 32, 64); bs4 += __shfl_xor(bs4, 32, 64);
@@ -938,7 +949,7 @@ k_node_wgrads(float* __restrict__ slabs, PvsNodeWgradIn in, int N, int row_block
         }
         __syncthreads();
     }
-    float* dst = slabs + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * kWgSlab;
+    float* dst = slabs + ((size_t)rbi * gridDim.y + blockIdx.y) * kWgSlab;
     for (int i = threadIdx.x; i < kWgSlab; i += kThreads) dst[i] = red[i];
 }
 
@@ -1247,6 +1258,8 @@ int pvs_launch_tsgemm_tn(hipStream_t s, float* out, int ldo, const float* A, int
 
 int pvs_node_wgrads_supported(int H) { return H == 32 || H == 64; }
 
+#define PVS_TRY_RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
 static int wg_row_blocks(int N) { return (N + kWgRowsPerBlock - 1) / kWgRowsPerBlock; }
 
 size_t pvs_node_wgrads_slab_floats(int N, int H) {
@@ -1271,8 +1284,14 @@ int pvs_launch_node_wgrads(hipStream_t s, int H, int N, const PvsNodeWgradIn& in
         gh.blocks = (N + rows_m - 1) / rows_m;
         if (gh.blocks > 1024) gh.blocks = 1024;
     }
-    if (hb == 1) k_node_wgrads<1><<<dim3(rb + ex.blocks() + gh.blocks, 1), kThreads, 0, s>>>(slabs, in, N, rb, ex, gh);
-    else k_node_wgrads<2><<<dim3(rb + ex.blocks() + gh.blocks, 4), kThreads, 0, s>>>(slabs, in, N, rb, ex, gh);
+    if (hb == 1) {
+        k_node_wgrads<1, true><<<dim3(rb + ex.blocks() + gh.blocks, 1), kThreads, 0, s>>>(slabs, in, N, rb, ex, gh);
+    } else {
+        if (gh_job)     // (H = 64: the product as its own launch, see k_node_wgrads)
+            PVS_TRY_RC(pvs_launch_linear(s, gh.g_h, H, gh.gPQ, 2 * H, gh.W1, 1, gh.ld1, nullptr, gh.gPQ + H, 2 * H,
+                                         gh.W1 + gh.off_q, 1, gh.ld1, N, H, H, H, true));
+        k_node_wgrads<2, false><<<dim3(rb + ex.blocks(), 4), kThreads, 0, s>>>(slabs, in, N, rb, ex, gh);
+    }
     PVS_CHECK_LAUNCH();
     if (slabs_out) {
         slabs_out->slabs = slabs; slabs_out->n_slabs = rb; slabs_out->width = width;

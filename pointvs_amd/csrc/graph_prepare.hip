@@ -372,25 +372,28 @@ constexpr int kCscAhead = 8;              // steps of 64 positions whose columns
 
 struct CscChunk { int begin, end, node_lo, width, g; };
 
-__device__ __forceinline__ CscChunk csc_chunk(int wid, int cpg, int stride, int n_graphs,
+// The caller's edge_ptr / node_ptr are CLAMPED into [0, E] / [0, N] and made monotone here: k_extract_runs verifies the
+// layout on the device and sets status bit 4, but these passes run before the host reads the status word, and a
+// direct C-ABI caller may pass tables that do not even end at E. With consistent tables the clamps do nothing.
+__device__ __forceinline__ CscChunk csc_chunk(int wid, int cpg, int stride, int n_graphs, int N, int E,
                                               const int32_t* __restrict__ node_ptr,
                                               const int32_t* __restrict__ edge_ptr) {
     CscChunk c;
     c.g = wid / cpg;
     const int k = wid - c.g * cpg;
     if (c.g >= n_graphs) { c.begin = c.end = 0; c.node_lo = 0; c.width = 0; return c; }
-    const int e0 = edge_ptr[c.g], e1 = edge_ptr[c.g + 1];
+    const int e0 = min(max(edge_ptr[c.g], 0), E), e1 = min(max(edge_ptr[c.g + 1], e0), E);
     const int len = (((e1 - e0) + cpg - 1) / cpg + 63) & ~63;
     c.begin = min(e0 + k * len, e1);
     c.end = min(c.begin + len, e1);
-    c.node_lo = node_ptr[c.g];
-    c.width = node_ptr[c.g + 1] - c.node_lo;      // (the caller clamps it to the table and flags a graph that does not fit)
+    c.node_lo = min(max(node_ptr[c.g], 0), N);
+    c.width = min(max(node_ptr[c.g + 1], c.node_lo), N) - c.node_lo;   // (the caller clamps it to the table and flags a graph that does not fit)
     return c;
 }
 
 template <bool PLACE>
 __global__ void __launch_bounds__(64 * kCscWaves)
-k_csc_pass(const int32_t* __restrict__ col, int n_graphs, const int32_t* __restrict__ node_ptr,
+k_csc_pass(const int32_t* __restrict__ col, int n_graphs, int N, int E, const int32_t* __restrict__ node_ptr,
            const int32_t* __restrict__ edge_ptr, int cpg, int stride, int32_t* __restrict__ cnt,
            int32_t* __restrict__ cedge, int32_t* __restrict__ status) {
     extern __shared__ int32_t csc_lds[];
@@ -403,12 +406,16 @@ k_csc_pass(const int32_t* __restrict__ col, int n_graphs, const int32_t* __restr
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int g_of_block = (j / bpg) * 8 + xcd;
     const int wid = g_of_block * cpg + (j % bpg) * kCscWaves + wv;
-    CscChunk c = csc_chunk(g_of_block < n_graphs ? wid : n_graphs * cpg, cpg, stride, n_graphs, node_ptr, edge_ptr);
+    CscChunk c = csc_chunk(g_of_block < n_graphs ? wid : n_graphs * cpg, cpg, stride, n_graphs, N, E, node_ptr, edge_ptr);
     if (c.width > stride) {        // a graph larger than the caller's bound: contract violation, stay inside the table
         if (lane == 0) atomicOr(status, 4);
         c.width = stride;
     }
     if (c.width <= 0) return;
+    if (PLACE && (*status & 4)) {      // broken contract: identity lists over the (clamped) chunk, colptr is all zeros
+        for (int p = c.begin + lane; p < c.end; p += 64) cedge[p] = p;
+        return;
+    }
     int32_t* tab = csc_lds + wv * (stride + stride / 4);
     unsigned char* tag = reinterpret_cast<unsigned char*>(tab + stride);
     int32_t* mine = cnt + (size_t)wid * stride;
@@ -465,7 +472,7 @@ k_csc_pass(const int32_t* __restrict__ col, int n_graphs, const int32_t* __restr
                 tab[key] = slot + members;
             }
             slot = __shfl(slot, leader, 64) + rank;
-            if (live) cedge[slot] = p;
+            if (live) cedge[min(max(slot, 0), E - 1)] = p;       // (a slot outside [0, E) only under status bit 4)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -489,15 +496,17 @@ __device__ __forceinline__ int csc_graph_of_node(const int32_t* __restrict__ nod
 }
 
 // indeg[n] = edges whose column is n (sum over the chunks of n's graph); indeg[N] = 0
+// (status bit 4 - a broken layout contract, final since k_extract_runs: every in-degree is 0, so colptr is all zeros
+// and nothing downstream follows cedge; the host raises at its next poll of the status word)
 __global__ void k_csc_totals(const int32_t* __restrict__ cnt, int N, int n_graphs, const int32_t* __restrict__ node_ptr,
-                             int cpg, int stride, int32_t* __restrict__ indeg) {
+                             int cpg, int stride, int32_t* __restrict__ indeg, const int32_t* __restrict__ status) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n > N) return;
-    if (n == N) { indeg[N] = 0; return; }
+    if (n == N || (*status & 4)) { indeg[n] = 0; return; }
     const int g = csc_graph_of_node(node_ptr, n_graphs, n);
     const int c = n - node_ptr[g];
     int t0 = 0, t1 = 0, t2 = 0, t3 = 0;          // (cpg is a multiple of 4: independent loads in flight)
-    if (c < stride) {
+    if (c >= 0 && c < stride) {                  // (c < 0: node_ptr[0] > n, a broken table - status bit 4)
         const int32_t* src = cnt + (size_t)g * cpg * stride + c;
         for (int k = 0; k < cpg; k += 4) {
             t0 += src[(size_t)k * stride];
@@ -516,7 +525,7 @@ __global__ void k_csc_bases(int32_t* __restrict__ cnt, int N, int n_graphs, cons
     if (n >= N) return;
     const int g = csc_graph_of_node(node_ptr, n_graphs, n);
     const int c = n - node_ptr[g];
-    if (c >= stride) return;
+    if (c < 0 || c >= stride) return;
     int run = colptr[n];
     for (int k = 0; k < cpg; ++k) {
         int32_t* slot = cnt + ((size_t)g * cpg + k) * stride + c;
@@ -637,20 +646,20 @@ extern "C" int pvs_graph_prepare_runs(const int64_t* edge_index, const int64_t* 
             PVS_CHECK_HIP(hipFuncSetAttribute((const void*)k_csc_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
         if (E > 0) {
-            k_csc_pass<false><<<blocks, 64 * kCscWaves, lds, stream>>>(col, n_graphs, node_ptr, edge_ptr, cpg, stride,
+            k_csc_pass<false><<<blocks, 64 * kCscWaves, lds, stream>>>(col, n_graphs, N, E, node_ptr, edge_ptr, cpg, stride,
                                                                         w.csc_cnt, nullptr, status);
             PVS_CHECK_LAUNCH();
         } else {
             PVS_CHECK_HIP(hipMemsetAsync(w.csc_cnt, 0, (size_t)waves * stride * sizeof(int32_t), stream));
         }
-        k_csc_totals<<<(N + 1 + T - 1) / T, T, 0, stream>>>(w.csc_cnt, N, n_graphs, node_ptr, cpg, stride, w.indeg);
+        k_csc_totals<<<(N + 1 + T - 1) / T, T, 0, stream>>>(w.csc_cnt, N, n_graphs, node_ptr, cpg, stride, w.indeg, status);
         PVS_CHECK_LAUNCH();
         sb = w.scan_bytes;
         PVS_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(w.scan_tmp, sb, w.indeg, colptr, N + 1, stream));
         if (E > 0) {
             k_csc_bases<<<(N + T - 1) / T, T, 0, stream>>>(w.csc_cnt, N, n_graphs, node_ptr, cpg, stride, colptr);
             PVS_CHECK_LAUNCH();
-            k_csc_pass<true><<<blocks, 64 * kCscWaves, lds, stream>>>(col, n_graphs, node_ptr, edge_ptr, cpg, stride,
+            k_csc_pass<true><<<blocks, 64 * kCscWaves, lds, stream>>>(col, n_graphs, N, E, node_ptr, edge_ptr, cpg, stride,
                                                                        w.csc_cnt, cedge, status);
             PVS_CHECK_LAUNCH();
         }

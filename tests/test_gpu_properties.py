@@ -1140,3 +1140,47 @@ def test_dynamic_range_inside_one_graph(hid, flags, log2_range):
         assert p99 <= 4 * p9932 + 2e-6, (tensor, 'p99', p99, p9932)
         worst = 64 if tensor == 'g_h_wide_input' else 16 if (tensor == 'h_out' and att) else 4
         assert mx <= worst * mx32 + (1e-5 if tensor == 'g_h_wide_input' else 2e-6), (tensor, 'max', mx, mx32)
+
+
+@pytest.mark.parametrize('breakage', ['edge_ptr_short', 'edge_ptr_past_end', 'edge_ptr_not_monotone', 'node_ptr_shifted',
+                                      'node_ptr_negative'])
+def test_counting_transpose_stays_in_bounds_on_broken_layout_tables(breakage):
+    """the by-column counting transpose of pvs_graph_prepare_runs used the caller's edge_ptr /
+    node_ptr unclamped, so a DIRECT C-ABI caller with inconsistent tables (Python's runs_layout validates them on the
+    host) could make it read col / write cedge out of bounds before the host sees status bit 4. Here the tables are
+    corrupted behind runs_layout's back, with max_graph_nodes > 0 (the counting path) and with the allocator's caching
+    off, so that every output is its own allocation and an access outside it faults: the call must complete, set
+    status bit 4 (check_status raises) and leave colptr monotone inside [0, E] with every list entry inside [0, E)."""
+    from pointvs_amd.graph import Batch, prepare_graph, runs_layout
+    from pointvs_amd.synthetic import synthetic_graph
+    items = [synthetic_graph(300 + k, n_nodes=n, n_lig=8, edge_radius=6.0) for k, n in enumerate((200, 90, 310))]
+    batch = Batch.from_data_list(items).to('cuda')
+    node_ptr, edge_ptr = runs_layout(batch)
+    n, e = int(batch.x.shape[0]), int(batch.edge_index.shape[1])
+    node_ptr, edge_ptr = node_ptr.clone(), edge_ptr.clone()
+    if breakage == 'edge_ptr_short':
+        edge_ptr[-1] = e - 1000
+    elif breakage == 'edge_ptr_past_end':
+        edge_ptr[-1] = e + 100000
+        edge_ptr[2] = e + 5000
+    elif breakage == 'edge_ptr_not_monotone':
+        edge_ptr[1], edge_ptr[2] = edge_ptr[2].item(), edge_ptr[1].item()
+    elif breakage == 'node_ptr_shifted':
+        node_ptr[0] = 50
+        node_ptr[2] = n + 400
+    else:
+        node_ptr[1] = -7
+    node_ptr.max_graph_nodes = 310
+    pg = prepare_graph(batch.edge_index, batch.edge_attr, n, need_backward=True, layout=(node_ptr, edge_ptr))
+    torch.cuda.synchronize()                      # (an out-of-bounds access would surface here as a GPU fault)
+    with pytest.raises(ValueError):
+        pg.check_status()
+    colptr, cedge = pg.t['colptr'].cpu().numpy(), pg.t['cedge'].cpu().numpy()
+    assert colptr[0] >= 0 and colptr[-1] <= e and np.all(np.diff(colptr) >= 0)
+    used = cedge[:colptr[-1]]
+    assert used.size == 0 or (used.min() >= 0 and used.max() < e)
+    for name in ('row', 'col'):
+        v = pg.t[name].cpu().numpy()
+        assert v.min() >= 0 and v.max() < n, name
+    rowptr = pg.t['rowptr'].cpu().numpy()
+    assert rowptr[0] >= 0 and rowptr[-1] <= e and np.all(np.diff(rowptr) >= 0)
