@@ -173,8 +173,8 @@ class PointNeuralNetworkBase(nn.Module):
                 self.p_epoch += 1
             if not self.only_save_best_models:
                 self.save()
-            if epoch_end_validation_set is not None:
-                done = self.a_epoch if 'regression' in self.model_task else self.p_epoch
+            done = self.a_epoch if 'regression' in self.model_task else self.p_epoch
+            if epoch_end_validation_set is not None and done < epochs:     # (:481: not after the last epoch)
                 fname = Path(self.predictions_file.parent, f'predictions_epoch_{done}.txt')
                 best = self.val(epoch_end_validation_set, predictions_file=fname, top1_on_end=top1_on_end)
                 if self.only_save_best_models and best:

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Reference-generated TRAINING TRAJECTORIES for the harness row.
+
+Build container only (needs /root/reference; same import-only stand-ins as make_golden.py). Drives the
+reference's own `train_model` (point_neural_network_base.py:136-205, backprop :417-429, training_setup
+:372-388, on_epoch_end :470-490, save :501-517) on a FIXED list of batches (the weighted sampler is
+bypassed: a plain list of collated batches stands in for the DataLoader) and records, per schedule:
+
+    default           SartorrasEGNN, Adam lr 2e-3 wd 1e-4, 3 epochs x 4 batches
+    one_cycle         the same with use_1cycle=True        (OneCycleLR over all 12 steps)
+    warm_restarts     the same with warm_restarts=True     (CosineAnnealingWarmRestarts, T_0 = 4)
+    multitask         MultitaskSatorrasEGNN: set_task('classification'), 2 epochs x 4 pose batches, then
+                      set_task('regression'), 1 epoch x 4 affinity batches (point_vs.py:258-270)
+
+per step: the loss `backprop()` returned and the learning rate the step ran at; at the end: the
+`state_dict`, the epoch counters, the checkpoint file names and the keys of a checkpoint dict.
+Output: tests/golden/train_<schedule>.npz (data only).
+"""
+import json
+import sys
+import tempfile
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+import make_golden as mg  # noqa: E402  (sets up the stubs, sys.path and cwd; defines the graph builders)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from point_vs.models.geometric.egnn_multitask import MultitaskSatorrasEGNN  # noqa: E402
+from point_vs.models.geometric.egnn_satorras import SartorrasEGNN  # noqa: E402
+from torch_geometric.data import Batch  # noqa: E402  (stub)
+
+
+class ListLoader(list):
+    """What train_model needs of a DataLoader: len(), iteration, .batch_size. Every pass yields fresh copies, as a
+    DataLoader does: the reference's layers update `graph.pos` IN PLACE, which ties a batch object to the
+    autograd graph of the step that used it."""
+    batch_size = 3
+
+    def __iter__(self):
+        for b in list.__iter__(self):
+            yield mg.clone_graph(b)
+
+
+def batches(seed0, regression=False):
+    out = ListLoader()
+    for b in range(4):
+        items = [mg.synthetic_ball_graph(n, nl, 5.0, seed=seed0 + 10 * b + k)
+                 for k, (n, nl) in enumerate(((44, 6), (36, 5), (52, 7)))]
+        batch = Batch.from_data_list(items)
+        if regression:
+            batch.y = torch.tensor([6.5, 4.75, 8.0]) + 0.25 * b
+        else:
+            batch.y = torch.tensor([1, 0, 1]) if b % 2 == 0 else torch.tensor([0, 1, 0])
+        out.append(batch)
+    return out
+
+
+KW = {'dim_input': 12, 'k': 32, 'dim_output': 1, 'num_layers': 2, 'residual': True, 'edge_residual': False,
+      'edge_attention': True, 'normalize': False, 'tanh': True, 'dropout': 0.0, 'graphnorm': False,
+      'update_coords': True, 'permutation_invariance': False, 'node_attention': False, 'gated_residual': False,
+      'rezero': False, 'softmax_attention': False, 'model_task': 'classification'}
+
+
+def record_training(model, phases):
+    """phases: [(task, loader, epochs)]. Returns the per-step records."""
+    steps = []
+    real_backprop = model.backprop
+
+    def backprop(y_true, y_pred):
+        lr = model.optimiser.param_groups[0]['lr']
+        loss = real_backprop(y_true, y_pred)
+        steps.append((model.model_task, float(loss), float(lr)))
+        return loss
+    model.backprop = backprop
+    model.eta = '0'                      # (train_model reads it for the wandb record)
+    for task, loader, epochs in phases:
+        model.set_task(task)
+        model.train_model(loader, epochs=epochs)
+    return steps
+
+
+def run(name, cls, ctor_kwargs, phases, seed=7):
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    with tempfile.TemporaryDirectory() as tmp:
+        model = cls(Path(tmp), 2e-3, 1e-4, None, None, silent=True, **ctor_kwargs, **KW)
+        sd0 = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
+        steps = record_training(model, phases)
+        ckpts = sorted(str(p.relative_to(tmp)) for p in Path(tmp).rglob('*.pt'))
+        ck = torch.load(Path(tmp) / ckpts[-1], map_location='cpu', weights_only=False)
+        ckpt_keys = sorted(ck.keys())
+        opt_steps = sorted({int(s['step']) for s in ck['optimiser_state_dict']['state'].values()})
+    out = {'meta': np.array(json.dumps({
+        'name': name, 'class': cls.__name__, 'kwargs': KW, 'ctor': ctor_kwargs, 'seed': seed, 'lr': 2e-3, 'wd': 1e-4,
+        'phases': [(t, len(l), e) for t, l, e in phases], 'tasks': [s[0] for s in steps],
+        'p_epoch': model.p_epoch, 'a_epoch': model.a_epoch, 'global_iter': model.global_iter,
+        'checkpoints': ckpts, 'checkpoint_keys': ckpt_keys, 'optimiser_steps_in_last_checkpoint': opt_steps})),
+        'loss': np.array([s[1] for s in steps], dtype=np.float64),
+        'lr': np.array([s[2] for s in steps], dtype=np.float64)}
+    for k, v in sd0.items():
+        out[f'sd0/{k}'] = v
+    for k, v in model.state_dict().items():
+        out[f'sd1/{k}'] = v.detach().numpy()
+    # the batches (inputs): every loader's batches, in order
+    for pi, (_, loader, _) in enumerate(phases):
+        for bi, b in enumerate(list.__iter__(loader)):
+            pre = f'in/p{pi}b{bi}/'
+            out[pre + 'x'] = b.x.numpy().astype(np.float32)
+            out[pre + 'pos'] = b.pos.numpy().astype(np.float32)
+            out[pre + 'edge_index'] = b.edge_index.numpy().astype(np.int32)
+            out[pre + 'edge_type'] = b.edge_attr.argmax(1).numpy().astype(np.uint8)
+            out[pre + 'batch'] = b.batch.numpy().astype(np.int32)
+            out[pre + 'y'] = b.y.numpy().astype(np.float32)
+    path = HERE / f'train_{name}.npz'
+    np.savez_compressed(path, **out)
+    print(f'{name:14s} steps={len(steps)} loss {steps[0][1]:.6f} -> {steps[-1][1]:.6f}  lr {steps[0][2]:.3e} .. '
+          f'{max(s[2] for s in steps):.3e}  ckpts={ckpts}  {path.stat().st_size / 1024:.0f} KiB')
+
+
+def main():
+    pose = batches(100)
+    run('default', SartorrasEGNN, {}, [('classification', pose, 3)])
+    run('one_cycle', SartorrasEGNN, {'use_1cycle': True}, [('classification', batches(100), 3)])
+    run('warm_restarts', SartorrasEGNN, {'warm_restarts': True}, [('classification', batches(100), 3)])
+    run('multitask', MultitaskSatorrasEGNN, {},
+        [('classification', batches(100), 2), ('regression', batches(500, regression=True), 1)])
+
+
+if __name__ == '__main__':
+    main()
