@@ -53,10 +53,12 @@ FP32_PEAK_TFLOPS = 157.3   # fp32 vector = fp32 MFMA peak
 # under a per-tile power-of-two scale and three partial products (O(2^-22 |a||b|), between bf16x3 and a sequential
 # fp32 FMA chain: tools/f16x2_numerics.py) - accumulated in fp32; parity at 1e-5 relative against the fp64 oracle
 # at BASELINE size is part of the GPU suite
-ARITHMETIC = ('fp32 I/O, accumulation and elementwise work; per-edge matrix products on the matrix cores with fp32 '
-              'accumulation and fp32-exact operand splits (no fp32 MFMA, no reduced-precision storage): H=32 forward and '
-              'backward and H=64 forward as 3-term fp16 splits (two fp16 parts per operand, 22 bits, one power-of-two '
-              'scale per 32-edge tile), H=64 backward and the node-level products as 6-term bf16x3 splits')
+ARITHMETIC = ('fp32 I/O, accumulation and elementwise work; no reduced-precision storage. Per-edge matrix products on the '
+              'matrix cores with fp32 accumulation: H=32 forward and backward and H=64 forward as 3-term fp16 products '
+              '(two fp16 parts per operand = 22 bits, power-of-two operand scales: per EDGE in the forward, per 32-edge '
+              'tile in the backward, where an element 2^-k below its tile\'s largest keeps 22 - max(0, k - 16) bits: '
+              'absolute error 2^-38 of the tile maximum), H=64 backward as 6-term bf16 products (three bf16 parts = 24 '
+              'bits, no scales); node-level products (N << E) on exact fp32 MFMAs')
 
 
 def scaling_note(args, world, strong):
@@ -129,6 +131,24 @@ def measured_traffic(config, kernel):
             if name.startswith(kernel) and rec.get('hbm_bytes_per_launch'):
                 return rec['hbm_bytes_per_launch'], tfile.name
     return None, None
+
+
+def measured_limiter(config, kernel):
+    """What the dominant kernel waits for, from the newest SQ counter summary of the same command
+    (tools/pmc_sq.sh + tools/pmc_summary.py -> profiles/rNN_<config>_pmc_sq.txt; like `traffic`, a PMC pass cannot run
+    inside this process): VALU busy and matrix-pipe busy as fractions of SIMD time, the share of a wave's cycles spent
+    in s_waitcnt. `bound: "hbm"` and `frac` keep SURVEY 8d's definition; these fields say what actually binds."""
+    import re
+    for pfile in sorted((ROOT / 'profiles').glob(f'r[0-9][0-9]_{config}_pmc_sq.txt'), reverse=True):
+        for line in pfile.read_text().splitlines():
+            if line.strip().startswith(kernel) and 'VALU busy' in line:
+                m = re.search(r'VALU busy (\d+)% of SIMD time, matrix pipe (\d+)%.*?issuing (\d+)%, issue-stalled (\d+)%, '
+                              r'in s_waitcnt (\d+)%', line)
+                if m:
+                    valu, mat, issuing, stalled, wait = (int(g) / 100.0 for g in m.groups())
+                    return {'limiter': 'valu_issue+wave_stalls', 'valu_busy': valu, 'matrix_busy': mat,
+                            'waitcnt_share': wait, 'issue_stalled_share': stalled, 'limiter_source': pfile.name}
+    return {'limiter': None, 'valu_busy': None, 'matrix_busy': None, 'waitcnt_share': None, 'limiter_source': None}
 
 
 def visible_gpu_count(topology='/sys/class/kfd/kfd/topology/nodes'):
@@ -457,7 +477,11 @@ def main():
     if distributed:
         if world == 1:      # --force-dist: a group of one, rendezvous on the loopback
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            os.environ.setdefault('MASTER_PORT', '29533')
+            if 'MASTER_PORT' not in os.environ:      # a free port, as self_launch() picks one (two smoke runs on one box)
+                import socket
+                with socket.socket() as sock:
+                    sock.bind(('127.0.0.1', 0))
+                    os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
             os.environ.setdefault('RANK', '0')
             os.environ.setdefault('WORLD_SIZE', '1')
         if backend == 'nccl':
@@ -663,6 +687,7 @@ def main():
                 'bound': 'hbm', 'kernel': dom_name,
                 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
+                **measured_limiter(args.config, dom_symbol),
                 'algorithmic_bytes_per_launch': dom_bytes,
                 'avg_launch_ms': round(dom_avg_ms, 4), 'launches': dom_n,
                 # the kernel is ALU-bound, not HBM-bound: its EXECUTED products against the
