@@ -114,7 +114,10 @@ struct F16Cfg {
 };
 
 // ERK: edge residual kind - 0 none; 1 the plain sum m + m_prev (nothing of the residual has to survive the tile's
-// coordinate branch); 2 rezero / gated (the gate's gradient needs the pre-residual message and m_prev at the end).
+// coordinate branch); 2 rezero (the gate's gradient needs the pre-residual message at the end); 3 gated (... and m_prev);
+// 4 rezero or gated by the run-time flags (every kind >= 2 before round 4). Compile-time kinds took rezero from 18 / 31
+// spilled VGPRs (without / with edge attention) to 2 / 9 and -11 % / -19 % per launch, gated + attention from 31 to 26 and
+// -4 %; gated without attention is faster the old way (profiles/r04_variants_gated_rezero.txt).
 template <int ERK, bool EATT>
 __global__ void __launch_bounds__(F16Cfg::kThreadsPerBlock, 2)
 k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks, int e_lo, int e_hi) {
@@ -176,12 +179,17 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 
     const float bac = EATT ? w.ba[0] : 0.f;
     float gate_raw = 0.f, gate = 1.f;
-    if (ERK == 2 && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
+    // (kind 4: the kind is read from the flags at run time, as all of them were before round 4 - the same source)
+    if (ERK == 4 && (flags & (PVS_REZERO | PVS_GATED_RESIDUAL))) {
         gate_raw = w.edge_gate[0];
         gate = (flags & PVS_GATED_RESIDUAL) ? fmaxf(gate_raw, 0.f) : gate_raw;
     }
-    const float res_a = (flags & (PVS_REZERO | PVS_GATED_RESIDUAL)) ? gate : 1.f;
-    const float res_b = (flags & PVS_GATED_RESIDUAL) ? 1.f - gate : 1.f;
+    if constexpr (ERK == 2 || ERK == 3) {
+        gate_raw = w.edge_gate[0];
+        gate = ERK == 3 ? fmaxf(gate_raw, 0.f) : gate_raw;
+    }
+    const float res_a = ERK == 4 ? ((flags & (PVS_REZERO | PVS_GATED_RESIDUAL)) ? gate : 1.f) : (ERK >= 2 ? gate : 1.f);
+    const float res_b = ERK == 4 ? ((flags & PVS_GATED_RESIDUAL) ? 1.f - gate : 1.f) : (ERK == 3 ? 1.f - gate : 1.f);
 
     // ---- accumulators that live for the whole kernel ----
     f32x16 gW2, gWc1;                          // D layout: [c = ch(r,hh)][k = j]
@@ -297,19 +305,19 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 for (int r = 0; r < 16; ++r) z2[r] = fmaf(acc2[r], k2, bias[0][r]);
             }
             float dz2[16], m[1][16];          // SiLU'(z2) and the message
-            float m_new[ERK == 2 ? 16 : 1], mp[1][16];
+            float m_new[ERK >= 2 ? 16 : 1], mp[1][16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float sg = pvs_sigmoid(z2[r]);
                 m[0][r] = z2[r] * sg;
                 dz2[r] = fmaf(m[0][r], 1.0f - sg, sg);
-                if constexpr (ERK == 2) m_new[r] = m[0][r];
+                if constexpr (ERK >= 2) m_new[r] = m[0][r];
             }
             if constexpr (ERES) {
                 load_x<1>(io.m_prev + (size_t)ee * H, hh, mp);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    if constexpr (ERK == 2) m[0][r] = fmaf(res_a, m_new[r], res_b * mp[0][r]);
+                    if constexpr (ERK >= 2) m[0][r] = fmaf(res_a, m_new[r], res_b * mp[0][r]);
                     else m[0][r] += mp[0][r];
                 }
             }
@@ -436,7 +444,17 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 const float gmv = gm[r];
                 float gnew = gmv;
                 if constexpr (ERK == 1) mp[0][r] = gmv;      // (plain sum: m_prev receives g_m as it is)
-                if constexpr (ERK == 2) {
+                if constexpr (ERK == 2) {           // rezero: m = m_prev + g m_new
+                    gnew = gate * gmv;
+                    g_gate = fmaf(gmv, m_new[r], g_gate);
+                    mp[0][r] = gmv;
+                }
+                if constexpr (ERK == 3) {           // gated: m = relu(g) m_new + (1 - relu(g)) m_prev
+                    gnew = gate * gmv;
+                    if (gate_raw > 0.f) g_gate = fmaf(gmv, m_new[r] - mp[0][r], g_gate);
+                    mp[0][r] = (1.f - gate) * gmv;
+                }
+                if constexpr (ERK == 4) {
                     if (flags & PVS_REZERO) {
                         gnew = gate * gmv;
                         g_gate = fmaf(gmv, m_new[r], g_gate);
@@ -597,9 +615,12 @@ int pvs_launch_edge_bwd_f16(hipStream_t s, int H, const PvsGraph& g, const PvsEd
         k_edge_bwd_f16<ER, EA><<<blocks, Cfg::kThreadsPerBlock, lds, s>>>(g, w, flags, att_act, io, n_chunks, \
                                                                           e_lo, e_hi);                   \
     } while (0)
-    const bool gated = flags & (PVS_REZERO | PVS_GATED_RESIDUAL);
-    if (eres && gated && eatt) PVS_BWD_F16_LAUNCH(2, true);
-    else if (eres && gated) PVS_BWD_F16_LAUNCH(2, false);
+    // (as the reference orders them: rezero wins over gated, egnn_satorras.py:194-202)
+    const bool rezero = flags & PVS_REZERO, gated = !rezero && (flags & PVS_GATED_RESIDUAL);
+    if (eres && rezero && eatt) PVS_BWD_F16_LAUNCH(2, true);
+    else if (eres && rezero) PVS_BWD_F16_LAUNCH(2, false);
+    else if (eres && gated && eatt) PVS_BWD_F16_LAUNCH(3, true);
+    else if (eres && gated) PVS_BWD_F16_LAUNCH(4, false);      // (kind 3 here: 23 spilled VGPRs, +9 %; kind 4: 18)
     else if (eres && eatt) PVS_BWD_F16_LAUNCH(1, true);
     else if (eres) PVS_BWD_F16_LAUNCH(1, false);
     else if (eatt) PVS_BWD_F16_LAUNCH(0, true);
