@@ -459,9 +459,22 @@ class SartorrasEGNN(PNNGeometricBase):
         p = float(getattr(self, 'dropout_p', 0.0) or 0.0)
         if p == 0.0 or not self.training:
             return edges, edge_attributes
+        if int(edges.shape[1]) == 0:          # nothing to draw from (and no device pointer to hand to the library)
+            return edges, edge_attributes
+        # the step of the draw: epochs done (restored from a checkpoint) and optimiser steps taken in this run (+ the
+        # calls since the last one, for several forwards per step), so that a resumed run does not replay the masks
+        # of its first epoch; the rank goes into the seed, so that data-parallel ranks do not drop the same edge
+        # indices
+        base = ((getattr(self, 'p_epoch', 0) + getattr(self, 'a_epoch', 0)) << 24) + getattr(self, 'global_iter', 0)
+        if base != getattr(self, '_dropout_base', None):
+            self._dropout_base, self._dropout_calls = base, 0
         self._dropout_calls = getattr(self, '_dropout_calls', 0) + 1
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * rank) & (2 ** 64 - 1)
         return PF.dropout_adj(edges, edge_attributes, p, force_undirected=True, training=True,
-                              seed=torch.initial_seed(), step=self._dropout_calls)
+                              seed=seed, step=(int(base) << 8) + self._dropout_calls)
 
     def embed_prepared(self, pg, feats, coords, need_messages=False, trace=None, need_coords=True):
         """Layer stack on a PreparedGraph. Edge messages stay in sorted order between layers and
@@ -489,6 +502,11 @@ class SartorrasEGNN(PNNGeometricBase):
         edge_messages in the caller's edge order."""
         edges, edge_attributes = self.edge_dropout(edges, edge_attributes)
         pg = prepared_for(edges, edge_attributes, feats.size(0))
+        if batch is not None and torch.is_grad_enabled() and batch.numel() > 1:
+            # the batch vector names the graphs: tiles of the fp16-split backward end where a graph ends (one host
+            # sync for the number of graphs - the reference's forward has the same one, pnn_geometric_base.py:27)
+            counts = torch.unique_consecutive(batch, return_counts=True)[1]
+            pg.set_graph_ptr(torch.cat([counts.new_zeros(1), counts.cumsum(0)]))
         feats, _, m_sorted = self.embed_prepared(pg, feats, coords, need_messages=True, need_coords=False)
         edge_messages = None if m_sorted is None else PF.rows_to_input_order(m_sorted, pg)
         return feats, edge_messages

@@ -223,6 +223,11 @@ def prepare_graph(edge_index, edge_attr, n_nodes, need_backward=None, layout=Non
             _lib.ptr(edge_ptr), *outputs, max_nodes, _lib.ptr(ws), ws_bytes, stream)
         _lib.check(rc, 'pvs_graph_prepare_runs')
         t['_layout'] = layout      # (keeps the pointer tables alive until the kernels have run)
+        # the batch's graphs are known: graph g's edges are the sorted positions [edge_ptr[g], edge_ptr[g + 1]) (graphs
+        # hold consecutive node ranges and the list is sorted by row) - exactly PvsGraph.graph_eptr, so every caller
+        # of this path gets tiles that end at graph boundaries, not only the models' forward
+        if n_graphs >= 2:
+            t['graph_eptr'] = edge_ptr
     else:
         ws_bytes = lib.pvs_graph_prepare_workspace_bytes(n_nodes, n_edges)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -230,7 +235,11 @@ def prepare_graph(edge_index, edge_attr, n_nodes, need_backward=None, layout=Non
             _lib.ptr(edge_index), _lib.ptr(edge_attr), n_attr, n_nodes, n_edges, *outputs, _lib.ptr(ws), ws_bytes,
             stream)
         _lib.check(rc, 'pvs_graph_prepare')
-    return PreparedGraph(n_nodes, n_edges, n_attr, t)
+    pg = PreparedGraph(n_nodes, n_edges, n_attr, t)
+    if 'graph_eptr' in t:
+        pg.c.graph_eptr = _lib.ptr(t['graph_eptr'])
+        pg.c.n_graphs = int(t['graph_eptr'].numel()) - 1
+    return pg
 
 
 _PREFETCH = {}
