@@ -221,6 +221,9 @@ int node_mlp_forward(hipStream_t s, const Dims& m, const PvsLayerDesc* d, const 
     const bool fuse_silu = can_epi && !(F & PVS_GRAPHNORM);
     const bool gated = (F & PVS_RESIDUAL) && (F & (PVS_REZERO | PVS_GATED_RESIDUAL));
     const bool fuse_out = can_epi && !(F & PVS_NODE_ATTENTION) && !gated;
+    // (The A/B switches are read from the environment at EVERY call on purpose - ADVICE r03 suggested statics: the
+    // test suite and tools/abenv.py flip them inside one process, e.g. the exact-fp32 family against the split products
+    // on the same tensors. A getenv is ~0.2 us of host time; a layer call enqueues 6-9 launches of >= 3 us each.)
     const bool split_small = getenv("PVS_EGNN_SPLIT_SMALL") != nullptr;     // (the launches apart, for A/B)
     if (fuse_silu && !gated && !split_small && p->node_b1 && p->node_b2 &&
         pvs_node_mlp_fused_supported(H, h, Magg, y1, h_out)) {

@@ -128,7 +128,8 @@ def test_layers_wider_than_the_fused_kernels_match_oracle(k, flags):
 def test_wide_layers_run_fused_and_match_oracle(k, flags):
     """Round 3: 64 < hidden <= 128 on the fused kernels at 128 channels (zero-padded below 128): the f16x2 edge
     forward as two launches (one split weight matrix in LDS each, the messages handed over through memory) and the
-    four-wave fp32 team backward with coord_mlp.0's weight read from global memory. Oracle: fp64 autograd."""
+    four-wave team backward on three-term fp16 products (edge_bwd_wide.hip) with coord_mlp.0's weight read from global
+    memory. Oracle: fp64 autograd."""
     _check_wide(k, flags)
 
 
