@@ -21,5 +21,10 @@ cp $src/soak_alone.json $dst/${tag}_soak_alone.json
 cp $src/soak_load.json $dst/${tag}_soak_concurrent_gpu_load.json
 cp $src/soak_poison.json $dst/${tag}_soak_poisoned_allocator.json
 cp $src/variants.txt $dst/${tag}_variants_backward_timings.txt
+cp $src/sustained_summary.txt $dst/${tag}_sustained_summary.txt; for c in cfg2 cfg3; do grep '^{' gpurun_out/${tag}_sustained_$c.json | tail -1 > $dst/${tag}_sustained_$c.json; done
+cp $src/strong_scaling_one_gpu_legs.txt $dst/${tag}_strong_scaling_one_gpu_legs.txt
+cp $src/allreduce_one_rank_rccl.json $dst/${tag}_allreduce_one_rank_rccl.json
+cp $src/dynamic_range.txt $dst/${tag}_dynamic_range.txt
+cp $src/parity_margins.txt $dst/${tag}_parity_margins.txt
 ls $dst | grep "^${tag}_" | wc -l
 python3 tools/pmc_header.py $dst/${tag}_cfg2_pmc_sq.txt cfg2 > /dev/null; python3 tools/pmc_header.py $dst/${tag}_cfg3_pmc_sq.txt cfg3 > /dev/null

@@ -5,12 +5,13 @@ tag=$1
 out=gpurun_out/final_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-python3 bench.py --steps 20 --warmup 5 > $out/bench_cfg2.json 2> $out/bench_cfg2.err
-python3 bench.py --config cfg3 --no-cpu-baseline > $out/bench_cfg3.json 2>/dev/null
-python3 bench.py --infer --no-cpu-baseline > $out/bench_cfg2_infer.json 2>/dev/null
-python3 bench.py --config cfg5 --sweep 12800 > $out/bench_cfg5.json 2>/dev/null
-python3 bench.py --skip-dead-coords --no-cpu-baseline > $out/bench_cfg2_skip.json 2>/dev/null
-PVS_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 5 --warmup 2 > $out/bench_cfg2_gpus2_gloo_shared_gpu.json 2>/dev/null
+line() { grep '^{' | tail -1; }          # keep the JSON line only ([Gloo] / library chatter goes to stdout too)
+python3 bench.py --steps 20 --warmup 5 2> $out/bench_cfg2.err | line > $out/bench_cfg2.json
+python3 bench.py --config cfg3 2>/dev/null | line > $out/bench_cfg3.json        # (with cpu_baseline since round 4)
+python3 bench.py --infer --no-cpu-baseline 2>/dev/null | line > $out/bench_cfg2_infer.json
+python3 bench.py --config cfg5 --sweep 12800 2>/dev/null | line > $out/bench_cfg5.json
+python3 bench.py --skip-dead-coords --no-cpu-baseline 2>/dev/null | line > $out/bench_cfg2_skip.json
+PVS_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 5 --warmup 2 2>/dev/null | line > $out/bench_cfg2_gpus2_gloo_shared_gpu.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg2 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/prof_cfg2.json 2> $out/prof_cfg2.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg3 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --config cfg3 > $out/prof_cfg3.json 2> $out/prof_cfg3.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg5 -- python3 bench.py --config cfg5 --steps 50 --warmup 5 --graph 0 --no-cpu-baseline > $out/prof_cfg5.json 2> $out/prof_cfg5.err
@@ -32,4 +33,10 @@ python3 tools/soak.py --repeats 40 --states nan,garbage --out $out/soak_poison.j
 tools/pmc_lat.sh ${tag} > $out/pmc_lat.txt 2>&1
 find gpurun_out/pmc_lat_${tag} -name '*.csv' -size +1M -delete
 tools/variants_r3b.sh $out/variants.txt > /dev/null 2>&1
-python3 bench.py --config cfg5 --sweep 100000 --no-cpu-baseline > $out/bench_cfg5_sweep100000.json 2>/dev/null
+python3 bench.py --config cfg5 --sweep 100000 --no-cpu-baseline 2>/dev/null | line > $out/bench_cfg5_sweep100000.json
+# round 4 additions: sustained clocks, strong-scaling legs, the 1-rank RCCL all-reduce, strict-parity margins, dynamic range
+tools/sustained.sh ${tag} > $out/sustained_summary.txt 2>&1
+tools/strong_scaling_legs.sh > $out/strong_scaling_one_gpu_legs.txt 2>&1
+python3 tools/allreduce_microbench.py 2>/dev/null | line > $out/allreduce_one_rank_rccl.json
+python3 tools/dynamic_range_probe.py 2>/dev/null | grep -v amdgpu.ids > $out/dynamic_range.txt
+python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_parity.py -q -m gpu > $out/parity.log 2>&1; cp gpurun_out/parity_margins.txt $out/parity_margins.txt
