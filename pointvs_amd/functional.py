@@ -353,6 +353,8 @@ def dropout_adj(edge_index, edge_attr=None, p=0.5, force_undirected=True, traini
     lib = _lib.lib()
     edge_index = edge_index.long().contiguous()
     n_edges = int(edge_index.shape[1])
+    if n_edges == 0:          # nothing to draw from (an empty tensor has no device pointer to hand over)
+        return edge_index, edge_attr
     dev = edge_index.device
     n_attr = 0
     if edge_attr is not None:

@@ -997,6 +997,8 @@ def test_edge_dropout_drops_both_directions_of_a_pair_together():
     ei, ea = g.edge_index, g.edge_attr
     same_i, same_a = PF.dropout_adj(ei, ea, 0.0, training=True)
     assert same_i is ei and same_a is ea
+    empty_i, empty_a = PF.dropout_adj(ei[:, :0], ea[:0], 0.5, training=True)          # (used to raise)
+    assert empty_i.shape == (2, 0) and empty_a.shape == (0, 3)
     same_i, _ = PF.dropout_adj(ei, ea, 0.4, training=False)
     assert same_i is ei
     p = 0.3
