@@ -11,6 +11,7 @@ bypassed: a plain list of collated batches stands in for the DataLoader) and rec
     warm_restarts     the same with warm_restarts=True     (CosineAnnealingWarmRestarts, T_0 = 4)
     multitask         MultitaskSatorrasEGNN: set_task('classification'), 2 epochs x 4 pose batches, then
                       set_task('regression'), 1 epoch x 4 affinity batches (point_vs.py:258-270)
+    k64_attention     BASELINE config 3's flag set at 64 channels, 3 layers, warm restarts
 
 per step: the loss `backprop()` returned and the learning rate the step ran at; at the end: the
 `state_dict`, the epoch counters, the checkpoint file names and the keys of a checkpoint dict.
@@ -82,9 +83,10 @@ def record_training(model, phases):
     return steps
 
 
-def run(name, cls, ctor_kwargs, phases, seed=7):
+def run(name, cls, ctor_kwargs, phases, seed=7, kw_changes=None):
     torch.manual_seed(seed)
     np.random.seed(seed)
+    KW = dict(globals()['KW'], **(kw_changes or {}))
     with tempfile.TemporaryDirectory() as tmp:
         model = cls(Path(tmp), 2e-3, 1e-4, None, None, silent=True, **ctor_kwargs, **KW)
         sd0 = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
@@ -127,6 +129,9 @@ def main():
     run('warm_restarts', SartorrasEGNN, {'warm_restarts': True}, [('classification', batches(100), 3)])
     run('multitask', MultitaskSatorrasEGNN, {},
         [('classification', batches(100), 2), ('regression', batches(500, regression=True), 1)])
+    # BASELINE config 3's flag set (64 channels, sigmoid edge gate + node gate): the H = 64 kernels in a training run
+    run('k64_attention', SartorrasEGNN, {'warm_restarts': True}, [('classification', batches(100), 3)],
+        kw_changes={'k': 64, 'edge_attention': True, 'node_attention': True, 'tanh': False, 'num_layers': 3})
 
 
 if __name__ == '__main__':

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests._golden import rel_err
+from tests._golden import CaseLog, assert_strict, grad_floor, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -95,12 +95,18 @@ def test_ragged_graphs_match_oracle(name, flags):
     g = random_graph(n, e, seed=sum(name.encode()) % 1000)
     y, grads = gpu_run(model, g)
     y_ref, _, g_ref = oracle_run(model, kw, g, dtype=torch.float64)
+    _, _, g_ref32 = oracle_run(model, kw, g, dtype=torch.float32)
     assert rel_err(y, y_ref.numpy()) < TOL
+    log = CaseLog(f'ragged_{name}_{flags}')
+    floor = grad_floor({k: (None if v is None else v.numpy()) for k, v in g_ref.items()})
     for pname, gr in grads.items():
         if gr is None:
             assert g_ref[pname] is None, pname
         else:
             assert rel_err(gr, g_ref[pname].numpy()) < TOL, pname
+            # (strict per-tensor form, tests/_golden.py: a small gradient tensor is compared at its own magnitude)
+            assert_strict(gr, g_ref[pname].numpy(), g_ref32[pname].numpy(), f'{log.case} grad {pname}', floor=floor, log=log)
+    log.finish()
 
 
 @pytest.mark.parametrize('k', [96, 128])
@@ -154,12 +160,18 @@ def _check_wide(k, flags):
     g = random_graph(300, 6000, seed=21, n_graphs=3)
     y, grads = gpu_run(model, g)
     y_ref, _, g_ref = oracle_run(model, kw, g, dtype=torch.float64)
+    _, _, g_ref32 = oracle_run(model, kw, g, dtype=torch.float32)
     assert rel_err(y, y_ref.numpy()) < TOL
+    log = CaseLog(f'ragged_{name}_{flags}')
+    floor = grad_floor({k: (None if v is None else v.numpy()) for k, v in g_ref.items()})
     for pname, gr in grads.items():
         if gr is None:
             assert g_ref[pname] is None, pname
         else:
             assert rel_err(gr, g_ref[pname].numpy()) < TOL, pname
+            # (strict per-tensor form, tests/_golden.py: a small gradient tensor is compared at its own magnitude)
+            assert_strict(gr, g_ref[pname].numpy(), g_ref32[pname].numpy(), f'{log.case} grad {pname}', floor=floor, log=log)
+    log.finish()
     if flags == 'att_res':
         n_edges = int(g.edge_index.shape[1])
         for layer in list(model.layers)[1:]:      # (the last one evaluates its dead coordinate update on demand)

@@ -1,7 +1,8 @@
 """The training harness against TRAJECTORIES of the reference's own `train_model`
 (tests/golden/train_*.npz, written by tests/golden/make_golden_training.py from /root/reference): twelve optimiser
-steps on a fixed list of batches under the three learning-rate schedules the reference offers, and the multitask
-sequence pose -> set_task('regression') -> affinity of point_vs.py:258-270.
+steps on a fixed list of batches under the three learning-rate schedules the reference offers, the multitask
+sequence pose -> set_task('regression') -> affinity of point_vs.py:258-270, and BASELINE config 3's flag set at 64
+channels (the H = 64 kernels in a training run).
 
 Checked per step: the loss `backprop()` computes (1e-4 relative: twelve Adam steps amplify fp32 summation-order noise,
 a single step is held to 1e-5 in tests/test_gpu_parity.py) and the learning rate the step ran at (the schedulers are
@@ -43,7 +44,7 @@ def _loaders(z, meta):
     return out
 
 
-@pytest.mark.parametrize('name', ['default', 'one_cycle', 'warm_restarts', 'multitask'])
+@pytest.mark.parametrize('name', ['default', 'one_cycle', 'warm_restarts', 'multitask', 'k64_attention'])
 def test_training_trajectory_matches_the_reference(name, tmp_path):
     from pointvs_amd.egnn_multitask import MultitaskSatorrasEGNN
     from pointvs_amd.egnn_satorras import SartorrasEGNN
