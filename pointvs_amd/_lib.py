@@ -122,6 +122,11 @@ def lib():
             raise RuntimeError(
                 f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; '
                 f'g.build()"` (or `make -C pointvs_amd/csrc`). pointvs_amd has no CPU fallback.')
+        # torch FIRST: it brings its own copy of the HIP runtime (SONAME libamdhip64.so.7, like the system's one this
+        # library is linked against). Loaded before torch, the library would bind the system runtime and torch its
+        # bundled one - two runtimes in one process, and the streams / device state of one are nothing to the other
+        # ("no ROCm-capable device is detected" from the first launch; seen when build() and smoke() ran in one process).
+        import torch  # noqa: F401
         handle = C.CDLL(str(LIB_PATH))
         for name, (restype, argtypes) in _PROTOTYPES.items():
             fn = getattr(handle, name)

@@ -162,7 +162,7 @@ def _check_wide(k, flags):
     y_ref, _, g_ref = oracle_run(model, kw, g, dtype=torch.float64)
     _, _, g_ref32 = oracle_run(model, kw, g, dtype=torch.float32)
     assert rel_err(y, y_ref.numpy()) < TOL
-    log = CaseLog(f'ragged_{name}_{flags}')
+    log = CaseLog(f'wide_{k}_{flags}')
     floor = grad_floor({k: (None if v is None else v.numpy()) for k, v in g_ref.items()})
     for pname, gr in grads.items():
         if gr is None:
