@@ -375,6 +375,8 @@ int pvs_segment_reduce_bwd(const float* g_out, const int64_t* ids, const int32_t
  * kernels ("edge_fwd", "edge_bwd", "col_gather", "graph_prepare") with HIP events on the launch
  * stream; pvs_profile_read waits for those events and returns the summed kernel time. Used by
  * bench.py for the roofline figure; off by default (no events are created).
+ * on: 0 = off; 1 = all four groups; otherwise a mask, bit (k + 1) = group k in the order above (an event pair costs the
+ * stream a ~6 us bubble per launch, so bench.py brackets only the dominant kernel inside its timed region).
  */
 int pvs_profile_enable(int on);
 int pvs_profile_reset(void);
