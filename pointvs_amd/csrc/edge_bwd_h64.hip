@@ -39,19 +39,29 @@ static_assert(kT16 * kTS16 * 4 + kT16 * 16 + kT16 * 4 <= kImg16 * 2, "g_z1 tile 
 
 __device__ __forceinline__ int ych(int r, int gr) { return 16 * (r >> 2) + 4 * gr + (r & 3); }
 
-// ---- LDS images: [rows][64] bf16, 128-byte rows, the 8-byte chunks of a row permuted by an XOR that depends
-// on the row. ds_read_b64 / ds_read_b64_tr_b16 are served per 32-lane half over 64 four-byte banks, so the 32
-// lanes of a half must hit 32 different 8-byte units mod 256 B: unit = 16 (row & 1) + (chunk ^ f(row)).
+// ---- LDS images of [rows][64] bf16 tensors: the 8-byte chunks of a row permuted by an XOR that depends on the
+// row. ds_read_b64 / ds_read_b64_tr_b16 are served per 32-lane half over 64 four-byte banks, so the 32 lanes of a
+// half must hit 32 different 8-byte units mod 256 B.
 // The swizzle of the H = 32 kernels (f = row / 2) leaves this kernel's reads 2-way (row reads) and 4-way
 // (transposed reads) conflicting - SQ_LDS_BANK_CONFLICT was half of all LDS cycles - so each image gets the f
 // its own access patterns need:
-//  * weights (frag16): row reads vary row bits 0-3 and chunk bit 0 (lane group), transposed reads vary row
-//    bits 0-2 (q, g0) and chunk bits 0-1 (p):  f = (r3, r1, r2) -> chunk bits (1, 2, 3)
-//  * activations / gradients: writes vary the row (16 lanes of one group: f must be a bijection of the row's
-//    4 bits), transposed reads vary row bits 0-1 (q) and chunk bits 0-2 (p, g0):  f = (r0, r3, r2, r1) -> bits (0, 1, 2, 3)
+//  * weights (frag16): per 16-row block TWO PLANES of [16 rows][32 bf16] - plane (c >> 4) & 1 holds the channels
+//    whose Y-layout register index has bit 2 set / clear - so that the two 8-byte halves of a lane's k-step
+//    fragment (channels 32 s + 4 g + . and 32 s + 16 + 4 g + .) sit a CONSTANT 1 KB apart, closer than any other
+//    pair of the product's loads: the compiler fuses loads by offset distance, and this pair becomes one
+//    ds_read2st64_b64 that lands in the operand's four consecutive registers. (With both halves in one
+//    128-byte row under a row-dependent XOR it paired loads of DIFFERENT fragments and rebuilt every operand
+//    with four v_mov: 130 per tile.) Inside a plane a row is 64 B = 8 chunks (s, g); row reads vary row bits
+//    0-3 and g0, transposed reads vary row bits 0-2 and chunk bits 0-1 (p):  f = (r2, r3) -> chunk bits (2, 1)
+//    makes both hit 32 different 8-byte units mod 256 B (unit = 8 (row & 3) + (chunk ^ f)).
+//  * activations / gradients ([16][64], 128-byte rows, unit = 16 (row & 1) + (chunk ^ f)): writes vary the row (16
+//    lanes of one group: f must be a bijection of the row's 4 bits), transposed reads vary row bits 0-1 (q) and
+//    chunk bits 0-2 (p, g0):  f = (r0, r3, r2, r1) -> bits (0, 1, 2, 3)
+constexpr int kWPlane = 16 * 32;
 __device__ __forceinline__ int w_off(int r, int c) {
-    const int f = (((r >> 3) & 1) << 1) | (((r >> 1) & 1) << 2) | (((r >> 2) & 1) << 3);
-    return r * kH + 4 * ((c >> 2) ^ f) + (c & 3);
+    const int f = (((r >> 2) & 1) << 2) | (((r >> 3) & 1) << 1);
+    const int chunk = ((c >> 5) << 2) | ((c >> 2) & 3);
+    return (r >> 4) * 2 * kWPlane + ((c >> 4) & 1) * kWPlane + (r & 15) * 32 + 4 * (chunk ^ f) + (c & 3);
 }
 __device__ __forceinline__ int a_off(int n, int c) {
     const int f = (n & 1) | (((n >> 3) & 1) << 1) | (((n >> 2) & 1) << 2) | (((n >> 1) & 1) << 3);
@@ -114,8 +124,9 @@ __device__ __forceinline__ bf16x8 frag16(const unsigned short* __restrict__ part
     uint2 a, c;
     if constexpr (!TRANSPOSE) {
         const int r = 16 * b + (lane & 15), c0 = 32 * s + 4 * gr;
-        a = *reinterpret_cast<const uint2*>(part + w_off(r, c0));
-        c = *reinterpret_cast<const uint2*>(part + w_off(r, c0 + 16));
+        const unsigned short* q = part + w_off(r, c0);
+        a = *reinterpret_cast<const uint2*>(q);
+        c = *reinterpret_cast<const uint2*>(q + kWPlane);
     } else {
         // 16-lane group: lane 4q+p supplies row q, columns 4p..4p+3 of a 4x16 block and receives column
         // (lane & 15) of its 4 rows
