@@ -346,8 +346,8 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                     logit = fmaf(wq4.z, m[0][4 * gq + 2], logit); dot = fmaf(m[0][4 * gq + 2], gq4.z, dot);
                     logit = fmaf(wq4.w, m[0][4 * gq + 3], logit); dot = fmaf(m[0][4 * gq + 3], gq4.w, dot);
                 }
-                logit += __shfl_xor(logit, 32, 64);
-                dot += __shfl_xor(dot, 32, 64);
+                logit = pvs_xor32_sum(logit);
+                dot = pvs_xor32_sum(dot);
                 logit += bac;
                 const float aval = io.att[ee];
                 g_l = (flags & PVS_SOFTMAX_ATT) ? aval * (dot - io.softD[i]) * vm   // softD = M_i . g_M_i
@@ -407,7 +407,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                     dq[r] = fmaf(q[r], 1.0f - sg, sg);
                     s = fmaf(wc2x[0][r], q[r], s);
                 }
-                s += __shfl_xor(s, 32, 64);
+                s = pvs_xor32_sum(s);
                 float dact = 1.f;
                 if (flags & PVS_TANH) { s = pvs_tanh(s); dact = 1.f - s * s; }
                 if (flags & PVS_NORMALIZE) nrm = 1.f / (sqrtf(rho) + 1e-8f);

@@ -176,6 +176,106 @@ __device__ __forceinline__ void chain16(const unsigned short* __restrict__ img, 
     mm(f2, v.lo[1]); mm(f2, v.mid[1]); mm(f2, v.hi[1]);   // hi, s = 1
 }
 
+// chain16 with the operand's split INSIDE the product. One wave per SIMD: the only vector work an MFMA can run
+// beside is this wave's own, and a 16x16x32 MFMA leaves room for two vector instructions (8 of its 16 cycles hold
+// the issue port). The split is 88 instructions per tensor - 8 v_perm for the hi parts, (v_and, v_sub) per value
+// for each residual, 8 v_perm per further part - and only the hi parts are needed by the first products, so the
+// order below is: hi parts of k-step 0, then every MFMA followed by ONE unit (two instructions) of the remaining
+// split, pinned in program order by sched_barrier(0) after every MFMA (left to itself the scheduler finishes the
+// split first and then issues the 48 MFMAs back to back with the vector ALU idle). Product order: every group of
+// four MFMAs needs only parts that are ready - (lo,0)hi (lo,1)hi (mid,0)hi (mid,0)mid (mid,1)hi (hi,0)hi (mid,1)mid
+// (hi,0)mid (hi,0)lo (hi,1)hi (hi,1)mid (hi,1)lo; fragment loads stay two groups ahead as in chain16.
+template <bool TRANSPOSE>
+__device__ __forceinline__ void chain16s(const unsigned short* __restrict__ img, int lane, const float (&x)[16],
+                                         Bf16Parts& pb, f32x4 (&acc)[4]) {
+    const unsigned short* lo = img + 2 * kH * kH;
+    const unsigned short* mid = img + kH * kH;
+    const unsigned short* hi = img;
+    bf16x8 f0[4], f1[4], f2[4];
+    unsigned ph[8], pm[8], pl[8];
+    float r[16], t[16];
+    auto ld = [&](const unsigned short* part, int s, bf16x8 (&f)[4]) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) f[b] = frag16<TRANSPOSE>(part, lane, b, s);
+    };
+    auto res = [](float v) { return v - __uint_as_float(__float_as_uint(v) & 0xffff0000u); };
+    auto part = [](const unsigned (&p)[8], int s) {
+        return __builtin_bit_cast(bf16x8, make_uint4(p[4 * s], p[4 * s + 1], p[4 * s + 2], p[4 * s + 3]));
+    };
+    // one unit = two vector instructions
+    auto HI = [&](int i) { ph[i] = pvs_pack_hi16(x[2 * i], x[2 * i + 1]); ph[i + 1] = pvs_pack_hi16(x[2 * i + 2], x[2 * i + 3]); };
+    auto MID = [&](int i) { pm[i] = pvs_pack_hi16(r[2 * i], r[2 * i + 1]); pm[i + 1] = pvs_pack_hi16(r[2 * i + 2], r[2 * i + 3]); };
+    auto LO = [&](int i) { pl[i] = pvs_pack_hi16(t[2 * i], t[2 * i + 1]); pl[i + 1] = pvs_pack_hi16(t[2 * i + 2], t[2 * i + 3]); };
+    auto R = [&](int k) { r[k] = res(x[k]); };
+    auto T = [&](int k) { t[k] = res(r[k]); };
+#define PVS_MM(f, b, v) do { acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[b], v, acc[b], 0, 0, 0); } while (0)
+#define PVS_PIN() __builtin_amdgcn_sched_barrier(0)
+    HI(0); HI(2);
+    ld(lo, 0, f0);
+    ld(lo, 1, f1);
+    ld(mid, 0, f2);
+    PVS_PIN();
+    {   // (lo, 0) hi0
+        const bf16x8 h0 = part(ph, 0);
+        PVS_MM(f0, 0, h0); HI(4); PVS_PIN();
+        PVS_MM(f0, 1, h0); HI(6); PVS_PIN();
+        PVS_MM(f0, 2, h0); R(0); PVS_PIN();
+        PVS_MM(f0, 3, h0); R(1); PVS_PIN();
+    }
+    ld(mid, 1, f0);
+    const bf16x8 h0 = part(ph, 0), h1 = part(ph, 1);
+    PVS_MM(f1, 0, h1); R(2); PVS_PIN();          // (lo, 1) hi1
+    PVS_MM(f1, 1, h1); R(3); PVS_PIN();
+    PVS_MM(f1, 2, h1); R(4); PVS_PIN();
+    PVS_MM(f1, 3, h1); R(5); PVS_PIN();
+    ld(hi, 0, f1);
+    PVS_MM(f2, 0, h0); R(6); PVS_PIN();          // (mid, 0) hi0
+    PVS_MM(f2, 1, h0); R(7); PVS_PIN();
+    PVS_MM(f2, 2, h0); MID(0); PVS_PIN();
+    PVS_MM(f2, 3, h0); MID(2); PVS_PIN();
+    const bf16x8 m0 = part(pm, 0);
+    PVS_MM(f2, 0, m0); R(8); PVS_PIN();          // (mid, 0) mid0
+    PVS_MM(f2, 1, m0); R(9); PVS_PIN();
+    PVS_MM(f2, 2, m0); R(10); PVS_PIN();
+    PVS_MM(f2, 3, m0); R(11); PVS_PIN();
+    ld(hi, 1, f2);
+    PVS_MM(f0, 0, h1); R(12); PVS_PIN();         // (mid, 1) hi1
+    PVS_MM(f0, 1, h1); R(13); PVS_PIN();
+    PVS_MM(f0, 2, h1); R(14); PVS_PIN();
+    PVS_MM(f0, 3, h1); R(15); PVS_PIN();
+    PVS_MM(f1, 0, h0); MID(4); PVS_PIN();        // (hi, 0) hi0
+    PVS_MM(f1, 1, h0); MID(6); PVS_PIN();
+    PVS_MM(f1, 2, h0); T(0); PVS_PIN();
+    PVS_MM(f1, 3, h0); T(1); PVS_PIN();
+    const bf16x8 m1 = part(pm, 1);
+    PVS_MM(f0, 0, m1); T(2); PVS_PIN();          // (mid, 1) mid1
+    PVS_MM(f0, 1, m1); T(3); PVS_PIN();
+    PVS_MM(f0, 2, m1); T(4); PVS_PIN();
+    PVS_MM(f0, 3, m1); T(5); PVS_PIN();
+    PVS_MM(f1, 0, m0); T(6); PVS_PIN();          // (hi, 0) mid0
+    PVS_MM(f1, 1, m0); T(7); PVS_PIN();
+    PVS_MM(f1, 2, m0); LO(0); PVS_PIN();
+    PVS_MM(f1, 3, m0); LO(2); PVS_PIN();
+    const bf16x8 l0 = part(pl, 0);
+    PVS_MM(f1, 0, l0); T(8); PVS_PIN();          // (hi, 0) lo0
+    PVS_MM(f1, 1, l0); T(9); PVS_PIN();
+    PVS_MM(f1, 2, l0); T(10); PVS_PIN();
+    PVS_MM(f1, 3, l0); T(11); PVS_PIN();
+    PVS_MM(f2, 0, h1); T(12); PVS_PIN();         // (hi, 1) hi1
+    PVS_MM(f2, 1, h1); T(13); PVS_PIN();
+    PVS_MM(f2, 2, h1); T(14); PVS_PIN();
+    PVS_MM(f2, 3, h1); T(15); PVS_PIN();
+    PVS_MM(f2, 0, m1); LO(4); PVS_PIN();         // (hi, 1) mid1
+    PVS_MM(f2, 1, m1); LO(6); PVS_PIN();
+    PVS_MM(f2, 2, m1);
+    PVS_MM(f2, 3, m1);
+    const bf16x8 l1 = part(pl, 1);
+    PVS_MM(f2, 0, l1); PVS_MM(f2, 1, l1); PVS_MM(f2, 2, l1); PVS_MM(f2, 3, l1);   // (hi, 1) lo1
+#undef PVS_MM
+#undef PVS_PIN
+    pb.hi[0] = h0; pb.hi[1] = h1; pb.mid[0] = m0; pb.mid[1] = m1; pb.lo[0] = l0; pb.lo[1] = l1;
+}
+
 // the three bf16 parts of a Y-layout tensor -> row-major [edge][channel] images (a_off swizzle)
 __device__ __forceinline__ void write_image16(unsigned short* __restrict__ img, int n, int gr, const Bf16Parts& p) {
 #pragma unroll
@@ -219,12 +319,51 @@ __device__ __forceinline__ void wgrad16(const unsigned short* __restrict__ gimg,
     }
 }
 
-// per-lane partial dot over the lane's 16 channels, summed over the 4 lane groups of the edge
-__device__ __forceinline__ float sum_groups(float s) {
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    return s;
+// gW2 += g_z2 (x) a1 of the PREVIOUS tile (images gimg, aimg) beside THIS tile's z1 -> a1 = SiLU(z1), SiLU'(z1):
+// 24 MFMAs of 32 cycles, each followed by its share of the 16 values' vector work (two values per three MFMAs),
+// pinned like chain16s. Fragment sets (three parts, 12 registers) are read one block pair ahead; the block order
+// (0,0) (0,1) (1,1) (1,0) reuses the activation fragments of block 1.
+template <class S1, class S2>
+__device__ __forceinline__ void wgrad16_beside(const unsigned short* __restrict__ gimg, const unsigned short* __restrict__ aimg,
+                                               int lane, f32x16 (&gW)[2][2], S1&& s1, S2&& s2) {
+    bf16x8 g0[3], g1[3], a0[3], a1[3];
+    auto ld = [&](const unsigned short* img, int blk, bf16x8 (&f)[3]) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f[p] = edge_fragment(img + p * kPart16, lane, blk);
+    };
+    // MFMA K (0..23) and its share of the vector work: values 2 (K / 3) and 2 (K / 3) + 1 over three MFMAs.
+    // (hi, mid, lo) = parts 0, 1, 2; small terms first.
+#define PVS_WG(acc, gp, ap, K)                                                          \
+    do {                                                                                \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gp, ap, acc, 0, 0, 0);            \
+        asm volatile("" : "+a"(acc));                                                   \
+        if constexpr ((K) % 3 == 0) { s1(2 * ((K) / 3)); }                              \
+        else if constexpr ((K) % 3 == 1) { s2(2 * ((K) / 3)); s1(2 * ((K) / 3) + 1); }  \
+        else { s2(2 * ((K) / 3) + 1); }                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+    } while (0)
+#define PVS_SIX(acc, g, a, K0)                                                          \
+    PVS_WG(acc, g[2], a[0], K0); PVS_WG(acc, g[0], a[2], K0 + 1); PVS_WG(acc, g[1], a[1], K0 + 2); \
+    PVS_WG(acc, g[1], a[0], K0 + 3); PVS_WG(acc, g[0], a[1], K0 + 4); PVS_WG(acc, g[0], a[0], K0 + 5)
+    ld(gimg, 0, g0);
+    ld(aimg, 0, a0);
+    ld(aimg, 1, a1);
+    __builtin_amdgcn_sched_barrier(0);
+    PVS_SIX(gW[0][0], g0, a0, 0);
+    ld(gimg, 1, g1);
+    __builtin_amdgcn_sched_barrier(0);
+    PVS_SIX(gW[0][1], g0, a1, 6);
+    ld(aimg, 0, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    PVS_SIX(gW[1][1], g1, a1, 12);
+    PVS_SIX(gW[1][0], g1, a0, 18);
+#undef PVS_SIX
+#undef PVS_WG
 }
+
+// per-lane partial dot over the lane's 16 channels, summed over the 4 lane groups of the edge
+// (lane-permute instructions, not ds_bpermute: edge_mfma_common.h, pvs_xor32_sum)
+__device__ __forceinline__ float sum_groups(float s) { return pvs_xor32_sum(pvs_xor16_sum(s)); }
 
 // node rows and per-row / per-edge scalars of one tile, fetched one tile ahead. EVERYTHING the first half of a
 // tile reads from HBM is in here: a load issued at the top of the tile would sit in front of the wait for this
@@ -305,8 +444,17 @@ __device__ __forceinline__ void reduce_rows16(const float* __restrict__ T, const
 #endif
 #ifdef PVS_ABL_H_NOCHAIN
 #define H64_CHAIN(T, img, lane, v, acc) do { for (int b_ = 0; b_ < 4; ++b_) acc[b_][0] += __builtin_bit_cast(uint4, v.hi[0]).x * 1e-30f; } while (0)
+#define H64_CHAINS(T, img, lane, x, pb, acc) do { split_bf16x3(x, pb); H64_CHAIN(T, img, lane, pb, acc); } while (0)
 #else
 #define H64_CHAIN(T, img, lane, v, acc) chain16<T>(img, lane, v, acc)
+// (the pinned form costs registers: with an edge residual - m_prev and, for the gates, the pre-residual message
+// live through the tile - it spills 8-22 VGPRs where split + chain16 spills 0-10; those instantiations keep the
+// two-step form)
+#define H64_CHAINS(T, img, lane, x, pb, acc)                                        \
+    do {                                                                            \
+        if constexpr (ERK == 0) chain16s<T>(img, lane, x, pb, acc);                 \
+        else { split_bf16x3(x, pb); chain16<T>(img, lane, pb, acc); }               \
+    } while (0)
 #endif
 
 // ERK: edge residual kind - 0 none; 1 the plain sum m + m_prev (nothing of the residual has to survive the tile's
@@ -316,6 +464,7 @@ __global__ void __launch_bounds__(256, 1)
 k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks, int e_lo, int e_hi) {
     constexpr int H = kH, NT = 256, NW = 4;
     constexpr bool ERES = ERK != 0;
+    constexpr bool PIPE = ERK == 0;      // gW2's product one tile late, beside the next tile's SiLU (registers: as H64_CHAINS)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short* W2i = reinterpret_cast<unsigned short*>(smem);         // 3 parts x [H][H] bf16
     unsigned short* Wc1i = W2i + 3 * H * H;
@@ -411,6 +560,15 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
         // tile, tx and rowbuf stay in LDS until then (their slot - the m image - is next written mid-tile).
         int pend_e0 = -1;
         unsigned pend_bmask = 0u;
+        if constexpr (PIPE) {
+            // gW2 += g_z2 (x) a1 of tile t is issued at the top of tile t+1 (wgrad16_beside); the first tile of a
+            // chunk multiplies two zeroed images
+            for (int k = lane; k < kImg16 * 2 / 16; k += 64) {
+                reinterpret_cast<uint4*>(A1I)[k] = make_uint4(0u, 0u, 0u, 0u);
+                reinterpret_cast<uint4*>(GI)[k] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            pvs_wave_lds_sync();
+        }
         auto store_phase = [&]() {
             if (gr == 0 && pend_e0 + n < e_end)       // per edge: grad wrt (x_row - x_col), rho and class: 16 B
                 pvs_store_nt(io.gd + (size_t)(pend_e0 + n) * 4, *reinterpret_cast<const float4*>(tx + n * 4));
@@ -448,21 +606,43 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 float a1[16], aa[16], rr[16];
                 load_y(attrt + ty * H, gr, aa);
                 load_y(wrhot, gr, rr);
+                if constexpr (PIPE) {
+                    float z[16], ex[16];
+                    wgrad16_beside(GI, A1I, lane, gW2,
+                                   // (the empty asm statements tie each value's work to its place between two
+                                   // MFMAs: sched_barrier pins the machine scheduler, but the optimiser before it
+                                   // moves pure arithmetic across the barriers and clumped the MFMAs again)
+                                   [&](int r) {
+                                       float p = G.P[r];
+                                       asm volatile("" : "+v"(p));
+                                       z[r] = p + G.Q[r] + fmaf(rr[r], rho, aa[r]);
+                                       ex[r] = pvs_exp(-z[r]);
+                                       asm volatile("" : "+v"(ex[r]));
+                                   },
+                                   [&](int r) {
+                                       const float sg = pvs_rcp(1.0f + ex[r]);
+                                       const float av = z[r] * sg;
+                                       d1r[r] = fmaf(av, 1.0f - sg, sg);
+                                       a1[r] = av;
+                                       asm volatile("" : "+v"(d1r[r]), "+v"(a1[r]));
+                                   });
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float z = G.P[r] + G.Q[r] + fmaf(rr[r], rho, aa[r]);
-                    const float sg = pvs_sigmoid(z);
-                    const float av = z * sg;
-                    d1r[r] = fmaf(av, 1.0f - sg, sg);       // SiLU'(z) = s + z s (1 - s)
-                    a1[r] = av;
+                    for (int r = 0; r < 16; ++r) {
+                        const float z = G.P[r] + G.Q[r] + fmaf(rr[r], rho, aa[r]);
+                        const float sg = pvs_sigmoid(z);
+                        const float av = z * sg;
+                        d1r[r] = fmaf(av, 1.0f - sg, sg);       // SiLU'(z) = s + z s (1 - s)
+                        a1[r] = av;
+                    }
                 }
-                split_bf16x3(a1, pb);
-                write_image16(A1I, n, gr, pb);
                 float bias[16];
                 load_y(b2t, gr, bias);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[r >> 2][r & 3] = bias[r];
-                H64_CHAIN(false, W2i, lane, pb, acc2);
+                H64_CHAINS(false, W2i, lane, a1, pb, acc2);
+                if constexpr (PIPE) pvs_wave_lds_sync();              // the previous tile's a1 image has been read
+                write_image16(A1I, n, gr, pb);
             }
             float dz2[16], m[16];             // SiLU'(z2) and the message
             float m_new[ERK == 2 ? 16 : 1];
@@ -498,9 +678,8 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 #pragma unroll
                     for (int r = 0; r < 16; ++r) accc[r >> 2][r & 3] = bias2[r];
                 }
-                split_bf16x3(m, pb);
+                H64_CHAINS(false, Wc1i, lane, m, pb, accc);            // zc = Wc1 m + bc1
                 write_image16(MI, n, gr, pb);
-                H64_CHAIN(false, Wc1i, lane, pb, accc);                 // zc = Wc1 m + bc1
                 float wc2y[16];
                 load_y(wc2t, gr, wc2y);
                 float q[16], dq[16];
@@ -526,10 +705,9 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                     g_wc2y[r] = fmaf(g_s, q[r], g_wc2y[r]);
                     g_bc1y[r] += g_zc[r];
                 }
-                split_bf16x3(g_zc, pb);
-                write_image16(GI, n, gr, pb);
                 load_y(io.gM + (size_t)i * H, gr, gMi);               // (in flight behind the two products below)
-                H64_CHAIN(true, Wc1i, lane, pb, gm);                    // g_m += Wc1^T g_zc
+                H64_CHAINS(true, Wc1i, lane, g_zc, pb, gm);            // g_m += Wc1^T g_zc
+                write_image16(GI, n, gr, pb);
                 pvs_wave_lds_sync();                                  // the m and g_zc images are complete
                 H64_WGRAD(GI, MI, lane, gWc1);                          // gWc1 += g_zc (x) m
             } else {
@@ -599,17 +777,18 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 if (valid) store_y(io.g_m_prev + (size_t)e * H, gr, mp);
             }
             // ---- g_a1 = W2^T g_z2 ; gW2 += g_z2 (x) a1 ; g_z1 = g_a1 * SiLU'(z1) ----
-            split_bf16x3(g_z2, pb);
-            pvs_wave_lds_sync();                                      // the g_zc image has been read
-            write_image16(GI, n, gr, pb);
             f32x4 ga1[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ga1[b][r] = 0.f;
-            H64_CHAIN(true, W2i, lane, pb, ga1);
-            pvs_wave_lds_sync();                                      // the a1 and g_z2 images are complete
-            H64_WGRAD(GI, A1I, lane, gW2);
+            H64_CHAINS(true, W2i, lane, g_z2, pb, ga1);
+            pvs_wave_lds_sync();                                      // the g_zc image has been read
+            write_image16(GI, n, gr, pb);
+            if constexpr (!PIPE) {
+                pvs_wave_lds_sync();                                  // the a1 and g_z2 images are complete
+                H64_WGRAD(GI, A1I, lane, gW2);
+            }
             float g_z1[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) g_z1[r] = ga1[r >> 2][r & 3] * d1r[r];
@@ -642,7 +821,13 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             G = Gn;
             pvs_wave_lds_sync();
         }
-        if (pend_e0 >= 0) store_phase();
+        if (pend_e0 >= 0) {
+            if constexpr (PIPE) {
+                pvs_wave_lds_sync();
+                H64_WGRAD(GI, A1I, lane, gW2);                          // the last tile's product
+            }
+            store_phase();
+        }
         flush(cur_row);
     }
 

@@ -321,7 +321,7 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
             s = fmaf(w4.x, v[4 * gq], s); s = fmaf(w4.y, v[4 * gq + 1], s);
             s = fmaf(w4.z, v[4 * gq + 2], s); s = fmaf(w4.w, v[4 * gq + 3], s);
         }
-        return s + __shfl_xor(s, 32, 64);
+        return pvs_xor32_sum(s);
     };
     auto tab16 = [&](const float* tab, float (&out)[16]) {
 #pragma unroll
@@ -443,7 +443,7 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                 float pdot = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pdot = fmaf(m[r], gMi[r], pdot);
-                pdot += __shfl_xor(pdot, 32, 64);
+                pdot = pvs_xor32_sum(pdot);
                 if (hh == 0) { pdA[cb * kTile + j] = pl; pdB[cb * kTile + j] = pdot; }
             }
             const float sm = team_scale(m, 1, &inv_sm);                           // barrier 3 (also: pdA / pdB complete)
@@ -486,7 +486,7 @@ k_edge_bwd_wide(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdI
                     dq[r] = fmaf(q[r], 1.0f - sg, sg);
                     ps = fmaf(wc2x[r], q[r], ps);
                 }
-                ps += __shfl_xor(ps, 32, 64);
+                ps = pvs_xor32_sum(ps);
                 if (hh == 0) pdC[cb * kTile + j] = ps;
                 __syncthreads();                                                  // barrier 5: pdC complete
                 float s = sum_pd(pdC);

@@ -99,6 +99,33 @@ __device__ __forceinline__ void load_tab(const float* __restrict__ tab, int hh, 
         }
 }
 
+// v + (the same register of lane ^ 32 / ^ 16 / ^ 8) without LDS. v_permlane32_swap / v_permlane16_swap with both
+// operands the same register return the low-half (even-row) value in one result and the high-half (odd-row) value
+// in the other, in EVERY lane; lane ^ 8 is a rotation by 8 inside a row of 16 (DPP row_ror:8). Bit-identical to
+// v + __shfl_xor(v, o) (one commutative fp32 addition per lane), but a vector instruction instead of a
+// ds_bpermute round trip through LDS - which a wave that shares its SIMD with at most one other waits out.
+__device__ __forceinline__ float pvs_xor32_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float pvs_xor16_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float pvs_xor8_sum(float v) {
+    const int u = __float_as_int(v);
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(u, u, 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+}
+template <int O>
+__device__ __forceinline__ float pvs_xor_sum(float v) {
+    static_assert(O == 8 || O == 16 || O == 32, "lane distance");
+    if constexpr (O == 8) return pvs_xor8_sum(v);
+    else if constexpr (O == 16) return pvs_xor16_sum(v);
+    else return pvs_xor32_sum(v);
+}
+
 template <int HB>
 __device__ __forceinline__ float dot_tab(const float* __restrict__ tab, int hh, const float (&v)[HB][16]) {
     float s = 0.f;
@@ -110,7 +137,7 @@ __device__ __forceinline__ float dot_tab(const float* __restrict__ tab, int hh, 
             s = fmaf(w.x, v[b][4 * g], s); s = fmaf(w.y, v[b][4 * g + 1], s);
             s = fmaf(w.z, v[b][4 * g + 2], s); s = fmaf(w.w, v[b][4 * g + 3], s);
         }
-    return s + __shfl_xor(s, 32, 64);   // other half holds the other 16 channels of each block
+    return pvs_xor32_sum(s);            // other half holds the other 16 channels of each block
 }
 
 // Wave chunks of the edge range [e_lo, e_hi) (row-aligned ends): chunk k starts at the row that
@@ -250,12 +277,10 @@ __device__ __forceinline__ void reduce_rows_tile(const float* __restrict__ T, co
 // sum a float4 over the row slots (lanes that share a quad)
 template <int HB>
 __device__ __forceinline__ float4 sum_row_slots(float4 a) {
-    constexpr int QPR = 8 * HB;
-#pragma unroll
-    for (int o = QPR; o < 64; o <<= 1) {
-        a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64);
-        a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
-    }
+    auto all = [&](auto f) { a.x = f(a.x); a.y = f(a.y); a.z = f(a.z); a.w = f(a.w); };
+    if constexpr (HB == 1) all([](float v) { return pvs_xor8_sum(v); });
+    if constexpr (HB <= 2) all([](float v) { return pvs_xor16_sum(v); });
+    all([](float v) { return pvs_xor32_sum(v); });
     return a;
 }
 
