@@ -23,6 +23,18 @@
 
 namespace {
 
+// timing-only ablation (tools/variant_obj.sh -DPVS_ABL_F_SCATTER): the per-edge outputs at scattered positions of a
+// 256k-edge region, the access pattern of a by-column layout
+#ifdef PVS_ABL_F_SCATTER
+#define PVS_ABL_SCR(e) pvs_abl_scr((e), g.n_edges)
+__device__ __forceinline__ int pvs_abl_scr(int e, int E) {
+    const int r = (e & ~262143) + (int)(((unsigned)(e & 262143) * 40503u) & 262143u);
+    return r < E ? r : e;
+}
+#else
+#define PVS_ABL_SCR(e) (e)
+#endif
+
 constexpr int kH = 32;
 constexpr int kPartShorts = 32 * kH;              // one fp16 part image of a [32 edges][32 channels] tensor
 constexpr int kImg2 = 2 * kPartShorts;            // hi + lo
@@ -505,7 +517,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 *reinterpret_cast<float4*>(tx + j * 4) = make_float4(gd0, gd1, gd2, 0.f);
                 rowbuf[j] = i;
                 if (valid)
-                    pvs_store_nt(io.gd + (size_t)e * 4, make_float4(gd0, gd1, gd2, pvs_pack_rho_type(rho, ty)));
+                    pvs_store_nt(io.gd + (size_t)PVS_ABL_SCR(e) * 4, make_float4(gd0, gd1, gd2, pvs_pack_rho_type(rho, ty)));
             }
             // ---- g_z1 edge-major, then whole rows to HBM + the row-side sums from the same reads ----
 #pragma unroll
@@ -517,7 +529,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             reduce_rows_tile<1>(T1, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
                                 [&](int rl, int q, const float4& v) {
                                     if (e0 + rl < e_this_end)   // streamed once: non-temporal
-                                        pvs_store_nt(io.gz1 + (size_t)(e0 + rl) * H + 4 * q, v);
+                                        pvs_store_nt(io.gz1 + (size_t)PVS_ABL_SCR(e0 + rl) * H + 4 * q, v);
                                 });
 #endif
             I = In;
