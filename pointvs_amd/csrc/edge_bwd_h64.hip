@@ -464,7 +464,6 @@ __global__ void __launch_bounds__(256, 1)
 k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO io, int n_chunks, int e_lo, int e_hi) {
     constexpr int H = kH, NT = 256, NW = 4;
     constexpr bool ERES = ERK != 0;
-    constexpr bool PIPE = ERK == 0;      // gW2's product one tile late, beside the next tile's SiLU (registers: as H64_CHAINS)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short* W2i = reinterpret_cast<unsigned short*>(smem);         // 3 parts x [H][H] bf16
     unsigned short* Wc1i = W2i + 3 * H * H;
@@ -560,15 +559,13 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
         // tile, tx and rowbuf stay in LDS until then (their slot - the m image - is next written mid-tile).
         int pend_e0 = -1;
         unsigned pend_bmask = 0u;
-        if constexpr (PIPE) {
-            // gW2 += g_z2 (x) a1 of tile t is issued at the top of tile t+1 (wgrad16_beside); the first tile of a
-            // chunk multiplies two zeroed images
-            for (int k = lane; k < kImg16 * 2 / 16; k += 64) {
-                reinterpret_cast<uint4*>(A1I)[k] = make_uint4(0u, 0u, 0u, 0u);
-                reinterpret_cast<uint4*>(GI)[k] = make_uint4(0u, 0u, 0u, 0u);
-            }
-            pvs_wave_lds_sync();
+        // gW2 += g_z2 (x) a1 of tile t is issued at the top of tile t+1 (wgrad16_beside); the first tile of a chunk
+        // multiplies two zeroed images
+        for (int k = lane; k < kImg16 * 2 / 16; k += 64) {
+            reinterpret_cast<uint4*>(A1I)[k] = make_uint4(0u, 0u, 0u, 0u);
+            reinterpret_cast<uint4*>(GI)[k] = make_uint4(0u, 0u, 0u, 0u);
         }
+        pvs_wave_lds_sync();
         auto store_phase = [&]() {
             if (gr == 0 && pend_e0 + n < e_end)       // per edge: grad wrt (x_row - x_col), rho and class: 16 B
                 pvs_store_nt(io.gd + (size_t)(pend_e0 + n) * 4, *reinterpret_cast<const float4*>(tx + n * 4));
@@ -606,7 +603,8 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 float a1[16], aa[16], rr[16];
                 load_y(attrt + ty * H, gr, aa);
                 load_y(wrhot, gr, rr);
-                if constexpr (PIPE) {
+#ifndef PVS_ABL_H_NOWGRAD
+                {
                     float z[16], ex[16];
                     wgrad16_beside(GI, A1I, lane, gW2,
                                    // (the empty asm statements tie each value's work to its place between two
@@ -622,26 +620,27 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                                    [&](int r) {
                                        const float sg = pvs_rcp(1.0f + ex[r]);
                                        const float av = z[r] * sg;
-                                       d1r[r] = fmaf(av, 1.0f - sg, sg);
+                                       d1r[r] = fmaf(av, 1.0f - sg, sg);       // SiLU'(z) = s + z s (1 - s)
                                        a1[r] = av;
                                        asm volatile("" : "+v"(d1r[r]), "+v"(a1[r]));
                                    });
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float z = G.P[r] + G.Q[r] + fmaf(rr[r], rho, aa[r]);
-                        const float sg = pvs_sigmoid(z);
-                        const float av = z * sg;
-                        d1r[r] = fmaf(av, 1.0f - sg, sg);       // SiLU'(z) = s + z s (1 - s)
-                        a1[r] = av;
-                    }
                 }
+#else
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float z = G.P[r] + G.Q[r] + fmaf(rr[r], rho, aa[r]);
+                    const float sg = pvs_sigmoid(z);
+                    const float av = z * sg;
+                    d1r[r] = fmaf(av, 1.0f - sg, sg);
+                    a1[r] = av;
+                }
+#endif
                 float bias[16];
                 load_y(b2t, gr, bias);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[r >> 2][r & 3] = bias[r];
                 H64_CHAINS(false, W2i, lane, a1, pb, acc2);
-                if constexpr (PIPE) pvs_wave_lds_sync();              // the previous tile's a1 image has been read
+                pvs_wave_lds_sync();                                  // the previous tile's a1 image has been read
                 write_image16(A1I, n, gr, pb);
             }
             float dz2[16], m[16];             // SiLU'(z2) and the message
@@ -785,10 +784,7 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             H64_CHAINS(true, W2i, lane, g_z2, pb, ga1);
             pvs_wave_lds_sync();                                      // the g_zc image has been read
             write_image16(GI, n, gr, pb);
-            if constexpr (!PIPE) {
-                pvs_wave_lds_sync();                                  // the a1 and g_z2 images are complete
-                H64_WGRAD(GI, A1I, lane, gW2);
-            }
+            // (gW2 += g_z2 (x) a1: at the top of the next tile / behind the loop)
             float g_z1[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) g_z1[r] = ga1[r >> 2][r & 3] * d1r[r];
@@ -822,10 +818,8 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             pvs_wave_lds_sync();
         }
         if (pend_e0 >= 0) {
-            if constexpr (PIPE) {
-                pvs_wave_lds_sync();
-                H64_WGRAD(GI, A1I, lane, gW2);                          // the last tile's product
-            }
+            pvs_wave_lds_sync();
+            H64_WGRAD(GI, A1I, lane, gW2);                              // the last tile's product
             store_phase();
         }
         flush(cur_row);
