@@ -56,8 +56,9 @@ FP32_PEAK_TFLOPS = 157.3   # fp32 vector = fp32 MFMA peak
 ARITHMETIC = ('fp32 I/O, accumulation and elementwise work; no reduced-precision storage. Per-edge matrix products on the '
               'matrix cores with fp32 accumulation: H=32 forward and backward and H=64 forward as 3-term fp16 products '
               '(two fp16 parts per operand = 22 bits, power-of-two operand scales: per EDGE in the forward, per 32-edge '
-              'tile in the backward, where an element 2^-k below its tile\'s largest keeps 22 - max(0, k - 16) bits: '
-              'absolute error 2^-38 of the tile maximum), H=64 backward as 6-term bf16 products (three bf16 parts = 24 '
+              'tile in the backward - without edge attention a scale kept while the tile maximum stays within two binades of its ceiling - where '
+              'an element 2^-k below its tile\'s largest keeps 22 - max(0, k - 14) bits: absolute error 2^-36 of the '
+              'tile maximum (k - 16 / 2^-38 with edge attention: per-tile scales)), H=64 backward as 6-term bf16 products (three bf16 parts = 24 '
               'bits, no scales); node-level products (N << E) on exact fp32 MFMAs')
 
 

@@ -81,8 +81,8 @@ typedef struct PvsGraph {
      * 32-edge tiles at graph boundaries, because one tile shares one power-of-two scale and two graphs'
      * gradients can differ by many orders of magnitude ("f16x2").
      * ACCURACY CONTRACT for callers that leave it NULL: a tile of the H = 32 backward may then span two graphs, and the
-     * smaller graph's per-edge gradients in that tile keep 22 - max(0, k - 16) bits when they are 2^-k below the
-     * larger graph's (absolute error 2^-38 of the tile's largest value). pointvs_amd fills it wherever it knows the
+     * smaller graph's per-edge gradients in that tile keep 22 - max(0, k - 14) bits when they are 2^-k below the
+     * larger graph's (absolute error 2^-36 of the tile's largest value). pointvs_amd fills it wherever it knows the
      * batch's graphs: model forward, get_embeddings (from the batch vector), every graph prepared by
      * pvs_graph_prepare_runs (edge_ptr IS this table). */
     const int32_t* graph_eptr;

@@ -107,11 +107,80 @@ __device__ __forceinline__ void wgrad_tile_f16(const unsigned short* __restrict_
     }
 }
 
+// ---- weight gradients accumulated IN the matrix core's accumulator (PVS_LAZY_WSCALE, round 4) ----------------------
+// wgrad_tile_f16 sums a tile into 32 temporary registers and folds them into the running sums with the tile's scales:
+// 64 v_fma + 32 live registers per tile in a kernel whose register file is full. Here the running sums ARE the MFMA
+// accumulators, kept at the scale of the operand images, and the images' scales move LAZILY: an operand keeps its
+// power-of-two scale while the tile's largest magnitude stays within kLazyWindow binades below the scale's ceiling
+// (s * max in [2^(13 - kLazyWindow), 2^14)); when it leaves the window the new scale puts it one binade below the
+// ceiling, and the accumulators that carry the old scale are multiplied by the (power-of-two, exact) ratio - a rare,
+// wave-uniform branch. Cost in accuracy: an element 2^-k below its tile's largest keeps 22 - max(0, k - 16 + d) bits,
+// d <= kLazyWindow the distance of the tile maximum from the ceiling (d = 0 with per-tile scales).
+// Scale ratios beyond 2^60 (a tile whose gradients are 2^-60 of what the accumulator holds, or the reverse) are not
+// applied: the smaller side is below the fp32 resolution of the sum - the tile is skipped, or the accumulator restarts.
+// Instantiations WITHOUT edge attention only: with it the bias tile gB also takes per-tile vector updates (the attention
+// weight's gradient rides in its idle columns), which would wait out every MFMA that writes it (+22 % per launch), and a
+// separate accumulator for those brings the spills back (5-57 VGPRs): they keep wgrad_tile_f16.
+constexpr int kLazyWindow = 2;
+struct LazyExp { int e; };                 // exponent of the scale's ceiling (scale = 2^(140 - e)); < 0: not set yet
+
+__device__ __forceinline__ float pvs_lazy_tile_scale(const float (&v)[16], LazyExp& st, float* inv) {
+    int e_t = (int)((pvs_wave_max_u32(__float_as_uint(pvs_absmax16(v))) >> 23) & 0xffu);
+    e_t = e_t < 16 ? 16 : e_t;
+    if (st.e < 0 || e_t > st.e || st.e - e_t > kLazyWindow) st.e = e_t + 1 > 254 ? 254 : e_t + 1;
+    *inv = __uint_as_float((unsigned)(st.e - 13) << 23);
+    return __uint_as_float((unsigned)(267 - st.e) << 23);
+}
+
+// the scale exponents an accumulator currently carries (operand G, operand Act); < 0: nothing accumulated yet
+struct AccExp { int eg, ea; };
+
+// Bring accumulator `a` (and the bias column of lanes j == col in gB) from the scale (cur) to (eg, ea).
+// Returns false when the tile's product is to be skipped (more than 2^60 below what the accumulator holds).
+__device__ __forceinline__ bool pvs_rescale_acc(f32x16& a, f32x16& gB, bool col_lane, AccExp& cur, int eg, int ea) {
+    if (cur.eg < 0) { cur.eg = eg; cur.ea = ea; return true; }
+    const int dg = cur.eg - eg, dw = dg + (cur.ea - ea);       // exponent of the ratio new scale / old scale
+    if (dw == 0 && dg == 0) return true;
+    if (dw > 60 || dg > 60) return false;
+    const float fw = dw < -60 ? 0.f : __uint_as_float((unsigned)(127 + dw) << 23);
+    const float fb = dg < -60 ? 0.f : __uint_as_float((unsigned)(127 + dg) << 23);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        a[r] *= fw;
+        gB[r] *= col_lane ? fb : 1.f;
+    }
+    cur.eg = eg; cur.ea = ea;
+    return true;
+}
+
+__device__ __forceinline__ void wgrad_tile_f16_acc(const unsigned short* __restrict__ g_img,
+                                                   const unsigned short* __restrict__ act_img,
+                                                   const unsigned* __restrict__ ones, int lane, f32x16& gW, f32x16& gB) {
+    const f16x8 one = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ones + lane * 4));
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const f16x8 gh = frag_f16<true>(g_img, lane, s);
+        const f16x8 gl = frag_f16<true>(g_img + kPartShorts, lane, s);
+        const f16x8 ah = frag_f16<true>(act_img, lane, s);
+        const f16x8 al = frag_f16<true>(act_img + kPartShorts, lane, s);
+        gW = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, ah, gW, 0, 0, 0);
+        gW = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, al, gW, 0, 0, 0);
+        gW = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, ah, gW, 0, 0, 0);
+        gB = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, one, gB, 0, 0, 0);
+        gB = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, one, gB, 0, 0, 0);
+    }
+}
+
 // timing-only ablations (tools/variant_obj.sh builds; never in the shipped library)
 #ifdef PVS_ABL_F_NOWGRAD
 #define F16_WGRAD(...) ((void)0)
+#define F16_WGRAD_ACC(...) ((void)0)
 #else
 #define F16_WGRAD(...) wgrad_tile_f16(__VA_ARGS__)
+#define F16_WGRAD_ACC(...) wgrad_tile_f16_acc(__VA_ARGS__)
+#endif
+#ifndef PVS_LAZY_WSCALE
+#define PVS_LAZY_WSCALE 1
 #endif
 
 struct F16Cfg {
@@ -216,6 +285,10 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 #pragma unroll
     for (int r = 0; r < 16; ++r) { gB[r] = 0.f; g_wc2x[r] = 0.f; gW2[r] = 0.f; gWc1[r] = 0.f; }
     float g_ba = 0.f, g_gate = 0.f;
+    // (LAZY) scale exponents of the four operand images and what the accumulators carry
+    constexpr bool LAZY = PVS_LAZY_WSCALE && !EATT;
+    LazyExp x_a1{-1}, x_m{-1}, x_g{-1}, x_g2{-1};
+    AccExp x_w2{-1, -1}, x_wc1{-1, -1};
 
     const int total_waves = gridDim.x * NW;
     for (int chunk = pvs_xcd_block(blockIdx.x, gridDim.x) * NW + wv; chunk < n_chunks; chunk += total_waves) {
@@ -303,7 +376,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                     }
                     *reinterpret_cast<float4*>(d1b + (gq * 64 + lane) * 4) = make_float4(dd[0], dd[1], dd[2], dd[3]);
                 }
-                const float sa1 = pvs_tile_scale(a1[0], &inv_sa1);
+                const float sa1 = LAZY ? pvs_lazy_tile_scale(a1[0], x_a1, &inv_sa1) : pvs_tile_scale(a1[0], &inv_sa1);
                 split_f16x2(a1[0], sa1, pb);
                 write_image_f16(A1I, j, hh, pb);
                 f32x16 acc2;
@@ -398,7 +471,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             float gT0 = 0.f, gT1 = 0.f, gT2 = 0.f;
             if (upd) {
                 gT0 = io.gxagg[3 * i]; gT1 = io.gxagg[3 * i + 1]; gT2 = io.gxagg[3 * i + 2];
-                const float sm = pvs_tile_scale(m[0], &inv_sm);
+                const float sm = LAZY ? pvs_lazy_tile_scale(m[0], x_m, &inv_sm) : pvs_tile_scale(m[0], &inv_sm);
                 split_f16x2(m[0], sm, pb);
                 write_image_f16(MI, j, hh, pb);
                 f32x16 accc;
@@ -432,7 +505,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                     g_wc2x[r] = fmaf(g_s, q[r], g_wc2x[r]);
                 }
                 float inv_sg;
-                const float sg_ = pvs_tile_scale(g_zc, &inv_sg);
+                const float sg_ = LAZY ? pvs_lazy_tile_scale(g_zc, x_g, &inv_sg) : pvs_tile_scale(g_zc, &inv_sg);
                 split_f16x2(g_zc, sg_, pb);
                 write_image_f16(GI, j, hh, pb);
                 f32x16 accg;
@@ -443,7 +516,12 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gm[r] = accg[r] * kg;
                 pvs_wave_lds_sync();                                  // the m and g_zc images are complete
-                F16_WGRAD(GI, MI, ones0, lane, inv_sg * inv_sm, inv_sg, gWc1, gB);   // gWc1 += g_zc (x) m ; g_bc1 += sum_e g_zc
+                // gWc1 += g_zc (x) m ; g_bc1 += sum_e g_zc
+                if constexpr (LAZY) {
+                    if (pvs_rescale_acc(gWc1, gB, j == 0, x_wc1, x_g.e, x_m.e)) F16_WGRAD_ACC(GI, MI, ones0, lane, gWc1, gB);
+                } else {
+                    F16_WGRAD(GI, MI, ones0, lane, inv_sg * inv_sm, inv_sg, gWc1, gB);
+                }
                 load_row_terms();
             } else {
                 load_row_terms();
@@ -486,7 +564,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             }
             // ---- g_a1 = W2^T g_z2 ; gW2 += g_z2 (x) a1 ; g_b2 += sum_e g_z2 ; g_z1 = g_a1 * SiLU'(z1) ----
             float inv_sg2;
-            const float sg2 = pvs_tile_scale(g_z2, &inv_sg2);
+            const float sg2 = LAZY ? pvs_lazy_tile_scale(g_z2, x_g2, &inv_sg2) : pvs_tile_scale(g_z2, &inv_sg2);
             split_f16x2(g_z2, sg2, pb);
             pvs_wave_lds_sync();                                      // the g_zc image has been read
             write_image_f16(GI, j, hh, pb);
@@ -495,7 +573,11 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             for (int r = 0; r < 16; ++r) ga1[r] = 0.f;
             chain_f16<true>(W2i, lane, pb, ga1);
             pvs_wave_lds_sync();                                      // the a1 and g_z2 images are complete
-            F16_WGRAD(GI, A1I, ones1, lane, inv_sg2 * inv_sa1, inv_sg2, gW2, gB);
+            if constexpr (LAZY) {
+                if (pvs_rescale_acc(gW2, gB, j == 1, x_w2, x_g2.e, x_a1.e)) F16_WGRAD_ACC(GI, A1I, ones1, lane, gW2, gB);
+            } else {
+                F16_WGRAD(GI, A1I, ones1, lane, inv_sg2 * inv_sa1, inv_sg2, gW2, gB);
+            }
             float g_z1[1][16];
             const float k1g = inv_sg2 * inv_sw2;
 #pragma unroll
@@ -545,6 +627,16 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
     __syncthreads();
     float* slab = smem;
     for (int i = threadIdx.x; i < L.total; i += NT) slab[i] = 0.f;
+    if constexpr (LAZY) {       // the accumulators back to true values: two exact power-of-two factors each
+        auto pw = [](int e) { return e < 0 ? 1.f : __uint_as_float((unsigned)(e - 13) << 23); };     // 1 / scale
+        const float a2 = pw(x_w2.eg), b2 = pw(x_w2.ea), ac = pw(x_wc1.eg), bc = pw(x_wc1.ea);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            gW2[r] = gW2[r] * a2 * b2;
+            gWc1[r] = gWc1[r] * ac * bc;
+            gB[r] *= j == 0 ? ac : (j == 1 ? a2 : 1.f);
+        }
+    }
     __syncthreads();
     // X-layout vectors: sum over the 32 edge lanes of each half
     auto lanes32 = [](float v) {

@@ -1145,8 +1145,8 @@ def test_dynamic_range_inside_one_graph(hid, flags, log2_range):
         per-operand rounding (two roundings to 11 bits against one to 24) shows: up to 16x (h_out) / 32x (one gate
         value, absolute error 7e-4 against 3e-5) on the worst row;
       * g_h when the INPUT rows span 2^(+-20): the backward keeps ONE scale per 32-edge tile (its weight gradients
-        sum over the tile's edges), so an element 2^-k below its tile's largest keeps 22 - max(0, k - 16) bits
-        (absolute error 2^-38 of the tile maximum): up to 64x on the worst row - where the fp32 family is itself
+        sum over the tile's edges; kept while the tile maximum stays within two binades of its ceiling), so an element
+        2^-k below its tile's largest keeps 22 - max(0, k - 14) bits (absolute error 2^-36 of the tile maximum): up to 64x on the worst row - where the fp32 family is itself
         1e-4 ... 1e-2 off. DESIGN.md section 4 states this bound; bench.py's config.arithmetic names it."""
     rec = dynamic_range_errors(hid, flags, log2_range)
     a, b = rec['f16x2'], rec['fp32']
