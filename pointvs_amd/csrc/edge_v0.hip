@@ -425,8 +425,11 @@ k_edge_bwd_v0(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO 
 // slabs [4H] - the MFMA edge backward leaves those to this memory-bound kernel, whose VALU is idle.
 // Lane = (edge slot, 16-byte quad): one wave-instruction fetches 64/(H/4) whole rows; UN independent
 // batches in flight. Fixed order everywhere: bitwise reproducible.
+#ifndef PVS_NG_MINBLOCKS
+#define PVS_NG_MINBLOCKS 5      // workgroups per CU the register budget must allow: 20 waves per CU with UN = 6
+#endif
 template <int H, bool WSUMS>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, PVS_NG_MINBLOCKS)
 k_node_gather(PvsGraph g, const float* __restrict__ gz1, const float* __restrict__ gd4,
               const float* __restrict__ gx_row, const float* __restrict__ g_x_out,
               float* __restrict__ gPQ, float* __restrict__ g_x, float* __restrict__ slabs,
@@ -434,8 +437,8 @@ k_node_gather(PvsGraph g, const float* __restrict__ gz1, const float* __restrict
     constexpr int QPR = H / 4;
     constexpr int EPW = 64 / QPR;
 #ifndef PVS_NG_UN
-#define PVS_NG_UN 8
-#endif
+#define PVS_NG_UN 6      // (8 at four waves per SIMD before round 4: the rate follows the waves in flight - five waves of six
+#endif                   // batches each: cfg3 gather -2.4 %, cfg2 -1.5 %; 8 waves of 4 spill and lose 5-8 %: profiles/r04_ab_gather_rows_in_flight.txt)
     constexpr int UN = PVS_NG_UN;
     __shared__ float red[kWaves][4 * H];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -618,7 +621,7 @@ int pvs_launch_edge_bwd_v0(hipStream_t s, int H, const PvsGraph& g, const PvsEdg
 int pvs_node_gather_blocks(int N) {
     int b = pvs_edge_v0_blocks(N);
 #ifndef PVS_NG_BLOCKS
-#define PVS_NG_BLOCKS 1024   // 512 -> 1024: cfg3 gather -18 %, cfg2 -3 % (2048: no further step gain)
+#define PVS_NG_BLOCKS 1280   // 512 -> 1024: cfg3 gather -18 %, cfg2 -3 %; 1280 = five resident workgroups per CU (PVS_NG_MINBLOCKS)
 #endif
     return b > PVS_NG_BLOCKS ? PVS_NG_BLOCKS : b;
 }
