@@ -9,6 +9,12 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// timing-only ablation (tools/variant_obj.sh dense_ops.hip "-DPVS_ABL_NODE_MFMA_STEP=3"): every third fp32 MFMA of the
+// node-level products only - what a faster product would buy (results are wrong in such a build)
+#ifndef PVS_ABL_NODE_MFMA_STEP
+#define PVS_ABL_NODE_MFMA_STEP 1
+#endif
+
 __device__ __forceinline__ int xch(int t, int hh) { return (t & 3) + 8 * (t >> 2) + 4 * hh; }
 
 // rows of a row-major [rows][ld] array <-> X layout: lane reads/writes 4 floats at 32b + 8g + 4hh
@@ -51,7 +57,7 @@ __device__ __forceinline__ void mfma_chain_rect(const float* __restrict__ Wn, in
 #pragma unroll
             for (int bi = 0; bi < KB; ++bi)
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
+                for (int t = 0; t < 16; t += PVS_ABL_NODE_MFMA_STEP) {
                     const float a = base[(32 * bo) * LD + 32 * bi + (t & 3) + 8 * (t >> 2)];
                     acc[bo] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v[bi][t], acc[bo], 0, 0, 0);
                 }
@@ -62,7 +68,7 @@ __device__ __forceinline__ void mfma_chain_rect(const float* __restrict__ Wn, in
 #pragma unroll
             for (int bi = 0; bi < CB; ++bi)
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
+                for (int t = 0; t < 16; t += PVS_ABL_NODE_MFMA_STEP) {
                     const float a = base[(32 * bi + (t & 3) + 8 * (t >> 2)) * LD + 32 * bo];
                     acc[bo] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v[bi][t], acc[bo], 0, 0, 0);
                 }
