@@ -1,0 +1,58 @@
+"""Register budget of the BASELINE kernel instantiations, from the compiler's own report (CPU: hipcc cross-compiles).
+
+The dominant kernels are tuned against hard occupancy steps: the H = 32 edge backward
+must fit 256 VGPRs unspilled (two waves per SIMD), the H = 32 forward 128 (four waves), the H = 64 forward 168 (three; both with the few spills listed below),
+the H = 64 backward lives in the whole unified file (256 + 256) with nothing in scratch. A change that quietly spills one
+of them costs 5-20 % without failing any parity test; this test fails instead."""
+import re
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+CSRC = Path(__file__).resolve().parent.parent / 'pointvs_amd' / 'csrc'
+HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+
+# (source, extra flags as in the Makefile, mangled-name fragment, max VGPRs, max AGPRs, max spilled VGPRs)
+# The two forward kernels are compiled AT their occupancy step and spill a few loop-invariant values (3 / 8 VGPRs,
+# reloaded once per tile: measured faster than one wave less); the bound is what is shipped, not a target.
+FWD = ['-fno-slp-vectorize', '-mllvm', '-amdgpu-mfma-vgpr-form=1']
+CASES = [
+    ('edge_bwd_f16.hip', [], 'k_edge_bwd_f16ILi0ELb0E', 256, 0, 0),
+    ('edge_mfma_fwd.hip', FWD, 'k_edge_fwd_mfmaILi1ELi256ELb0ELb1ELi0E', 128, 0, 3),
+    ('edge_mfma_fwd.hip', FWD, 'k_edge_fwd_mfmaILi2ELi768ELb0ELb1ELi0E', 168, 0, 8),
+    ('edge_bwd_h64.hip', [], 'k_edge_bwd_h64ILi0ELb1E', 256, 256, 0),
+    ('edge_bwd_h64.hip', [], 'k_edge_bwd_h64ILi0ELb0E', 256, 256, 0),
+]
+
+
+def _report(src, flags):
+    out = subprocess.run([HIPCC, '-O3', '-fPIC', '-std=c++17', '--offload-arch=gfx950', '-Wno-unused-value', *flags,
+                          '-Rpass-analysis=kernel-resource-usage', '-c', str(CSRC / src), '-o', '/dev/null'],
+                         capture_output=True, text=True, cwd=CSRC)
+    assert out.returncode == 0, out.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r'Function Name: (\S+)', line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r'remark:\s+(VGPRs Spill|SGPRs Spill|VGPRs|AGPRs|ScratchSize \[bytes/lane\]): (\d+)', line)
+        if m and cur is not None:
+            cur[m.group(1)] = int(m.group(2))
+    return kernels
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason='hipcc not installed')
+@pytest.mark.parametrize('src', sorted({c[0] for c in CASES}))
+def test_baseline_instantiations_fit_their_register_budget(src):
+    flags = next(c[1] for c in CASES if c[0] == src)
+    kernels = _report(src, flags)
+    for _, _, frag, max_v, max_a, max_spill in (c for c in CASES if c[0] == src):
+        hits = [v for k, v in kernels.items() if frag in k]
+        assert len(hits) == 1, (frag, list(kernels))
+        r = hits[0]
+        assert r['VGPRs Spill'] <= max_spill and r['SGPRs Spill'] == 0, (frag, r)
+        assert max_spill > 0 or r['ScratchSize [bytes/lane]'] == 0, (frag, r)
+        assert r['VGPRs'] <= max_v and r['AGPRs'] <= max_a, (frag, r)
