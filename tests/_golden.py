@@ -165,3 +165,13 @@ def margins_report():
     lines.append(f'{len(MARGINS)} strict checks; {len(small)} on tensors with max|ref64| < 1e-5 '
                  f'(the old max(1, |ref|) scale would have passed zeros there)')
     return '\n'.join(lines) + '\n'
+
+
+# hipGraph capture needs torch's caching allocator (its private graph pools); the memory-safety run of the GPU suite
+# (PYTORCH_NO_CUDA_MEMORY_CACHING=1: every tensor its own allocation, an access outside it faults) skips those tests
+import os as _os
+
+import pytest as _pytest
+
+needs_caching_allocator = _pytest.mark.skipif(_os.environ.get('PYTORCH_NO_CUDA_MEMORY_CACHING') == '1',
+                                              reason='hipGraph capture needs the caching allocator')

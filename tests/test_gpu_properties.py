@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests._golden import CaseLog, assert_strict, grad_floor, rel_err
+from tests._golden import CaseLog, assert_strict, grad_floor, needs_caching_allocator, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -383,6 +383,7 @@ def test_bce_with_logits_as_one_op(n):
         PF.bce_with_logits_mean(x.cuda().reshape(-1, 1), t.cuda())
 
 
+@needs_caching_allocator
 def test_hipgraph_captured_step_matches_eager():
     """The whole training step (prepare + forward + loss + backward + clip + Adam) captured in a
     hipGraph and replayed gives the same parameters as the eager step (the C ABI allocates nothing

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests._golden import GOLDEN_DIR
+from tests._golden import GOLDEN_DIR, needs_caching_allocator
 
 pytestmark = pytest.mark.gpu
 
@@ -217,6 +217,7 @@ def test_pose_batch_builder_equals_the_generic_builder():
             assert torch.equal(screen._fast[k + '_l'][:el], lig_ref.t[k][:el]), k
 
 
+@needs_caching_allocator
 def test_captured_screening_step_replays_on_new_poses():
     """hipGraph capture of the whole screening step (graph build + layer stack + head): replays on
     other pose batches give the eager results."""
@@ -242,6 +243,7 @@ def test_captured_screening_step_replays_on_new_poses():
     graph.check()
 
 
+@needs_caching_allocator
 def test_screening_sweep_streams_size_buckets_and_writes_predictions(tmp_path):
     """ScreeningSweep: ligands of two sizes (two captured buckets, the second ligand of a size reuses the
     first one's captured step with its own features), pose counts that are not multiples of the batch,
