@@ -121,38 +121,6 @@ __device__ __forceinline__ void wgrad_tile_f16(const unsigned short* __restrict_
 // Instantiations WITHOUT edge attention only: with it the bias tile gB also takes per-tile vector updates (the attention
 // weight's gradient rides in its idle columns), which would wait out every MFMA that writes it (+22 % per launch), and a
 // separate accumulator for those brings the spills back (5-57 VGPRs): they keep wgrad_tile_f16.
-constexpr int kLazyWindow = 2;
-struct LazyExp { int e; };                 // exponent of the scale's ceiling (scale = 2^(140 - e)); < 0: not set yet
-
-__device__ __forceinline__ float pvs_lazy_tile_scale(const float (&v)[16], LazyExp& st, float* inv) {
-    int e_t = (int)((pvs_wave_max_u32(__float_as_uint(pvs_absmax16(v))) >> 23) & 0xffu);
-    e_t = e_t < 16 ? 16 : e_t;
-    if (st.e < 0 || e_t > st.e || st.e - e_t > kLazyWindow) st.e = e_t + 1 > 254 ? 254 : e_t + 1;
-    *inv = __uint_as_float((unsigned)(st.e - 13) << 23);
-    return __uint_as_float((unsigned)(267 - st.e) << 23);
-}
-
-// the scale exponents an accumulator currently carries (operand G, operand Act); < 0: nothing accumulated yet
-struct AccExp { int eg, ea; };
-
-// Bring accumulator `a` (and the bias column of lanes j == col in gB) from the scale (cur) to (eg, ea).
-// Returns false when the tile's product is to be skipped (more than 2^60 below what the accumulator holds).
-__device__ __forceinline__ bool pvs_rescale_acc(f32x16& a, f32x16& gB, bool col_lane, AccExp& cur, int eg, int ea) {
-    if (cur.eg < 0) { cur.eg = eg; cur.ea = ea; return true; }
-    const int dg = cur.eg - eg, dw = dg + (cur.ea - ea);       // exponent of the ratio new scale / old scale
-    if (dw == 0 && dg == 0) return true;
-    if (dw > 60 || dg > 60) return false;
-    const float fw = dw < -60 ? 0.f : __uint_as_float((unsigned)(127 + dw) << 23);
-    const float fb = dg < -60 ? 0.f : __uint_as_float((unsigned)(127 + dg) << 23);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        a[r] *= fw;
-        gB[r] *= col_lane ? fb : 1.f;
-    }
-    cur.eg = eg; cur.ea = ea;
-    return true;
-}
-
 __device__ __forceinline__ void wgrad_tile_f16_acc(const unsigned short* __restrict__ g_img,
                                                    const unsigned short* __restrict__ act_img,
                                                    const unsigned* __restrict__ ones, int lane, f32x16& gW, f32x16& gB) {
@@ -179,9 +147,7 @@ __device__ __forceinline__ void wgrad_tile_f16_acc(const unsigned short* __restr
 #define F16_WGRAD(...) wgrad_tile_f16(__VA_ARGS__)
 #define F16_WGRAD_ACC(...) wgrad_tile_f16_acc(__VA_ARGS__)
 #endif
-#ifndef PVS_LAZY_WSCALE
-#define PVS_LAZY_WSCALE 1
-#endif
+
 
 struct F16Cfg {
     static constexpr int kThreadsPerBlock = 512;                          // two waves per SIMD

@@ -538,6 +538,56 @@ __device__ __forceinline__ void mfma_chain_f16x2_blocks(const unsigned* __restri
     }
 }
 
+// ---- lazily moving tile scales (round 4; edge_bwd_f16.hip "weight gradients accumulated IN the matrix core's
+// accumulator" explains why). H = 32 backward only: in the 512-register kernels (H = 64, the wide team backward) the
+// weight-gradient accumulators live in the accumulator half of the register file, and the rescaling branch - vector
+// instructions that touch them inside the tile loop - makes the allocator move them out of it: the wide backward went
+// from 25-163 to 145-237 spilled VGPRs with this scheme (the same wall as profiles/r03_h64_backward_f16x2_rejected.txt) ----
+#ifndef PVS_LAZY_WSCALE
+#define PVS_LAZY_WSCALE 1
+#endif
+constexpr int kLazyWindow = 2;
+struct LazyExp { int e; };                 // exponent of the scale's ceiling (scale = 2^(140 - e)); < 0: not set yet
+
+// (max_bits: the fp32 bit pattern of the tile's - or the team's - largest magnitude, wave-uniform)
+__device__ __forceinline__ float pvs_lazy_scale_from_max(unsigned max_bits, LazyExp& st, float* inv) {
+    int e_t = (int)((max_bits >> 23) & 0xffu);
+    e_t = e_t < 16 ? 16 : e_t;
+    if (st.e < 0 || e_t > st.e || st.e - e_t > kLazyWindow) st.e = e_t + 1 > 254 ? 254 : e_t + 1;
+    *inv = __uint_as_float((unsigned)(st.e - 13) << 23);
+    return __uint_as_float((unsigned)(267 - st.e) << 23);
+}
+__device__ __forceinline__ float pvs_lazy_tile_scale(const float (&v)[16], LazyExp& st, float* inv) {
+    return pvs_lazy_scale_from_max(pvs_wave_max_u32(__float_as_uint(pvs_absmax16(v))), st, inv);
+}
+
+// the scale exponents an accumulator currently carries (operand G, operand Act); < 0: nothing accumulated yet
+struct AccExp { int eg, ea; };
+
+// Bring accumulator `a` (and the bias column of lanes j == col in gB) from the scale (cur) to (eg, ea).
+// Returns false when the tile's product is to be skipped (more than 2^60 below what the accumulator holds).
+template <int NB>
+__device__ __forceinline__ bool pvs_rescale_acc(f32x16 (&a)[NB], f32x16& gB, bool col_lane, AccExp& cur, int eg, int ea) {
+    if (cur.eg < 0) { cur.eg = eg; cur.ea = ea; return true; }
+    const int dg = cur.eg - eg, dw = dg + (cur.ea - ea);       // exponent of the ratio new scale / old scale
+    if (dw == 0 && dg == 0) return true;
+    if (dw > 60 || dg > 60) return false;
+    const float fw = dw < -60 ? 0.f : __uint_as_float((unsigned)(127 + dw) << 23);
+    const float fb = dg < -60 ? 0.f : __uint_as_float((unsigned)(127 + dg) << 23);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[b][r] *= fw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gB[r] *= col_lane ? fb : 1.f;
+    cur.eg = eg; cur.ea = ea;
+    return true;
+}
+__device__ __forceinline__ bool pvs_rescale_acc(f32x16& a, f32x16& gB, bool col_lane, AccExp& cur, int eg, int ea) {
+    return pvs_rescale_acc<1>(reinterpret_cast<f32x16 (&)[1]>(a), gB, col_lane, cur, eg, ea);
+}
+
+
 // tile scale of an H = 32*HB channel operand (all blocks share one scale)
 template <int HB>
 __device__ __forceinline__ float pvs_tile_scale_blocks(const float (&v)[HB][16], float* inv) {
