@@ -155,8 +155,9 @@ struct F16Cfg {
     static constexpr int kTS = kH + 4;                                    // g_z1 tile row stride (floats)
     // per wave: a1 image, m image, gradient image (4 KB each), SiLU'(z1) (4 KB)
     static constexpr int kWaveBytes = 3 * kImg2 * 2 + 16 * 64 * 4;
-    // shared: W2 and Wc1 images (hi + lo), tables, two ones columns, 4 words of weight maxima
-    static constexpr int kSharedBytes = 2 * kImg2 * 2 + (5 + PVS_MAX_EDGE_ATTR) * kH * 4 + 2 * 64 * 16 + 16;
+    // shared: W2 and Wc1 images (hi + lo), tables, two ones columns, 4 words of weight maxima, one all-zero image
+    // (what a weight-gradient product reads in place of an operand it must not add: pvs_rescale_acc)
+    static constexpr int kSharedBytes = 2 * kImg2 * 2 + (5 + PVS_MAX_EDGE_ATTR) * kH * 4 + 2 * 64 * 16 + 16 + kImg2 * 2;
     static_assert(kTile * kTS * 4 + kTile * 16 + kTile * 4 <= 2 * kImg2 * 2, "g_z1 tile + tx + rowbuf must fit the m + gradient images");
 };
 
@@ -183,7 +184,8 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
     unsigned* ones0 = reinterpret_cast<unsigned*>(attrt + PVS_MAX_EDGE_ATTR * H);   // [64 lanes][4]: fp16 ones, column 0 (g_bc1)
     unsigned* ones1 = ones0 + 64 * 4;               // ... column 1 (g_b2)
     unsigned* wmax = ones1 + 64 * 4;                // [0]: max |W2|, [1]: max |Wc1| (fp32 bits)
-    char* wave_base = reinterpret_cast<char*>(wmax + 4);
+    unsigned short* ZI = reinterpret_cast<unsigned short*>(wmax + 4);      // kImg2 shorts of zeros
+    char* wave_base = reinterpret_cast<char*>(ZI + kImg2);
 
     const bool upd = (flags & PVS_UPDATE_COORDS) && io.gxagg != nullptr;
 
@@ -206,6 +208,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
         for (int t = 0; t < PVS_MAX_EDGE_ATTR; ++t)
             attrt[t * H + c] = t < w.n_attr ? w.w1[c * w.ld1 + w.off_rho + 1 + t] : 0.f;
     }
+    for (int i = threadIdx.x; i < kImg2 / 2; i += NT) reinterpret_cast<unsigned*>(ZI)[i] = 0u;
     for (int i = threadIdx.x; i < 64 * 4; i += NT) {
         const int col = (i >> 2) & 31;
         ones0[i] = col == 0 ? 0x3c003c00u : 0u;      // fp16 1.0 pairs
@@ -254,7 +257,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
     // (LAZY) scale exponents of the four operand images and what the accumulators carry
     constexpr bool LAZY = PVS_LAZY_WSCALE && !EATT;
     LazyExp x_a1{-1}, x_m{-1}, x_g{-1}, x_g2{-1};
-    AccExp x_w2{-1, -1}, x_wc1{-1, -1};
+    AccUnits u_w2{-1}, u_b2{-1}, u_wc1{-1}, u_bc1{-1};
 
     const int total_waves = gridDim.x * NW;
     for (int chunk = pvs_xcd_block(blockIdx.x, gridDim.x) * NW + wv; chunk < n_chunks; chunk += total_waves) {
@@ -484,7 +487,9 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 pvs_wave_lds_sync();                                  // the m and g_zc images are complete
                 // gWc1 += g_zc (x) m ; g_bc1 += sum_e g_zc
                 if constexpr (LAZY) {
-                    if (pvs_rescale_acc(gWc1, gB, j == 0, x_wc1, x_g.e, x_m.e)) F16_WGRAD_ACC(GI, MI, ones0, lane, gWc1, gB);
+                    const int what = pvs_rescale_acc(gWc1, gB, j == 0, u_wc1, u_bc1, x_g.e, x_m.e);
+                    // (an operand whose product is not to be added is read from the all-zero image instead)
+                    if (what) F16_WGRAD_ACC(GI, (what & 1) ? MI : ZI, (what & 2) ? ones0 : reinterpret_cast<unsigned*>(ZI), lane, gWc1, gB);
                 } else {
                     F16_WGRAD(GI, MI, ones0, lane, inv_sg * inv_sm, inv_sg, gWc1, gB);
                 }
@@ -540,7 +545,8 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             chain_f16<true>(W2i, lane, pb, ga1);
             pvs_wave_lds_sync();                                      // the a1 and g_z2 images are complete
             if constexpr (LAZY) {
-                if (pvs_rescale_acc(gW2, gB, j == 1, x_w2, x_g2.e, x_a1.e)) F16_WGRAD_ACC(GI, A1I, ones1, lane, gW2, gB);
+                const int what = pvs_rescale_acc(gW2, gB, j == 1, u_w2, u_b2, x_g2.e, x_a1.e);
+                if (what) F16_WGRAD_ACC(GI, (what & 1) ? A1I : ZI, (what & 2) ? ones1 : reinterpret_cast<unsigned*>(ZI), lane, gW2, gB);
             } else {
                 F16_WGRAD(GI, A1I, ones1, lane, inv_sg2 * inv_sa1, inv_sg2, gW2, gB);
             }
@@ -593,14 +599,17 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
     __syncthreads();
     float* slab = smem;
     for (int i = threadIdx.x; i < L.total; i += NT) slab[i] = 0.f;
-    if constexpr (LAZY) {       // the accumulators back to true values: two exact power-of-two factors each
-        auto pw = [](int e) { return e < 0 ? 1.f : __uint_as_float((unsigned)(e - 13) << 23); };     // 1 / scale
-        const float a2 = pw(x_w2.eg), b2 = pw(x_w2.ea), ac = pw(x_wc1.eg), bc = pw(x_wc1.ea);
+    if constexpr (LAZY) {       // the accumulators back to true values: an exact power of two each (in two factors:
+        // 1 / (s_G s_Act) = 2^(units - 280), units = the sum of two exponents in [17, 254], need not be a normal float)
+        auto pw = [](int u, int n) { return u < 0 ? 1.f : __uint_as_float((unsigned)(n ? u - u / 2 - 13 : u / 2 - 13) << 23); };
+        const float a2 = pw(u_w2.cur(), 0), b2 = pw(u_w2.cur(), 1), ac = pw(u_wc1.cur(), 0), bc = pw(u_wc1.cur(), 1);
+        const float kb2 = u_b2.cur() < 0 ? 1.f : __uint_as_float((unsigned)(u_b2.cur() - 13) << 23);
+        const float kbc = u_bc1.cur() < 0 ? 1.f : __uint_as_float((unsigned)(u_bc1.cur() - 13) << 23);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             gW2[r] = gW2[r] * a2 * b2;
             gWc1[r] = gWc1[r] * ac * bc;
-            gB[r] *= j == 0 ? ac : (j == 1 ? a2 : 1.f);
+            gB[r] *= j == 0 ? kbc : (j == 1 ? kb2 : 1.f);
         }
     }
     __syncthreads();

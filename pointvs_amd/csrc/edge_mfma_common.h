@@ -557,34 +557,82 @@ __device__ __forceinline__ float pvs_lazy_scale_from_max(unsigned max_bits, Lazy
     *inv = __uint_as_float((unsigned)(st.e - 13) << 23);
     return __uint_as_float((unsigned)(267 - st.e) << 23);
 }
+// The scale stays while  e_t <= st.e  and  st.e - e_t <= kLazyWindow  (e_t = the wave maximum's exponent, at least 16):
+// that is "every lane's maximum is below 2^(st.e - 126) and some lane's is at least 2^(st.e - kLazyWindow - 127)" - two
+// compares of the lanes' OWN maxima against wave-uniform bit patterns (round 5). The wave-wide maximum (four DPP steps,
+// four v_readlane and the scalar work behind them) is only formed on the tiles where the scale moves; same decisions, same
+// scales, bit for bit.
 __device__ __forceinline__ float pvs_lazy_tile_scale(const float (&v)[16], LazyExp& st, float* inv) {
-    return pvs_lazy_scale_from_max(pvs_wave_max_u32(__float_as_uint(pvs_absmax16(v))), st, inv);
+    const unsigned m = __float_as_uint(pvs_absmax16(v));
+    const unsigned hi = (unsigned)(st.e + 1) << 23;
+    const unsigned lo = st.e - kLazyWindow <= 16 ? 0u : (unsigned)(st.e - kLazyWindow) << 23;
+    if (st.e < 0 || __ballot(m >= hi) != 0ull || __ballot(m >= lo) == 0ull)
+        return pvs_lazy_scale_from_max(pvs_wave_max_u32(m), st, inv);
+    *inv = __uint_as_float((unsigned)(st.e - 13) << 23);
+    return __uint_as_float((unsigned)(267 - st.e) << 23);
 }
 
-// the scale exponents an accumulator currently carries (operand G, operand Act); < 0: nothing accumulated yet
-struct AccExp { int eg, ea; };
+// What an accumulator that lives in MFMA registers carries. Its content is  true value x 2^(-units)  up to a fixed
+// offset, units = the sum of the exponents of its operand images' scale ceilings (LazyExp.e; the bias column: of the
+// gradient image alone). `cur` = the units it is in now; `top` = the COARSEST units (largest magnitudes) it has been in
+// since it (re)started; cur < 0: nothing accumulated yet. Wave-uniform, in scalar registers.
+// (one scalar register: cur in the low half, top in the high half - the H = 32 backward has no scalar register to spare)
+struct AccUnits {
+    int v;
+    __device__ __forceinline__ int cur() const { return v < 0 ? -1 : (v & 0xffff); }
+    __device__ __forceinline__ int top() const { return v >> 16; }
+    __device__ __forceinline__ void set(int cur_, int top_) { v = cur_ | (top_ << 16); }
+};
+constexpr int kAccSpan = 60;
 
-// Bring accumulator `a` (and the bias column of lanes j == col in gB) from the scale (cur) to (eg, ea).
-// Returns false when the tile's product is to be skipped (more than 2^60 below what the accumulator holds).
+// Decide what happens to an accumulator when the next tile's product comes in `units`:
+//   0  skip the tile: it lies more than 2^kAccSpan below the coarsest tile accumulated so far - below the fp32
+//      resolution of the sum (a tile's largest operand entries fill [2^11, 2^14) of their image, so its product sums
+//      are comparable to the accumulator's content in the same units);
+//   1  accumulate, after multiplying the accumulator by *factor (an exact power of two, 2^-120 ... 2^120; 1 when the
+//      units did not move; 0 = restart: the tile lies more than 2^kAccSpan ABOVE everything accumulated so far).
+// The window is measured from `top`, not from `cur` (round 5): measured from the current units, a run of tiles that
+// each step DOWN by less than the span multiplied the content by the product of all the steps (2^150 over three steps
+// of 2^-50: infinity), and a restart could drop content that an earlier, coarser tile had left. From `top` the content
+// is never scaled up by more than 2^kAccSpan in total and a restart drops only what is 2^-60 of the new tile.
+__device__ __forceinline__ int pvs_acc_step(AccUnits& st, int units, float* factor) {
+    *factor = 1.f;
+    if (st.v < 0) { st.set(units, units); return 1; }
+    const int cur = st.cur(), top = st.top();
+    if (units == cur) return 1;
+    if (top - units > kAccSpan) return 0;
+    if (units - top > kAccSpan) { st.set(units, units); *factor = 0.f; return 1; }
+    *factor = __uint_as_float((unsigned)(127 + cur - units) << 23);
+    st.set(units, units > top ? units : top);
+    return 1;
+}
+
+// The weight-gradient accumulator(s) `a` (operands G and Act) and the bias column that rides in lanes `col_lane` of gB
+// (operand G alone) are brought to the scales (eg, ea) of the tile's images SEPARATELY (one shared decision
+// dropped a tile's bias sums whenever its ACTIVATION image alone was far below the accumulator's - an all-zero m tile
+// beside ordinary ones - and could skip where the bias column had to restart).
+// Returns bit 0: issue the weight-gradient MFMAs, bit 1: issue the bias-column MFMAs.
 template <int NB>
-__device__ __forceinline__ bool pvs_rescale_acc(f32x16 (&a)[NB], f32x16& gB, bool col_lane, AccExp& cur, int eg, int ea) {
-    if (cur.eg < 0) { cur.eg = eg; cur.ea = ea; return true; }
-    const int dg = cur.eg - eg, dw = dg + (cur.ea - ea);       // exponent of the ratio new scale / old scale
-    if (dw == 0 && dg == 0) return true;
-    if (dw > 60 || dg > 60) return false;
-    const float fw = dw < -60 ? 0.f : __uint_as_float((unsigned)(127 + dw) << 23);
-    const float fb = dg < -60 ? 0.f : __uint_as_float((unsigned)(127 + dg) << 23);
+__device__ __forceinline__ int pvs_rescale_acc(f32x16 (&a)[NB], f32x16& gB, bool col_lane, AccUnits& uw, AccUnits& ub,
+                                               int eg, int ea) {
+    if (uw.cur() == eg + ea && ub.cur() == eg) return 3;      // (the common case: no scale moved)
+    float fw, fb;
+    const int do_w = pvs_acc_step(uw, eg + ea, &fw), do_b = pvs_acc_step(ub, eg, &fb);
+    if (do_w && fw != 1.f) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[b][r] *= fw;
+            for (int r = 0; r < 16; ++r) a[b][r] *= fw;
+    }
+    if (do_b && fb != 1.f) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) gB[r] *= col_lane ? fb : 1.f;
-    cur.eg = eg; cur.ea = ea;
-    return true;
+        for (int r = 0; r < 16; ++r) gB[r] *= col_lane ? fb : 1.f;
+    }
+    return do_w | (do_b << 1);
 }
-__device__ __forceinline__ bool pvs_rescale_acc(f32x16& a, f32x16& gB, bool col_lane, AccExp& cur, int eg, int ea) {
-    return pvs_rescale_acc<1>(reinterpret_cast<f32x16 (&)[1]>(a), gB, col_lane, cur, eg, ea);
+__device__ __forceinline__ int pvs_rescale_acc(f32x16& a, f32x16& gB, bool col_lane, AccUnits& uw, AccUnits& ub, int eg,
+                                               int ea) {
+    return pvs_rescale_acc<1>(reinterpret_cast<f32x16 (&)[1]>(a), gB, col_lane, uw, ub, eg, ea);
 }
 
 

@@ -13,7 +13,13 @@ for hid in (32, 64):
     for name, flags in (('default', {}), ('attention', ATT)):
         for R in (0, 6, 12, 20):
             rec = dynamic_range_errors(hid, flags, R)
+            for pname, err in rec['f16x2']['param_grads'].items():     # per tensor, relative to its own largest entry
+                e32 = rec['fp32']['param_grads'][pname]
+                print(f'H={hid:3d} {name:9s} range 2^+-{R:<2d} grad {pname:36s} f16x2 {err:9.2e}   fp32 family {e32:9.2e}   '
+                      f'ratio {err / max(e32, 1e-30):7.2f}')
             for tensor in rec['f16x2']:
+                if tensor == 'param_grads':
+                    continue
                 a, b = rec['f16x2'][tensor], rec['fp32'][tensor]
                 print(f'H={hid:3d} {name:9s} range 2^+-{R:<2d} {tensor:15s} f16x2 {a[0]:9.2e} ({a[1]:8.2e})   '
                       f'fp32 family {b[0]:9.2e} ({b[1]:8.2e})   ratio {a[0] / max(b[0], 1e-30):7.2f}')
