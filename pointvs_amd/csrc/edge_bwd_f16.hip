@@ -20,6 +20,18 @@
 // Reference semantics: autograd of EGNNLayer.edge_model / coord_model / node_model's aggregation,
 // /root/reference/point_vs/models/geometric/egnn_satorras.py:123-206 (SURVEY.md §8a "Backward spec").
 #include "edge_mfma_common.h"
+#ifndef PVS_SA_IDX
+#define PVS_SA_IDX 0
+#endif
+#ifndef PVS_SA_GATHER
+#define PVS_SA_GATHER 0
+#endif
+#ifndef PVS_SA_ROW
+#define PVS_SA_ROW 0
+#endif
+#ifndef PVS_SA_STORE
+#define PVS_SA_STORE 0
+#endif
 
 namespace {
 
@@ -271,7 +283,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
         auto flush = [&](int row_id) {
             if (row_id >= 0) {
                 const float4 tot = sum_row_slots<1>(acc);
-                if (rsub == 0) *reinterpret_cast<float4*>(io.gPQ + (size_t)row_id * 2 * H + 4 * quad) = tot;
+                if (rsub == 0) *reinterpret_cast<float4*>(PVS_SA_STORE ? pvs_off(io.gPQ + (size_t)row_id * 2 * H, 16u * quad) : io.gPQ + (size_t)row_id * 2 * H + 4 * quad) = tot;
                 const float4 tx4 = sum_row_slots<1>(accx);
                 if (lane == 0) {
                     io.gx_row[3 * row_id] = tx4.x;
@@ -300,7 +312,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
         // only what comes out of memory is carried from tile to tile (4 registers); e / ee / valid are recomputed
         struct Loaded { int i, jn, ty, prev_row; };
         auto load_idx = [&](int start, int end) {
-            const TileIdx t = load_tile_idx(g, w.n_attr, start, e_begin, end, j);
+            const TileIdx t = PVS_SA_IDX ? load_tile_idx32(g, w.n_attr, start, e_begin, end, j) : load_tile_idx(g, w.n_attr, start, e_begin, end, j);
             return Loaded{t.i, t.jn, t.ty, t.prev_row};
         };
         Loaded I = load_idx(e_begin, t_end);
@@ -327,7 +339,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 TileGather<1> G;
                 TileIdx Ig;
                 Ig.i = I.i; Ig.jn = I.jn;
-                gather_tile<1>(io.PQ, io.x, Ig, hh, G);
+                if (PVS_SA_GATHER) gather_tile32<1>(io.PQ, io.x, Ig, hh, G); else gather_tile<1>(io.PQ, io.x, Ig, hh, G);
                 d0 = G.d0; d1 = G.d1; d2 = G.d2;
                 rho = d0 * d0 + d1 * d1 + d2 * d2;
                 float a1[1][16];
@@ -383,7 +395,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 #pragma unroll
             for (int r = 0; r < 16; ++r) gm[r] = 0.f;
             float gMi[1][16];
-            auto load_row_terms = [&]() { load_x<1>(io.gM + (size_t)i * H, hh, gMi); };
+            auto load_row_terms = [&]() { if (PVS_SA_ROW) load_x<1>(pvs_off(io.gM, (unsigned)i * (4u * H) + 16u * hh), 0, gMi); else load_x<1>(io.gM + (size_t)i * H, hh, gMi); };
             // Edge attention: everything that needs the message itself - the logit, m . g_M, the gate's gradient g_l
             // and its weight gradient g_wa += g_l m - is evaluated HERE, while m is live anyway; two scalars (the gate
             // value and g_l) cross the coordinate branch and m dies with its split, as in the plain kernel. The g_M
@@ -439,7 +451,8 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             float s_coord = 0.f, nrm = 1.f;
             float gT0 = 0.f, gT1 = 0.f, gT2 = 0.f;
             if (upd) {
-                gT0 = io.gxagg[3 * i]; gT1 = io.gxagg[3 * i + 1]; gT2 = io.gxagg[3 * i + 2];
+                const float* gT = PVS_SA_ROW ? pvs_off(io.gxagg, 12u * (unsigned)i) : io.gxagg + 3 * i;
+                gT0 = gT[0]; gT1 = gT[1]; gT2 = gT[2];
                 const float sm = LAZY ? pvs_lazy_tile_scale(m[0], x_m, &inv_sm) : pvs_tile_scale(m[0], &inv_sm);
                 split_f16x2(m[0], sm, pb);
                 write_image_f16(MI, j, hh, pb);
@@ -488,8 +501,9 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 // gWc1 += g_zc (x) m ; g_bc1 += sum_e g_zc
                 if constexpr (LAZY) {
                     const int what = pvs_rescale_acc(gWc1, gB, j == 0, u_wc1, u_bc1, x_g.e, x_m.e);
-                    // (an operand whose product is not to be added is read from the all-zero image instead)
-                    if (what) F16_WGRAD_ACC(GI, (what & 1) ? MI : ZI, (what & 2) ? ones0 : reinterpret_cast<unsigned*>(ZI), lane, gWc1, gB);
+                    // (an operand whose product is not to be added is read from the all-zero image instead: the product
+                    // itself is never inside a branch, so that its MFMAs can be scheduled among the vector work behind it)
+                    F16_WGRAD_ACC(GI, (what & 1) ? MI : ZI, (what & 2) ? ones0 : reinterpret_cast<unsigned*>(ZI), lane, gWc1, gB);
                 } else {
                     F16_WGRAD(GI, MI, ones0, lane, inv_sg * inv_sm, inv_sg, gWc1, gB);
                 }
@@ -546,7 +560,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             pvs_wave_lds_sync();                                      // the a1 and g_z2 images are complete
             if constexpr (LAZY) {
                 const int what = pvs_rescale_acc(gW2, gB, j == 1, u_w2, u_b2, x_g2.e, x_a1.e);
-                if (what) F16_WGRAD_ACC(GI, (what & 1) ? A1I : ZI, (what & 2) ? ones1 : reinterpret_cast<unsigned*>(ZI), lane, gW2, gB);
+                F16_WGRAD_ACC(GI, (what & 1) ? A1I : ZI, (what & 2) ? ones1 : reinterpret_cast<unsigned*>(ZI), lane, gW2, gB);
             } else {
                 F16_WGRAD(GI, A1I, ones1, lane, inv_sg2 * inv_sa1, inv_sg2, gW2, gB);
             }
@@ -570,8 +584,14 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             if (hh == 0) {
                 *reinterpret_cast<float4*>(tx + j * 4) = make_float4(gd0, gd1, gd2, 0.f);
                 rowbuf[j] = i;
-                if (valid)
-                    pvs_store_nt(io.gd + (size_t)PVS_ABL_SCR(e) * 4, make_float4(gd0, gd1, gd2, pvs_pack_rho_type(rho, ty)));
+                if (valid) {
+#if defined(PVS_ABL_F_SCATTER) || !PVS_SA_STORE
+                    float* gd_at = io.gd + (size_t)PVS_ABL_SCR(e) * 4;
+#else
+                    float* gd_at = pvs_off(io.gd + (size_t)e0 * 4, 16u * j);       // (e0 is wave-uniform: a scalar base)
+#endif
+                    pvs_store_nt(gd_at, make_float4(gd0, gd1, gd2, pvs_pack_rho_type(rho, ty)));
+                }
             }
             // ---- g_z1 edge-major, then whole rows to HBM + the row-side sums from the same reads ----
 #pragma unroll
@@ -582,8 +602,14 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 #ifndef PVS_ABL_F_NOREDUCE
             reduce_rows_tile<1>(T1, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
                                 [&](int rl, int q, const float4& v) {
-                                    if (e0 + rl < e_this_end)   // streamed once: non-temporal
-                                        pvs_store_nt(io.gz1 + (size_t)PVS_ABL_SCR(e0 + rl) * H + 4 * q, v);
+                                    if (e0 + rl < e_this_end) {  // streamed once: non-temporal
+#if defined(PVS_ABL_F_SCATTER) || !PVS_SA_STORE
+                                        float* at = io.gz1 + (size_t)PVS_ABL_SCR(e0 + rl) * H + 4 * q;
+#else
+                                        float* at = pvs_off(io.gz1 + (size_t)e0 * H, (unsigned)rl * (4u * H) + 16u * q);
+#endif
+                                        pvs_store_nt(at, v);
+                                    }
                                 });
 #endif
             I = In;

@@ -7,6 +7,7 @@
 #include "profile.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -172,6 +173,38 @@ __device__ __forceinline__ TileIdx load_tile_idx(const PvsGraph& g, int n_attr, 
     return t;
 }
 
+// ---- 32-bit lane offsets (round 5) -----------------------------------------------------------------------------------
+// base + (size_t)index * stride makes the compiler form a 64-bit address PER LANE (a sign extension and a
+// v_lshl_add_u64 per access, two registers per live address: 37 vector instructions and ten kernel-lifetime registers in
+// the H = 32 backward's tile loop). A wave-uniform base (kernel argument, or argument + a wave-uniform element offset,
+// formed in scalar registers) plus an UNSIGNED 32-bit byte offset selects the `global_load v, v_off, s[base:base+1]`
+// form instead: one register and at most one instruction per address. Callers bound the offsets: node tables below
+// 2^32 bytes (the launchers check N), per-edge arrays addressed relative to the tile's first edge.
+#ifndef PVS_SADDR
+#define PVS_SADDR 1
+#endif
+template <class T>
+__device__ __forceinline__ T* pvs_off(T* base, unsigned bytes) {
+    if (!PVS_SADDR) return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(base)) + (long long)(int)bytes);
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(base)) + bytes);
+}
+
+// load_tile_idx with 32-bit offsets (the same values)
+__device__ __forceinline__ TileIdx load_tile_idx32(const PvsGraph& g, int n_attr, int e0, int e_begin, int e_end, int j) {
+    TileIdx t;
+    t.e = e0 + j;
+    t.valid = t.e < e_end;
+    t.ee = t.valid ? t.e : e_end - 1;
+    t.ee = min(max(t.ee, 0), g.n_edges - 1);
+    const unsigned o = 4u * (unsigned)t.ee;
+    t.i = *pvs_off(g.row, o);
+    t.jn = *pvs_off(g.col, o);
+    if (n_attr & 0x100) { t.i &= 7; t.jn &= 7; }   // ablation: every gather hits 8 hot rows
+    t.ty = (n_attr & 0xff) ? (int)*pvs_off(g.etype, (unsigned)t.ee) : 0;
+    t.prev_row = (t.ee == e_begin || t.ee == 0) ? -1 : *pvs_off(g.row, o - 4u);
+    return t;
+}
+
 // Gathered node data of one tile in X layout: P_i and Q_j rows, coordinate difference.
 template <int HB>
 struct TileGather {
@@ -197,6 +230,29 @@ __device__ __forceinline__ void gather_tile(const float* __restrict__ PQ, const 
     G.d0 = x[3 * t.i] - x[3 * t.jn];
     G.d1 = x[3 * t.i + 1] - x[3 * t.jn + 1];
     G.d2 = x[3 * t.i + 2] - x[3 * t.jn + 2];
+}
+
+// gather_tile with 32-bit offsets (node tables below 2^32 bytes)
+template <int HB>
+__device__ __forceinline__ void gather_tile32(const float* __restrict__ PQ, const float* __restrict__ x,
+                                              const TileIdx& t, int hh, TileGather<HB>& G) {
+    constexpr int H = 32 * HB;
+    const float* Pp = pvs_off(PQ, (unsigned)t.i * (8u * H) + 16u * hh);
+    const float* Qp = pvs_off(PQ, (unsigned)t.jn * (8u * H) + 4u * H + 16u * hh);
+#pragma unroll
+    for (int b = 0; b < HB; ++b)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 p = *reinterpret_cast<const float4*>(Pp + 32 * b + 8 * gq);
+            const float4 q = *reinterpret_cast<const float4*>(Qp + 32 * b + 8 * gq);
+            G.P[b][4 * gq] = p.x; G.P[b][4 * gq + 1] = p.y; G.P[b][4 * gq + 2] = p.z; G.P[b][4 * gq + 3] = p.w;
+            G.Q[b][4 * gq] = q.x; G.Q[b][4 * gq + 1] = q.y; G.Q[b][4 * gq + 2] = q.z; G.Q[b][4 * gq + 3] = q.w;
+        }
+    const float* xi = pvs_off(x, 12u * (unsigned)t.i);
+    const float* xj = pvs_off(x, 12u * (unsigned)t.jn);
+    G.d0 = xi[0] - xj[0];
+    G.d1 = xi[1] - xj[1];
+    G.d2 = xi[2] - xj[2];
 }
 
 // z1 = P_i + Q_j + w_rho * rho + W_a[type]  (X layout)
@@ -566,7 +622,10 @@ __device__ __forceinline__ float pvs_lazy_tile_scale(const float (&v)[16], LazyE
     const unsigned m = __float_as_uint(pvs_absmax16(v));
     const unsigned hi = (unsigned)(st.e + 1) << 23;
     const unsigned lo = st.e - kLazyWindow <= 16 ? 0u : (unsigned)(st.e - kLazyWindow) << 23;
-    if (st.e < 0 || __ballot(m >= hi) != 0ull || __ballot(m >= lo) == 0ull)
+#ifndef PVS_WINDOW_CHECK
+#define PVS_WINDOW_CHECK 1
+#endif
+    if (!PVS_WINDOW_CHECK || st.e < 0 || __ballot(m >= hi) != 0ull || __ballot(m >= lo) == 0ull)
         return pvs_lazy_scale_from_max(pvs_wave_max_u32(m), st, inv);
     *inv = __uint_as_float((unsigned)(st.e - 13) << 23);
     return __uint_as_float((unsigned)(267 - st.e) << 23);
