@@ -48,11 +48,11 @@ FP32_PEAK_TFLOPS = 157.3   # fp32 vector = fp32 MFMA peak
 
 
 # what "dtype": "f32" means on this path: inputs, outputs, every accumulation and all
-# elementwise work are fp32; the matrix products run on the 16-bit matrix pipes with each fp32 operand split into
-# exact parts - three bf16 parts and six partial products (error O(2^-25 |a||b|)), or, round 3, two fp16 parts
-# under a per-tile power-of-two scale and three partial products (O(2^-22 |a||b|), between bf16x3 and a sequential
-# fp32 FMA chain: tools/f16x2_numerics.py) - accumulated in fp32; parity at 1e-5 relative against the fp64 oracle
-# at BASELINE size is part of the GPU suite
+# elementwise work are fp32; the per-edge matrix products run on the 16-bit matrix pipes with each fp32 operand split
+# into parts - two fp16 parts under a power-of-two scale and three partial products (H = 32 forward and backward, H = 64
+# forward: O(2^-22 |a||b|), between a sequential fp32 FMA chain and bf16x3: tools/f16x2_numerics.py), or three bf16
+# parts and six partial products (H = 64 backward: O(2^-25 |a||b|)) - accumulated in fp32; parity at 1e-5 relative
+# against the fp64 oracle at BASELINE size is part of the GPU suite
 ARITHMETIC = ('fp32 I/O, accumulation and elementwise work; no reduced-precision storage. Per-edge matrix products on the '
               'matrix cores with fp32 accumulation: H=32 forward and backward and H=64 forward as 3-term fp16 products '
               '(two fp16 parts per operand = 22 bits, power-of-two operand scales: per EDGE in the forward, per 32-edge '
@@ -67,6 +67,13 @@ def _kernel_ms(lib, name):
     tot, cnt = C.c_double(0.0), C.c_int64(0)
     rc = lib.pvs_profile_read(name.encode(), C.byref(tot), C.byref(cnt))
     return (tot.value, cnt.value) if rc == 0 else (0.0, 0)
+
+
+def _kernel_each(lib, name, cap=4096):
+    """Per-launch milliseconds of one profiled kernel group, in launch order (pvs_profile_read_each)."""
+    buf, cnt = (C.c_double * cap)(), C.c_int64(0)
+    rc = lib.pvs_profile_read_each(name.encode(), buf, cap, C.byref(cnt))
+    return [buf[k] for k in range(min(cnt.value, cap))] if rc == 0 else []
 
 
 def scaling_note(args, world, strong):
@@ -145,18 +152,29 @@ def measured_limiter(config, kernel):
     """What the dominant kernel waits for, from the newest SQ counter summary of the same command
     (tools/pmc_sq.sh + tools/pmc_summary.py -> profiles/rNN_<config>_pmc_sq.txt; like `traffic`, a PMC pass cannot run
     inside this process): VALU busy and matrix-pipe busy as fractions of SIMD time, the share of a wave's cycles spent
-    in s_waitcnt. `bound: "hbm"` and `frac` keep SURVEY 8d's definition; these fields say what actually binds."""
+    in s_waitcnt. `bound: "hbm"` and `frac` keep SURVEY 8d's definition; these fields say what actually binds.
+    `limiter` is DERIVED from the parsed shares: every resource above its threshold (VALU or matrix pipe
+    busy >= 50 % of SIMD time, a wave parked in s_waitcnt >= 30 % of its cycles), else the largest share; the shares are
+    those of the build the file was measured on (`limiter_source`, `limiter_commit` when the file records one), not of
+    this run."""
     import re
     for pfile in sorted((ROOT / 'profiles').glob(f'r[0-9][0-9]_{config}_pmc_sq.txt'), reverse=True):
-        for line in pfile.read_text().splitlines():
+        text = pfile.read_text()
+        commit = re.search(r'^commit:\s*(\S+)', text, re.M)
+        for line in text.splitlines():
             if line.strip().startswith(kernel) and 'VALU busy' in line:
                 m = re.search(r'VALU busy (\d+)% of SIMD time, matrix pipe (\d+)%.*?issuing (\d+)%, issue-stalled (\d+)%, '
                               r'in s_waitcnt (\d+)%', line)
                 if m:
                     valu, mat, issuing, stalled, wait = (int(g) / 100.0 for g in m.groups())
-                    return {'limiter': 'valu_issue+wave_stalls', 'valu_busy': valu, 'matrix_busy': mat,
-                            'waitcnt_share': wait, 'issue_stalled_share': stalled, 'limiter_source': pfile.name}
-    return {'limiter': None, 'valu_busy': None, 'matrix_busy': None, 'waitcnt_share': None, 'limiter_source': None}
+                    shares = {'valu_issue': valu, 'matrix_pipe': mat, 'wave_stalls': wait}
+                    over = [k for k, lim in (('valu_issue', 0.5), ('matrix_pipe', 0.5), ('wave_stalls', 0.3)) if shares[k] >= lim]
+                    label = '+'.join(over) if over else max(shares, key=shares.get)
+                    return {'limiter': label, 'valu_busy': valu, 'matrix_busy': mat,
+                            'waitcnt_share': wait, 'issue_stalled_share': stalled, 'limiter_source': pfile.name,
+                            'limiter_commit': commit.group(1) if commit else None}
+    return {'limiter': None, 'valu_busy': None, 'matrix_busy': None, 'waitcnt_share': None, 'limiter_source': None,
+            'limiter_commit': None}
 
 
 def visible_gpu_count(topology='/sys/class/kfd/kfd/topology/nodes'):
@@ -402,10 +420,8 @@ def screening_bench(args, rank, world, dev):
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_screening(cfg, lig, rec, feats)
-        print(json.dumps(out), flush=True)
-    if getattr(args, 'distributed', world > 1):
-        dist.barrier()
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 def main():
@@ -413,9 +429,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg5'],
+    ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg5', 'real4A'],
                     help='cfg5: virtual-screening sweep (BASELINE config 5): forward only, random poses '
-                         'of one ligand against one receptor, graphs built on the GPU per batch')
+                         'of one ligand against one receptor, graphs built on the GPU per batch; real4A: NOT a BASELINE '
+                         'configuration - the reference\'s default CLI shape (6 layers, 32 channels, r = 4 A, ~500 atoms '
+                         'per graph: the launch-bound regime; compare --graph 0 and --graph 1)')
     ap.add_argument('--batch', type=int, default=None,
                     help='graphs per GPU (default 32; cfg5: poses per replayed step, default 128 - the sweep streams '
                          'one ligand\'s poses in fixed-size batches of its choosing: 24.5k / 26.2k / 27.7k / 26.8k poses/s '
@@ -429,6 +447,10 @@ def main():
                     help='let the model skip the last layer\'s coordinate update, whose result nothing reads '
                          '(the library default); the bench evaluates it by default, like the reference does')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='default cfg2 run only: do not also time BASELINE configs 3 and 5 behind the headline (the '
+                         '"secondary" object of the line); implied by --no-cpu-baseline, the flag of every profiling and '
+                         'A/B invocation under tools/ (a kernel trace of ONE configuration)')
     ap.add_argument('--model-flags', default='',
                     help='NOT a BASELINE configuration: extra model keywords on top of --config, e.g. '
                          '"edge_residual=True,tanh=True" (profiles of kernel instantiations no BASELINE config uses); '
@@ -497,19 +519,67 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.config == 'cfg5':
+        out = screening_bench(args, rank, world, dev)
+    else:
+        out = training_bench(args, rank, world, dev)
+        plain = not (args.infer or args.model_flags or args.build_graph or args.host_inputs or strong or args.force_dist
+                     or args.graph or args.skip_dead_coords or args.batch != 32)
+        if args.config == 'cfg2' and world == 1 and plain and not (args.no_secondary or args.no_cpu_baseline):
+            sec = secondary_configs(args, rank, world, dev)
+            if out is not None:
+                out['secondary'] = sec
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def secondary_configs(args, rank, world, dev):
+    """BASELINE configs 3 and 5 in the SAME process as the headline line, behind its timed region (VERDICT r04 item 2:
+    the driver runs only `bench.py --gpus 1 --steps 20 --warmup 5`, so these two were builder-run numbers only):
+    cfg3 = 10 timed steps of the 12-layer / 64-channel / edge + node attention model, cfg5 = a 12,800-pose sweep (the
+    per-GPU share of BASELINE's 100k poses over 8 GPUs) with the step replayed from a hipGraph. Same code paths as
+    `--config cfg3` / `--config cfg5 --sweep 12800`; the full records of those invocations are in profiles/."""
+    import copy
+    import gc
+    sec = {}
+    for name, changes in (('cfg3', dict(config='cfg3', steps=10, warmup=3, batch=32, graph=0)),
+                          ('cfg5', dict(config='cfg5', sweep=12800, warmup=1, batch=128, graph=1))):
+        gc.collect()
+        torch.cuda.empty_cache()
+        a = copy.copy(args)
+        for k, v in changes.items():
+            setattr(a, k, v)
+        a.no_cpu_baseline = True
+        rec = screening_bench(a, rank, world, dev) if name == 'cfg5' else training_bench(a, rank, world, dev)
+        if rec is None:
+            continue
+        roof = rec['roofline']
+        sec[name] = {'metric': rec['metric'], 'value': rec['value'], 'unit': rec['unit'], 'steps': rec['steps'],
+                     'warmup': rec['warmup'], 'ms_per_step': rec['ms_per_step'], 'workload': rec['config']['workload'],
+                     'roofline': {k: roof.get(k) for k in ('kernel', 'bound', 'frac', 'achieved', 'avg_launch_ms',
+                                                           'avg_launch_ms_full_work', 'frac_full_work', 'launches',
+                                                           'algorithmic_bytes_per_launch', 'kernel_ms_per_step')}}
+    return sec
+
+
+def training_bench(args, rank, world, dev):
+    """One training (or --infer) configuration: returns the record on rank 0, None elsewhere."""
     from pointvs_amd import _lib, graph as pgraph
     from pointvs_amd.distributed import OverlappedGradAllReducer
     from pointvs_amd.egnn_satorras import SartorrasEGNN
     from pointvs_amd.synthetic import CONFIGS, synthetic_batch
-
-    if args.config == 'cfg5':
-        return screening_bench(args, rank, world, dev)
+    distributed = args.distributed
+    strong = args.global_batch > 0
     cfg = CONFIGS[args.config]
     if args.model_flags:
         import ast
         extra = {k.strip(): ast.literal_eval(v.strip()) for k, v in (kv.split('=', 1) for kv in args.model_flags.split(','))}
         cfg = dict(cfg, model=dict(cfg['model'], **extra))
     lib = _lib.lib()
+    cache_was = pgraph.CACHE_ENABLED
     pgraph.CACHE_ENABLED = False        # every step prepares its batch, as a fresh batch would
 
     # ---- inputs: this rank's graphs, built on the host, then resident in HBM ----
@@ -614,6 +684,7 @@ def main():
         elapsed = time.perf_counter() - t0
         lib.pvs_profile_enable(0)
         dom_live = None if use_graph else _kernel_ms(lib, dom_group)      # (total ms, launches) of the timed region
+        dom_each = [] if use_graph else _kernel_each(lib, dom_group)
         # the per-step breakdown (every group), eager, behind the timed region
         lib.pvs_profile_reset()
         lib.pvs_profile_enable(1)
@@ -622,11 +693,14 @@ def main():
             eager_step()
         torch.cuda.synchronize(dev)
         lib.pvs_profile_enable(0)
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    rank_ms = [elapsed / args.steps * 1e3]
+    if distributed:     # the contract's value uses the MAX over ranks; min / max per rank make a straggler visible
+        every = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(every, torch.tensor([elapsed], dtype=torch.float64, device=dev))
+        rank_ms = [float(v.item()) / args.steps * 1e3 for v in every]
+        elapsed = max(float(v.item()) for v in every)
     final_loss = float(loss.item())
+    pgraph.CACHE_ENABLED = cache_was
 
     def kernel_ms(name):
         return _kernel_ms(lib, name)
@@ -643,7 +717,7 @@ def main():
         col_ms, col_n = kernel_ms('col_gather')
         prep_ms, prep_n = kernel_ms('graph_prepare')
         if training:     # dominant kernel: the edge backward (one launch per layer)
-            dom_ms, dom_n = dom_live if dom_live else (bwd_ms, bwd_n)
+            dom_ms, dom_n = dom_live if dom_live and dom_live[1] > 0 else (bwd_ms, bwd_n)
             dom_bytes = algorithmic_bytes_edge_bwd(n_nodes, n_edges, h)
             dom_flops = (12.0 * h * h + 4 * h) * n_edges     # 2 recompute + 2 dgrad + 2 wgrad products
             fp32_family = os.environ.get('PVS_EGNN_BF16X3') == '0'
@@ -652,7 +726,7 @@ def main():
             dom_name = (f'{dom_symbol} (H={h} edge backward, one launch per layer)')
             step_bytes = layers * algorithmic_bytes_per_layer(n_nodes, n_edges, h)
         else:            # forward only: the edge forward
-            dom_ms, dom_n = dom_live if dom_live else (fwd_ms, fwd_n)
+            dom_ms, dom_n = dom_live if dom_live and dom_live[1] > 0 else (fwd_ms, fwd_n)
             dom_bytes = algorithmic_bytes_edge_fwd(n_nodes, n_edges, h)
             dom_flops = (4.0 * h * h + 2 * h) * n_edges
             dom_symbol = 'k_edge_fwd_mfma'
@@ -661,12 +735,19 @@ def main():
         dom_avg_ms = dom_ms / max(dom_n, 1)
         achieved = dom_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
         dom_tflops = dom_flops / (dom_avg_ms * 1e-3) / 1e12 if dom_avg_ms > 0 else 0.0
+        # The launches of one step do not do the same work: the backward runs the layers last to first, and nothing
+        # differentiates the last layer's coordinate update (its x is dead: SURVEY Q3, the reference's autograd skips
+        # it too), so the FIRST backward launch of every step has no coordinate branch. `avg_launch_ms` is over all
+        # launches (the contract's definition); `avg_launch_ms_full_work` leaves those lighter launches out.
+        full = [ms for k, ms in enumerate(dom_each) if k % layers != 0] if (training and layers > 1) else []
+        full_avg_ms = sum(full) / len(full) if full else None
         ref_flops = algorithmic_flops_per_step(n_nodes, n_edges, h, 3, layers, eatt, natt, training)
         exec_flops = executed_flops_per_step(n_nodes, n_edges, h, layers, eatt, natt, training)
         traffic, traffic_src = measured_traffic(args.config, dom_symbol)
         what = 'forward only (inference)' if args.infer else 'fwd+bwd (+Adam step)'
-        shape = ('3-layer EGNN ch=32, ~2k nodes r=10A' if args.config == 'cfg2' else
-                 '12-layer EGNN ch=64 edge+node attention, ~2k nodes r=6A')
+        shape = {'cfg2': '3-layer EGNN ch=32, ~2k nodes r=10A',
+                 'cfg3': '12-layer EGNN ch=64 edge+node attention, ~2k nodes r=6A',
+                 'real4A': 'NOT A BASELINE CONFIGURATION: 6-layer EGNN ch=32, ~500 nodes r=4A (reference CLI defaults)'}[args.config]
         out = {
             'metric': f'protein-ligand graphs/sec {what}, {shape}',
             'value': round(graphs_per_s, 2), 'unit': 'graphs/s', 'n_gpus': world,
@@ -685,6 +766,14 @@ def main():
                        'graphs_per_gpu': args.batch, 'global_batch': world * args.batch,
                        'parallelism': f'dp{world}', 'final_loss': round(final_loss, 6),
                        'arithmetic': ARITHMETIC,
+                       # self-diagnosis of a multi-rank run: what the process group really is, and
+                       # every rank's own step time beside the max the value is computed from
+                       'rccl_world': dist.get_world_size() if distributed else 1,
+                       'dist_backend': dist.get_backend() if distributed else None,
+                       'rccl_version': ('.'.join(str(v) for v in torch.cuda.nccl.version())
+                                        if distributed and dist.get_backend() == 'nccl' else None),
+                       'rank_ms_per_step': {'min': round(min(rank_ms), 3), 'max': round(max(rank_ms), 3),
+                                            'all': [round(v, 3) for v in rank_ms]},
                        'scaling_note': scaling_note(args, world, strong),
                        'last_layer_coord_update': 'skipped (dead)' if args.skip_dead_coords else 'evaluated',
                        'launch': 'hipGraph replay of the whole step' if use_graph else 'eager',
@@ -702,10 +791,12 @@ def main():
                 **measured_limiter(args.config, dom_symbol),
                 'algorithmic_bytes_per_launch': dom_bytes,
                 'avg_launch_ms': round(dom_avg_ms, 4), 'launches': dom_n,
+                'avg_launch_ms_full_work': None if full_avg_ms is None else round(full_avg_ms, 4),
+                'frac_full_work': None if not full_avg_ms else round(dom_bytes / (full_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 # the kernel is ALU-bound, not HBM-bound: its EXECUTED products against the
-                # fp32 matrix peak, beside the HBM fraction north_star asks for. Four of the six products
-                # run as bf16x3 on the bf16 pipe, so this is an effective fp32 rate, not a utilisation:
-                # the PMC busy figures in profiles/ are the utilisation
+                # fp32 matrix peak, beside the HBM fraction north_star asks for. The products run as three fp16
+                # terms (H = 32) or six bf16 terms (H = 64 backward) on the 16-bit matrix pipes, so this is an
+                # effective fp32 rate, not a utilisation: the PMC busy figures in profiles/ are the utilisation
                 'kernel_exec_fp32': {'achieved': round(dom_tflops, 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                      'frac': round(dom_tflops / FP32_PEAK_TFLOPS, 5)},
                 'step_hbm_frac': round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -721,10 +812,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)
-        print(json.dumps(out), flush=True)
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 if __name__ == '__main__':

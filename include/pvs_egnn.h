@@ -381,6 +381,10 @@ int pvs_segment_reduce_bwd(const float* g_out, const int64_t* ids, const int32_t
 int pvs_profile_enable(int on);
 int pvs_profile_reset(void);
 int pvs_profile_read(const char* kernel, double* total_ms, int64_t* launches);
+/* The same records one by one, in launch order: ms[0 .. min(*launches, cap)) = the duration of each recorded launch of
+ * the group, *launches = how many were recorded (bench.py: the launches of one step do different amounts of work - the
+ * last layer's backward has no coordinate branch - and the line states the full-work average beside the overall one). */
+int pvs_profile_read_each(const char* kernel, double* ms, int64_t cap, int64_t* launches);
 
 #ifdef __cplusplus
 }

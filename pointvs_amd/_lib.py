@@ -108,6 +108,7 @@ _PROTOTYPES = {
     'pvs_profile_enable': (C.c_int, [C.c_int]),
     'pvs_profile_reset': (C.c_int, []),
     'pvs_profile_read': (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    'pvs_profile_read_each': (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int64)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

@@ -67,3 +67,22 @@ extern "C" int pvs_profile_read(const char* kernel, double* total_ms, int64_t* l
     *launches = n;
     return 0;
 }
+
+extern "C" int pvs_profile_read_each(const char* kernel, double* out_ms, int64_t cap, int64_t* launches) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int id = -1;
+    for (int i = 0; i < PVS_PROF_COUNT; ++i)
+        if (strcmp(kernel, kNames[i]) == 0) id = i;
+    if (id < 0) return -1;
+    int64_t n = 0;
+    for (Rec* r : g_recs) {
+        if (r->id != id) continue;
+        if (hipEventSynchronize(r->b) != hipSuccess) return -2;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r->a, r->b) != hipSuccess) return -2;
+        if (n < cap && out_ms) out_ms[n] = ms;
+        ++n;
+    }
+    *launches = n;
+    return 0;
+}

@@ -93,4 +93,15 @@ CONFIGS = {
                             permutation_invariance=False, node_attention=True,
                             gated_residual=False, rezero=False, softmax_attention=False,
                             model_task='classification')),
+    # NOT a BASELINE configuration: the reference's own default CLI shape (parse_args.py:56,67,152: 32 channels, 6
+    # layers, edge_radius 4 A; BASELINE config 1's real graphs have ~500 atoms and ~11 edges per atom) - the launch-bound
+    # regime (bench.py --config real4A; ~100 launches per step of a few microseconds each). The generator's density of
+    # 0.05 atoms / A^3 gives E / N = 11.2 at r = 4 A.
+    'real4A': dict(cfg_id=6, graph=dict(n_nodes=500, n_lig=30, edge_radius=4.0),
+                   model=dict(dim_input=12, k=32, dim_output=1, num_layers=6, residual=False,
+                              edge_residual=False, edge_attention=False, normalize=False, tanh=False,
+                              dropout=0.0, graphnorm=False, update_coords=True,
+                              permutation_invariance=False, node_attention=False,
+                              gated_residual=False, rezero=False, softmax_attention=False,
+                              model_task='classification')),
 }
