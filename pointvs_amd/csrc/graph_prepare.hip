@@ -581,6 +581,46 @@ size_t carve_runs(PvsArena& a, int N, int E, int B, int max_graph_nodes, RunsWs*
     return a.off;
 }
 
+// Exclusive prefix sum of n int32 by ONE workgroup (round 5): the two scans of the merge route are over N + 1 = 64,001
+// degrees at BASELINE size - 256 KB that one CU reads and writes from L2 in a few microseconds, against two launches each
+// of the library scan (its look-back state needs an init kernel). Thread t owns a contiguous slice; slice totals are
+// scanned over the workgroup (wave scans + the 16 wave totals through LDS). Larger tables keep the library scan.
+constexpr int kSmallScanMax = 1 << 17;
+__global__ void __launch_bounds__(1024) k_exclusive_scan_small(const int32_t* __restrict__ in, int32_t* __restrict__ out, int n) {
+    __shared__ int32_t wave_tot[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(t * per, n), hi = min(lo + per, n);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += in[i];
+    int inc = s;                                   // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wv; ++k) base += wave_tot[k];
+    int run = base + inc - s;
+    for (int i = lo; i < hi; ++i) {
+        const int v = in[i];
+        out[i] = run;
+        run += v;
+    }
+}
+
+int exclusive_scan_i32(hipStream_t stream, void* tmp, size_t tmp_bytes, const int32_t* in, int32_t* out, int n) {
+    if (n <= kSmallScanMax) {
+        k_exclusive_scan_small<<<1, 1024, 0, stream>>>(in, out, n);
+        PVS_CHECK_LAUNCH();
+        return 0;
+    }
+    PVS_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, in, out, n, stream));
+    return 0;
+}
+
 }  // namespace
 
 extern "C" size_t pvs_graph_prepare_runs_workspace_bytes(int32_t n_nodes, int32_t n_edges, int32_t n_graphs,
@@ -626,8 +666,7 @@ extern "C" int pvs_graph_prepare_runs(const int64_t* edge_index, const int64_t* 
     k_run_starts<<<(N + T - 1) / T, T, 0, stream>>>(w.row32, N, E, n_graphs, status, node_ptr, edge_ptr, w.split, w.start_a,
                                                     w.start_b, w.cnt_a, w.deg, inv_deg);
     PVS_CHECK_LAUNCH();
-    size_t sb = w.scan_bytes;
-    PVS_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(w.scan_tmp, sb, w.deg, rowptr, N + 1, stream));
+    if (int rc = exclusive_scan_i32(stream, w.scan_tmp, w.scan_bytes, w.deg, rowptr, N + 1)) return rc;
     if (E > 0) {
         k_place_runs<<<(E + T - 1) / T, T, 0, stream>>>(w.row32, w.col32, w.etype_in, E, n_graphs, edge_ptr, w.split,
                                                         rowptr, w.start_a, w.start_b, w.cnt_a, row, col,
@@ -654,8 +693,7 @@ extern "C" int pvs_graph_prepare_runs(const int64_t* edge_index, const int64_t* 
         }
         k_csc_totals<<<(N + 1 + T - 1) / T, T, 0, stream>>>(w.csc_cnt, N, n_graphs, node_ptr, cpg, stride, w.indeg, status);
         PVS_CHECK_LAUNCH();
-        sb = w.scan_bytes;
-        PVS_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(w.scan_tmp, sb, w.indeg, colptr, N + 1, stream));
+        if (int rc = exclusive_scan_i32(stream, w.scan_tmp, w.scan_bytes, w.indeg, colptr, N + 1)) return rc;
         if (E > 0) {
             k_csc_bases<<<(N + T - 1) / T, T, 0, stream>>>(w.csc_cnt, N, n_graphs, node_ptr, cpg, stride, colptr);
             PVS_CHECK_LAUNCH();

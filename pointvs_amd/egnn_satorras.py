@@ -473,8 +473,11 @@ class SartorrasEGNN(PNNGeometricBase):
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             rank = torch.distributed.get_rank()
         seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * rank) & (2 ** 64 - 1)
+        # (epochs, optimiser steps, calls) -> ONE 64-bit step by a mix, not by packing bit fields (with
+        # fields, more than 255 forwards under one base - a loop that never bumps global_iter - carried into the next
+        # base's range, and 2^24 optimiser steps into the epoch field: masks could repeat)
         return PF.dropout_adj(edges, edge_attributes, p, force_undirected=True, training=True,
-                              seed=seed, step=(int(base) << 8) + self._dropout_calls)
+                              seed=seed, step=_mix64(_mix64(int(base)) + self._dropout_calls))
 
     def embed_prepared(self, pg, feats, coords, need_messages=False, trace=None, need_coords=True):
         """Layer stack on a PreparedGraph. Edge messages stay in sorted order between layers and
@@ -502,14 +505,26 @@ class SartorrasEGNN(PNNGeometricBase):
         edge_messages in the caller's edge order."""
         edges, edge_attributes = self.edge_dropout(edges, edge_attributes)
         pg = prepared_for(edges, edge_attributes, feats.size(0))
-        if batch is not None and torch.is_grad_enabled() and batch.numel() > 1:
+        if (batch is not None and torch.is_grad_enabled() and batch.numel() > 1 and not pg.c.graph_eptr
+                and not torch.cuda.is_current_stream_capturing()):
             # the batch vector names the graphs: tiles of the fp16-split backward end where a graph ends (one host
-            # sync for the number of graphs - the reference's forward has the same one, pnn_geometric_base.py:27)
+            # sync for the number of graphs - the reference's forward has the same one, pnn_geometric_base.py:27).
+            # Skipped when the PreparedGraph already knows its graphs (a cached one) and under hipGraph capture (a
+            # data-dependent shape; only accuracy across graphs of very different gradient magnitude is at stake).
+            # `batch` is the PyG batch vector: sorted, as Batch.from_data_list and the reference's loader build it.
             counts = torch.unique_consecutive(batch, return_counts=True)[1]
             pg.set_graph_ptr(torch.cat([counts.new_zeros(1), counts.cumsum(0)]))
         feats, _, m_sorted = self.embed_prepared(pg, feats, coords, need_messages=True, need_coords=False)
         edge_messages = None if m_sorted is None else PF.rows_to_input_order(m_sorted, pg)
         return feats, edge_messages
+
+
+def _mix64(x):
+    """splitmix64's finaliser: a bijection of 64-bit integers that spreads nearby inputs."""
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return x ^ (x >> 31)
 
 
 def unsorted_segment_sum(data, segment_ids, num_segments):

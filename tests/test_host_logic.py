@@ -308,6 +308,89 @@ def test_changed_gradient_set_raises_on_every_rank_gloo_world2():
     assert out[0] == [False, False, True] and out[1] == [False, False, True]
 
 
+def _straggler_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, str(ROOT))
+        import time
+        from pointvs_amd.distributed import GradAllReducer, OverlappedGradAllReducer
+        res = {}
+        for name in ('flat', 'overlap'):
+            torch.manual_seed(0)
+            net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.SiLU(), torch.nn.Linear(8, 8), torch.nn.SiLU(),
+                                      torch.nn.Linear(8, 8), torch.nn.SiLU(), torch.nn.Linear(8, 1))
+            params = list(net.parameters())
+            launched = []
+            if name == 'overlap':
+                if rank == 1:
+                    # rank 1's backward is slow where it matters: the hooks of the LAST layers (the first gradients
+                    # to land, the first bucket) run late, so rank 0 has launched bucket 0 - and reached reducer()
+                    # with the rest - long before rank 1 launches anything. Registered BEFORE the reducer's own
+                    # hooks: hooks of a parameter run in registration order.
+                    for p in params[-2:] + params[2:4]:
+                        p.register_post_accumulate_grad_hook(lambda _p: time.sleep(0.3))
+                red = OverlappedGradAllReducer(params, n_buckets=3)
+            else:
+                red = GradAllReducer(params)
+            steps = []
+            for step in range(4):
+                x = torch.randn(5, 6, generator=torch.Generator().manual_seed(10 * step + rank))
+                for p in params:
+                    p.grad = None
+                if name == 'overlap' and red._buckets is not None:
+                    import pointvs_amd.distributed as D
+                    orig = D._Bucket.launch
+
+                    def spy(self, weight, flag, group, _orig=orig, _red=red):
+                        launched.append(_red._buckets.index(self))
+                        return _orig(self, weight, flag, group)
+                    D._Bucket.launch = spy
+                    try:
+                        net(x).square().sum().backward()
+                        red()
+                    finally:
+                        D._Bucket.launch = orig
+                else:
+                    net(x).square().sum().backward()
+                    red()
+                steps.append([p.grad.clone() for p in params])
+            res[name] = steps
+            res[name + '_order'] = list(launched)
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_order_is_the_same_on_a_delayed_rank_gloo_world2():
+    """collectives are matched by ISSUE ORDER, so the buckets of the overlapped exchange must be
+    launched in one order on every rank however the ranks' backward passes are timed. Rank 1's gradient hooks are
+    delayed by 0.3 s each: both ranks must launch buckets 0, 1, 2 in that order on every step, finish within 60 s (no
+    hang) and hold the same reduced gradients - the flat exchange's."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    ctx = mp.start_processes(_straggler_worker, args=(2, port, out), nprocs=2, join=False, start_method='spawn')
+    import time
+    deadline = time.time() + 60
+    while not ctx.join(timeout=1.0):
+        if time.time() > deadline:
+            for p in ctx.processes:
+                p.kill()
+            raise AssertionError('the delayed-rank exchange did not finish within 60 s (ranks stuck in a collective)')
+    for rank in range(2):
+        assert out[rank]['overlap_order'] == [0, 1, 2] * 3, out[rank]['overlap_order']     # (step 0: the flat exchange)
+        for a, b in zip(out[rank]['flat'], out[rank]['overlap']):
+            for ga, gb in zip(a, b):
+                assert torch.allclose(ga, gb, atol=1e-6)
+    for a, b in zip(out[0]['overlap'], out[1]['overlap']):
+        for ga, gb in zip(a, b):
+            assert torch.equal(ga, gb)
+
+
 def test_fused_clip_adam_falls_back_to_torch_on_cpu_tensors():
     """No GPU here: FusedClipAdam must behave exactly like clip_grad_value_ + torch.optim.Adam."""
     from pointvs_amd.optim import FusedClipAdam
