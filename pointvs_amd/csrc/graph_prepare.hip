@@ -277,14 +277,14 @@ __global__ void k_run_starts(const int32_t* __restrict__ row32, int N, int E, in
                              const int32_t* __restrict__ status, const int32_t* __restrict__ node_ptr,
                              const int32_t* __restrict__ edge_ptr, const int32_t* __restrict__ split,
                              int32_t* __restrict__ start_a, int32_t* __restrict__ start_b, int32_t* __restrict__ cnt_a,
-                             int32_t* __restrict__ deg, float* __restrict__ inv_deg) {
+                             int32_t* __restrict__ rowptr, float* __restrict__ inv_deg) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
+    if (n == N - 1) rowptr[N] = E;
     if (*status & 4) {      // broken contract (all of it is known after k_extract_runs): a SAFE graph - every
         // edge a self-edge of node 0 - so that nothing downstream indexes out of bounds before the host raises
         start_a[n] = 0; start_b[n] = 0; cnt_a[n] = 0;
-        deg[n] = n == 0 ? E : 0;
-        if (n == N - 1) deg[N] = 0;
+        rowptr[n] = n == 0 ? 0 : E;
         inv_deg[n] = 1.0f;
         return;
     }
@@ -312,8 +312,9 @@ __global__ void k_run_starts(const int32_t* __restrict__ row32, int N, int E, in
     start_b[n] = sb;
     cnt_a[n] = sa_next - sa;
     const int d = (sa_next - sa) + (sb_next - sb);
-    deg[n] = d;
-    if (n == N - 1) deg[N] = 0;
+    // rowptr WITHOUT a prefix sum (round 5): the graph's edges fill [edge_ptr[g], edge_ptr[g + 1]) of the sorted list, and
+    // those in front of row n are the (sa - a0) edges of run A and the (sb - a1) edges of run B with a smaller row
+    rowptr[n] = a0 + (sa - a0) + (sb - a1);
     inv_deg[n] = 1.0f / (float)(d > 1 ? d : 1);
 }
 
@@ -495,46 +496,6 @@ __device__ __forceinline__ int csc_graph_of_node(const int32_t* __restrict__ nod
     return lo;
 }
 
-// indeg[n] = edges whose column is n (sum over the chunks of n's graph); indeg[N] = 0
-// (status bit 4 - a broken layout contract, final since k_extract_runs: every in-degree is 0, so colptr is all zeros
-// and nothing downstream follows cedge; the host raises at its next poll of the status word)
-__global__ void k_csc_totals(const int32_t* __restrict__ cnt, int N, int n_graphs, const int32_t* __restrict__ node_ptr,
-                             int cpg, int stride, int32_t* __restrict__ indeg, const int32_t* __restrict__ status) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n > N) return;
-    if (n == N || (*status & 4)) { indeg[n] = 0; return; }
-    const int g = csc_graph_of_node(node_ptr, n_graphs, n);
-    const int c = n - node_ptr[g];
-    int t0 = 0, t1 = 0, t2 = 0, t3 = 0;          // (cpg is a multiple of 4: independent loads in flight)
-    if (c >= 0 && c < stride) {                  // (c < 0: node_ptr[0] > n, a broken table - status bit 4)
-        const int32_t* src = cnt + (size_t)g * cpg * stride + c;
-        for (int k = 0; k < cpg; k += 4) {
-            t0 += src[(size_t)k * stride];
-            t1 += src[(size_t)(k + 1) * stride];
-            t2 += src[(size_t)(k + 2) * stride];
-            t3 += src[(size_t)(k + 3) * stride];
-        }
-    }
-    indeg[n] = (t0 + t1) + (t2 + t3);
-}
-
-// cnt[chunk][column] <- first cedge slot of that column's edges in that chunk
-__global__ void k_csc_bases(int32_t* __restrict__ cnt, int N, int n_graphs, const int32_t* __restrict__ node_ptr,
-                            int cpg, int stride, const int32_t* __restrict__ colptr) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const int g = csc_graph_of_node(node_ptr, n_graphs, n);
-    const int c = n - node_ptr[g];
-    if (c < 0 || c >= stride) return;
-    int run = colptr[n];
-    for (int k = 0; k < cpg; ++k) {
-        int32_t* slot = cnt + ((size_t)g * cpg + k) * stride + c;
-        const int t = *slot;
-        *slot = run;
-        run += t;
-    }
-}
-
 int csc_chunks_per_graph(int n_graphs) {      // a multiple of the waves per workgroup
     int cpg = kCscTargetChunks / (n_graphs > 0 ? n_graphs : 1);
     cpg = (cpg / kCscWaves) * kCscWaves;
@@ -581,44 +542,73 @@ size_t carve_runs(PvsArena& a, int N, int E, int B, int max_graph_nodes, RunsWs*
     return a.off;
 }
 
-// Exclusive prefix sum of n int32 by ONE workgroup (round 5): the two scans of the merge route are over N + 1 = 64,001
-// degrees at BASELINE size - 256 KB that one CU reads and writes from L2 in a few microseconds, against two launches each
-// of the library scan (its look-back state needs an init kernel). Thread t owns a contiguous slice; slice totals are
-// scanned over the workgroup (wave scans + the 16 wave totals through LDS). Larger tables keep the library scan.
-constexpr int kSmallScanMax = 1 << 17;
-__global__ void __launch_bounds__(1024) k_exclusive_scan_small(const int32_t* __restrict__ in, int32_t* __restrict__ out, int n) {
-    __shared__ int32_t wave_tot[16];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int per = (n + 1023) / 1024;
-    const int lo = min(t * per, n), hi = min(lo + per, n);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += in[i];
-    int inc = s;                                   // inclusive scan over the wave
+// indeg[n] = edges whose column is n (sum over the chunks of n's graph)
+// (status bit 4 - a broken layout contract, final since k_extract_runs: every in-degree is 0, so colptr is all zeros
+// and nothing downstream follows cedge; the host raises at its next poll of the status word)
+__global__ void k_csc_totals(const int32_t* __restrict__ cnt, int N, int n_graphs, const int32_t* __restrict__ node_ptr,
+                             int cpg, int stride, int32_t* __restrict__ indeg, const int32_t* __restrict__ status) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    if (*status & 4) { indeg[n] = 0; return; }
+    const int g = csc_graph_of_node(node_ptr, n_graphs, n);
+    const int c = n - node_ptr[g];
+    int t0 = 0, t1 = 0, t2 = 0, t3 = 0;          // (cpg is a multiple of 4: independent loads in flight)
+    if (c >= 0 && c < stride) {                  // (c < 0: node_ptr[0] > n, a broken table - status bit 4)
+        const int32_t* src = cnt + (size_t)g * cpg * stride + c;
+        for (int k = 0; k < cpg; k += 4) {
+            t0 += src[(size_t)k * stride];
+            t1 += src[(size_t)(k + 1) * stride];
+            t2 += src[(size_t)(k + 2) * stride];
+            t3 += src[(size_t)(k + 3) * stride];
+        }
+    }
+    indeg[n] = (t0 + t1) + (t2 + t3);
+}
+
+// colptr and the per-chunk first slots WITHOUT a device-wide prefix sum (round 5; before: a library scan of the N + 1
+// in-degrees = two launches, then k_csc_bases). A graph's columns hold exactly the graph's edges, which fill
+// [edge_ptr[g], edge_ptr[g + 1]) of every sorted list, so colptr[n] = edge_ptr[g] + the in-degrees of the graph's columns
+// in front of n: workgroup (bx, g) owns columns [256 bx, 256 bx + 256) of graph g (a graph has at most kCscMaxCols = 4096
+// here), sums the in-degrees in front of its slice (at most 16 per thread), scans its own 256, and turns
+// cnt[chunk][column] into the first cedge slot of that column's edges in that chunk, as k_csc_bases did.
+__global__ void __launch_bounds__(256) k_csc_colptr(int32_t* __restrict__ cnt, const int32_t* __restrict__ indeg, int N, int E,
+                                                    int n_graphs, const int32_t* __restrict__ node_ptr,
+                                                    const int32_t* __restrict__ edge_ptr, int cpg, int stride,
+                                                    int32_t* __restrict__ colptr, const int32_t* __restrict__ status) {
+    __shared__ int32_t wave_tot[4], front_tot[4];
+    const int g = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (*status & 4) {
+        for (int i = (g * gridDim.x + blockIdx.x) * 256 + t; i <= N; i += gridDim.x * gridDim.y * 256) colptr[i] = 0;
+        return;
+    }
+    if (g == n_graphs - 1 && blockIdx.x == 0 && t == 0) colptr[N] = E;
+    const int n0 = node_ptr[g], width = min(node_ptr[g + 1] - n0, stride);
+    const int c0 = blockIdx.x * 256;
+    if (c0 >= width) return;
+    int front = 0;
+    for (int c = t; c < c0; c += 256) front += indeg[n0 + c];
+    const int c = c0 + t;
+    const int mine = c < width ? indeg[n0 + c] : 0;
+    int inc = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int up = __shfl_up(inc, o, 64);
         if (lane >= o) inc += up;
+        front += __shfl_xor(front, o, 64);
     }
     if (lane == 63) wave_tot[wv] = inc;
+    if (lane == 0) front_tot[wv] = front;
     __syncthreads();
-    int base = 0;
-    for (int k = 0; k < wv; ++k) base += wave_tot[k];
-    int run = base + inc - s;
-    for (int i = lo; i < hi; ++i) {
-        const int v = in[i];
-        out[i] = run;
+    int run = edge_ptr[g] + (front_tot[0] + front_tot[1]) + (front_tot[2] + front_tot[3]) + inc - mine;
+    for (int k = 0; k < wv; ++k) run += wave_tot[k];
+    if (c >= width) return;
+    colptr[n0 + c] = run;
+    for (int k = 0; k < cpg; ++k) {
+        int32_t* slot = cnt + ((size_t)g * cpg + k) * stride + c;
+        const int v = *slot;
+        *slot = run;
         run += v;
     }
-}
-
-int exclusive_scan_i32(hipStream_t stream, void* tmp, size_t tmp_bytes, const int32_t* in, int32_t* out, int n) {
-    if (n <= kSmallScanMax) {
-        k_exclusive_scan_small<<<1, 1024, 0, stream>>>(in, out, n);
-        PVS_CHECK_LAUNCH();
-        return 0;
-    }
-    PVS_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, in, out, n, stream));
-    return 0;
 }
 
 }  // namespace
@@ -664,9 +654,8 @@ extern "C" int pvs_graph_prepare_runs(const int64_t* edge_index, const int64_t* 
         PVS_CHECK_LAUNCH();
     }
     k_run_starts<<<(N + T - 1) / T, T, 0, stream>>>(w.row32, N, E, n_graphs, status, node_ptr, edge_ptr, w.split, w.start_a,
-                                                    w.start_b, w.cnt_a, w.deg, inv_deg);
+                                                    w.start_b, w.cnt_a, rowptr, inv_deg);
     PVS_CHECK_LAUNCH();
-    if (int rc = exclusive_scan_i32(stream, w.scan_tmp, w.scan_bytes, w.deg, rowptr, N + 1)) return rc;
     if (E > 0) {
         k_place_runs<<<(E + T - 1) / T, T, 0, stream>>>(w.row32, w.col32, w.etype_in, E, n_graphs, edge_ptr, w.split,
                                                         rowptr, w.start_a, w.start_b, w.cnt_a, row, col,
@@ -691,12 +680,12 @@ extern "C" int pvs_graph_prepare_runs(const int64_t* edge_index, const int64_t* 
         } else {
             PVS_CHECK_HIP(hipMemsetAsync(w.csc_cnt, 0, (size_t)waves * stride * sizeof(int32_t), stream));
         }
-        k_csc_totals<<<(N + 1 + T - 1) / T, T, 0, stream>>>(w.csc_cnt, N, n_graphs, node_ptr, cpg, stride, w.indeg, status);
+        k_csc_totals<<<(N + T - 1) / T, T, 0, stream>>>(w.csc_cnt, N, n_graphs, node_ptr, cpg, stride, w.indeg, status);
         PVS_CHECK_LAUNCH();
-        if (int rc = exclusive_scan_i32(stream, w.scan_tmp, w.scan_bytes, w.indeg, colptr, N + 1)) return rc;
+        k_csc_colptr<<<dim3((max_graph_nodes + 255) / 256, n_graphs), 256, 0, stream>>>(w.csc_cnt, w.indeg, N, E, n_graphs, node_ptr,
+                                                                                         edge_ptr, cpg, stride, colptr, status);
+        PVS_CHECK_LAUNCH();
         if (E > 0) {
-            k_csc_bases<<<(N + T - 1) / T, T, 0, stream>>>(w.csc_cnt, N, n_graphs, node_ptr, cpg, stride, colptr);
-            PVS_CHECK_LAUNCH();
             k_csc_pass<true><<<blocks, 64 * kCscWaves, lds, stream>>>(col, n_graphs, N, E, node_ptr, edge_ptr, cpg, stride,
                                                                        w.csc_cnt, cedge, status);
             PVS_CHECK_LAUNCH();
