@@ -268,7 +268,18 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
     float g_ba = 0.f, g_gate = 0.f;
     // (LAZY) scale exponents of the four operand images and what the accumulators carry
     constexpr bool LAZY = PVS_LAZY_WSCALE && !EATT;
-    LazyExp x_a1{-1}, x_m{-1}, x_g{-1}, x_g2{-1};
+    // (the four exponents share ONE scalar register, a byte each, 0 = not set yet: the kernel has no scalar register to
+    // spare, and a spilled one costs a v_readlane / v_writelane pair per use)
+    unsigned lazy_pack = 0u;
+    auto lazy_scale = [&](const float (&v)[16], int slot, float* inv) {
+        const int e = (int)((lazy_pack >> (8 * slot)) & 0xffu);
+        LazyExp st{e ? e : -1};
+        const float sc = pvs_lazy_tile_scale(v, st, inv);
+        lazy_pack = (lazy_pack & ~(0xffu << (8 * slot))) | ((unsigned)st.e << (8 * slot));
+        return sc;
+    };
+    auto lazy_e = [&](int slot) { return (int)((lazy_pack >> (8 * slot)) & 0xffu); };
+    constexpr int kXa1 = 0, kXm = 1, kXg = 2, kXg2 = 3;
     AccUnits u_w2{-1}, u_b2{-1}, u_wc1{-1}, u_bc1{-1};
 
     const int total_waves = gridDim.x * NW;
@@ -357,7 +368,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                     }
                     *reinterpret_cast<float4*>(d1b + (gq * 64 + lane) * 4) = make_float4(dd[0], dd[1], dd[2], dd[3]);
                 }
-                const float sa1 = LAZY ? pvs_lazy_tile_scale(a1[0], x_a1, &inv_sa1) : pvs_tile_scale(a1[0], &inv_sa1);
+                const float sa1 = LAZY ? lazy_scale(a1[0], kXa1, &inv_sa1) : pvs_tile_scale(a1[0], &inv_sa1);
                 split_f16x2(a1[0], sa1, pb);
                 write_image_f16(A1I, j, hh, pb);
                 f32x16 acc2;
@@ -453,7 +464,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             if (upd) {
                 const float* gT = PVS_SA_ROW ? pvs_off(io.gxagg, 12u * (unsigned)i) : io.gxagg + 3 * i;
                 gT0 = gT[0]; gT1 = gT[1]; gT2 = gT[2];
-                const float sm = LAZY ? pvs_lazy_tile_scale(m[0], x_m, &inv_sm) : pvs_tile_scale(m[0], &inv_sm);
+                const float sm = LAZY ? lazy_scale(m[0], kXm, &inv_sm) : pvs_tile_scale(m[0], &inv_sm);
                 split_f16x2(m[0], sm, pb);
                 write_image_f16(MI, j, hh, pb);
                 f32x16 accc;
@@ -487,7 +498,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                     g_wc2x[r] = fmaf(g_s, q[r], g_wc2x[r]);
                 }
                 float inv_sg;
-                const float sg_ = LAZY ? pvs_lazy_tile_scale(g_zc, x_g, &inv_sg) : pvs_tile_scale(g_zc, &inv_sg);
+                const float sg_ = LAZY ? lazy_scale(g_zc, kXg, &inv_sg) : pvs_tile_scale(g_zc, &inv_sg);
                 split_f16x2(g_zc, sg_, pb);
                 write_image_f16(GI, j, hh, pb);
                 f32x16 accg;
@@ -500,7 +511,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 pvs_wave_lds_sync();                                  // the m and g_zc images are complete
                 // gWc1 += g_zc (x) m ; g_bc1 += sum_e g_zc
                 if constexpr (LAZY) {
-                    const int what = pvs_rescale_acc(gWc1, gB, j == 0, u_wc1, u_bc1, x_g.e, x_m.e);
+                    const int what = pvs_rescale_acc(gWc1, gB, j == 0, u_wc1, u_bc1, lazy_e(kXg), lazy_e(kXm));
                     // (an operand whose product is not to be added is read from the all-zero image instead: the product
                     // itself is never inside a branch, so that its MFMAs can be scheduled among the vector work behind it)
                     F16_WGRAD_ACC(GI, (what & 1) ? MI : ZI, (what & 2) ? ones0 : reinterpret_cast<unsigned*>(ZI), lane, gWc1, gB);
@@ -549,7 +560,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             }
             // ---- g_a1 = W2^T g_z2 ; gW2 += g_z2 (x) a1 ; g_b2 += sum_e g_z2 ; g_z1 = g_a1 * SiLU'(z1) ----
             float inv_sg2;
-            const float sg2 = LAZY ? pvs_lazy_tile_scale(g_z2, x_g2, &inv_sg2) : pvs_tile_scale(g_z2, &inv_sg2);
+            const float sg2 = LAZY ? lazy_scale(g_z2, kXg2, &inv_sg2) : pvs_tile_scale(g_z2, &inv_sg2);
             split_f16x2(g_z2, sg2, pb);
             pvs_wave_lds_sync();                                      // the g_zc image has been read
             write_image_f16(GI, j, hh, pb);
@@ -559,7 +570,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             chain_f16<true>(W2i, lane, pb, ga1);
             pvs_wave_lds_sync();                                      // the a1 and g_z2 images are complete
             if constexpr (LAZY) {
-                const int what = pvs_rescale_acc(gW2, gB, j == 1, u_w2, u_b2, x_g2.e, x_a1.e);
+                const int what = pvs_rescale_acc(gW2, gB, j == 1, u_w2, u_b2, lazy_e(kXg2), lazy_e(kXa1));
                 F16_WGRAD_ACC(GI, (what & 1) ? A1I : ZI, (what & 2) ? ones1 : reinterpret_cast<unsigned*>(ZI), lane, gW2, gB);
             } else {
                 F16_WGRAD(GI, A1I, ones1, lane, inv_sg2 * inv_sa1, inv_sg2, gW2, gB);

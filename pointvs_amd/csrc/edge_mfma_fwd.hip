@@ -15,6 +15,12 @@
 //
 // Layout maps validated lane-by-lane in tools/mfma_layout_check.py.
 #include "edge_mfma_common.h"
+// Node gathers and index loads with a scalar base + 32-bit lane offset (pvs_off, edge_mfma_common.h): 1-2 spilled
+// registers fewer at both widths, cfg3's forward -0.9 %, cfg5 +1.7 % poses/s, cfg2 unchanged (round 5; the H = 32 BACKWARD
+// lost 14 % with the same change: its schedule, not the addressing - profiles/r05_ab_saddr_and_schedule.txt)
+#ifndef PVS_FWD_SADDR
+#define PVS_FWD_SADDR 1
+#endif
 
 namespace {
 
@@ -142,11 +148,13 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
         };
 
         // tile t+1's indices are loaded at the top of tile t (its node rows at its own start)
-        TileIdx I = load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_begin, e_begin, e_end, j);
+        TileIdx I = PVS_FWD_SADDR ? load_tile_idx32(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_begin, e_begin, e_end, j)
+                                  : load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_begin, e_begin, e_end, j);
         TileGather<HB> G;
         for (int e0 = e_begin; e0 < e_end; e0 += kTile) {
             const int e_next = (e0 + kTile < e_end) ? e0 + kTile : e0;
-            const TileIdx In = load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_next, e_begin, e_end, j);
+            const TileIdx In = PVS_FWD_SADDR ? load_tile_idx32(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_next, e_begin, e_end, j)
+                                             : load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_next, e_begin, e_end, j);
             const int e = I.e, ee = I.ee, i = I.i;
             const bool valid = I.valid;
             const unsigned long long ball = __ballot(valid && hh == 0 && i != I.prev_row);
@@ -157,7 +165,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                 d1 = io.x[3 * I.i + 1] - io.x[3 * I.jn + 1];
                 d2 = io.x[3 * I.i + 2] - io.x[3 * I.jn + 2];
             } else {
-                gather_tile<HB>(io.PQ, io.x, I, hh, G);
+                if (PVS_FWD_SADDR) gather_tile32<HB>(io.PQ, io.x, I, hh, G); else gather_tile<HB>(io.PQ, io.x, I, hh, G);
                 d0 = G.d0; d1 = G.d1; d2 = G.d2;
             }
             const float rho = d0 * d0 + d1 * d1 + d2 * d2;
@@ -348,6 +356,9 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
                              int att_act, const PvsEdgeFwdIO& io) {
     PVS_REQUIRE(w.n_attr <= PVS_MAX_EDGE_ATTR, "edge_attr classes %d > %d", w.n_attr,
                 PVS_MAX_EDGE_ATTR);
+    // (32-bit byte offsets into the node tables [N, 2H] fp32 and the edge index arrays: pvs_off)
+    PVS_REQUIRE((long long)g.n_nodes * 8 * H < (1ll << 32) && g.n_edges < (1 << 30),
+                "edge forward: N = %d nodes x %d channels or E = %d edges exceed the 32-bit offsets of this build", g.n_nodes, H, g.n_edges);
     // rows without edges are never flushed: M = 0, x_out = x
     if (!io.init_done) {
         const long long threads = (long long)g.n_nodes * (H / 4);

@@ -15,16 +15,23 @@ CSRC = Path(__file__).resolve().parent.parent / 'pointvs_amd' / 'csrc'
 HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
 
 # (source, extra flags as in the Makefile, mangled-name fragment, max VGPRs, max AGPRs, max spilled VGPRs)
-# The two forward kernels are compiled AT their occupancy step and spill a few loop-invariant values (3 / 8 VGPRs,
+# The two forward kernels are compiled AT their occupancy step and spill a few loop-invariant values (1 / 4 VGPRs,
 # reloaded once per tile: measured faster than one wave less); the bound is what is shipped, not a target.
 FWD = ['-fno-slp-vectorize', '-mllvm', '-amdgpu-mfma-vgpr-form=1']
 CASES = [
-    ('edge_bwd_f16.hip', [], 'k_edge_bwd_f16ILi0ELb0E', 256, 0, 0),
-    ('edge_mfma_fwd.hip', FWD, 'k_edge_fwd_mfmaILi1ELi256ELb0ELb1ELi0E', 128, 0, 3),
-    ('edge_mfma_fwd.hip', FWD, 'k_edge_fwd_mfmaILi2ELi768ELb0ELb1ELi0E', 168, 0, 8),
+    ('edge_bwd_f16.hip', [], 'k_edge_bwd_f16ILi0ELb0E', 256, 0, 0),      # (+ 2 scalar registers: see SGPR_SPILL_OK)
+    ('edge_mfma_fwd.hip', FWD, 'k_edge_fwd_mfmaILi1ELi256ELb0ELb1ELi0E', 128, 0, 1),
+    ('edge_mfma_fwd.hip', FWD, 'k_edge_fwd_mfmaILi2ELi768ELb0ELb1ELi0E', 168, 0, 4),
     ('edge_bwd_h64.hip', [], 'k_edge_bwd_h64ILi0ELb1E', 256, 256, 0),
     ('edge_bwd_h64.hip', [], 'k_edge_bwd_h64ILi0ELb0E', 256, 256, 0),
 ]
+
+
+# Scalar registers the compiler parks in lanes of a vector register (v_writelane / v_readlane). Round 5: the H = 32
+# backward keeps two more wave-uniform words (the units of its weight-gradient and bias accumulators, tracked separately)
+# and parks one kernel-argument pointer pair for the duration of the chunk loop: written once in front of it, read once
+# behind it, nothing inside the tile loop (checked in the ISA when the bound was set) and no vector register spilled.
+SGPR_SPILL_OK = {'k_edge_bwd_f16ILi0ELb0E': 2}
 
 
 def _report(src, flags):
@@ -53,6 +60,6 @@ def test_baseline_instantiations_fit_their_register_budget(src):
         hits = [v for k, v in kernels.items() if frag in k]
         assert len(hits) == 1, (frag, list(kernels))
         r = hits[0]
-        assert r['VGPRs Spill'] <= max_spill and r['SGPRs Spill'] == 0, (frag, r)
+        assert r['VGPRs Spill'] <= max_spill and r['SGPRs Spill'] <= SGPR_SPILL_OK.get(frag, 0), (frag, r)
         assert max_spill > 0 or r['ScratchSize [bytes/lane]'] == 0, (frag, r)
         assert r['VGPRs'] <= max_v and r['AGPRs'] <= max_a, (frag, r)
