@@ -164,7 +164,7 @@ __device__ __forceinline__ void wgrad_tile_f16_acc(const unsigned short* __restr
 struct F16Cfg {
     static constexpr int kThreadsPerBlock = 512;                          // two waves per SIMD
     static constexpr int kWavesPerBlock = kThreadsPerBlock / 64;
-    static constexpr int kTS = kH + 4;                                    // g_z1 tile row stride (floats)
+    static constexpr int kTS = kH;                                        // g_z1 tile: unpadded rows, rotated quads (pvs_tile_quad_off)
     // per wave: a1 image, m image, gradient image (4 KB each), SiLU'(z1) (4 KB)
     static constexpr int kWaveBytes = 3 * kImg2 * 2 + 16 * 64 * 4;
     // shared: W2 and Wc1 images (hi + lo), tables, two ones columns, 4 words of weight maxima, one all-zero image
@@ -601,17 +601,19 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 #else
                     float* gd_at = pvs_off(io.gd + (size_t)e0 * 4, 16u * j);       // (e0 is wave-uniform: a scalar base)
 #endif
+#ifndef PVS_ABL_F_NOGZ1      // timing-only: no per-edge outputs (what a column side fused into this kernel would not write)
                     pvs_store_nt(gd_at, make_float4(gd0, gd1, gd2, pvs_pack_rho_type(rho, ty)));
+#endif
                 }
             }
             // ---- g_z1 edge-major, then whole rows to HBM + the row-side sums from the same reads ----
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq)
-                *reinterpret_cast<float4*>(T1 + j * Cfg::kTS + 8 * gq + 4 * hh) =
+                *reinterpret_cast<float4*>(T1 + pvs_tile_quad_off<1>(j, 2 * gq + hh)) =
                     make_float4(g_z1[0][4 * gq], g_z1[0][4 * gq + 1], g_z1[0][4 * gq + 2], g_z1[0][4 * gq + 3]);
             pvs_wave_lds_sync();
 #ifndef PVS_ABL_F_NOREDUCE
-            reduce_rows_tile<1>(T1, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
+            reduce_rows_tile<1, false, true, true>(T1, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
                                 [&](int rl, int q, const float4& v) {
                                     if (e0 + rl < e_this_end) {  // streamed once: non-temporal
 #if defined(PVS_ABL_F_SCATTER) || !PVS_SA_STORE
@@ -619,7 +621,9 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 #else
                                         float* at = pvs_off(io.gz1 + (size_t)e0 * H, (unsigned)rl * (4u * H) + 16u * q);
 #endif
+#ifndef PVS_ABL_F_NOGZ1
                                         pvs_store_nt(at, v);
+#endif
                                     }
                                 });
 #endif

@@ -484,6 +484,9 @@ k_node_gather(PvsGraph g, const float* __restrict__ gz1, const float* __restrict
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 const bool ok = idx[u] >= 0;
+#ifdef PVS_ABL_NG_RESIDENT      // timing-only: every row from a 4 MB window (32k edges) that stays in the caches
+                if (ok) idx[u] &= 32767;
+#endif
                 v[u] = ok ? *reinterpret_cast<const float4*>(gz1 + (size_t)idx[u] * H + 4 * quad)
                           : make_float4(0.f, 0.f, 0.f, 0.f);
                 d[u] = ok ? *reinterpret_cast<const float4*>(gd4 + (size_t)idx[u] * 4)

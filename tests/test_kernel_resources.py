@@ -15,13 +15,13 @@ CSRC = Path(__file__).resolve().parent.parent / 'pointvs_amd' / 'csrc'
 HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
 
 # (source, extra flags as in the Makefile, mangled-name fragment, max VGPRs, max AGPRs, max spilled VGPRs)
-# The two forward kernels are compiled AT their occupancy step and spill a few loop-invariant values (1 / 4 VGPRs,
+# The two forward kernels are compiled AT their occupancy step and spill a few loop-invariant values (3 / 8 VGPRs,
 # reloaded once per tile: measured faster than one wave less); the bound is what is shipped, not a target.
 FWD = ['-fno-slp-vectorize', '-mllvm', '-amdgpu-mfma-vgpr-form=1']
 CASES = [
     ('edge_bwd_f16.hip', [], 'k_edge_bwd_f16ILi0ELb0E', 256, 0, 0),      # (+ 2 scalar registers: see SGPR_SPILL_OK)
-    ('edge_mfma_fwd.hip', FWD, 'k_edge_fwd_mfmaILi1ELi256ELb0ELb1ELi0E', 128, 0, 1),
-    ('edge_mfma_fwd.hip', FWD, 'k_edge_fwd_mfmaILi2ELi768ELb0ELb1ELi0E', 168, 0, 4),
+    ('edge_mfma_fwd.hip', FWD, 'k_edge_fwd_mfmaILi1ELi256ELb0ELb1ELi0E', 128, 0, 3),
+    ('edge_mfma_fwd.hip', FWD, 'k_edge_fwd_mfmaILi2ELi768ELb0ELb1ELi0E', 168, 0, 8),
     ('edge_bwd_h64.hip', [], 'k_edge_bwd_h64ILi0ELb1E', 256, 256, 0),
     ('edge_bwd_h64.hip', [], 'k_edge_bwd_h64ILi0ELb0E', 256, 256, 0),
 ]

@@ -50,9 +50,16 @@ def cycles(kind, addr):
     return total, len(gs)
 
 
-def img_off(r, c, H=32):
+def img_off_r04(r, c, H=32):
     nch, rpc = H // 4, 128 // H
     return r * H + 4 * ((c >> 2) ^ ((r // rpc) & (nch - 1))) + (c & 3)      # in shorts
+
+
+def img_off_r05(r, c, H=32):      # H = 32: swz(r) = bits (r2, r3, r1 ^ r4) of the row (edge_mfma_common.h img_off<1>)
+    return r * H + 4 * ((c >> 2) ^ (((r >> 2) & 3) | ((((r >> 1) ^ (r >> 4)) & 1) << 2))) + (c & 3)
+
+
+img_off = img_off_r04
 
 
 def report(name, kind, addr, per_tile):
@@ -110,7 +117,8 @@ def h32_backward(ts=36, swz_t1=False):
 
 
 if __name__ == '__main__':
-    print('== H = 32 backward (k_edge_bwd_f16), g_z1 tile stride 36 floats ==')
+    print('== H = 32 backward (k_edge_bwd_f16) as of round 4: image swizzle (r / 4) & 7, g_z1 tile stride 36 floats ==')
     h32_backward(36)
-    print('== the same with a 32-float stride and the quads of row r rotated by r & 7 ==')
+    print('== round 5: image swizzle bits (r2, r3, r1 ^ r4), g_z1 tile unpadded with the quads of row r rotated by r & 7 ==')
+    img_off = img_off_r05
     h32_backward(32, swz_t1=True)

@@ -18,7 +18,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 enum {
     FMA, FMAC, ADD, MUL, SUB, MAXF, MAX3, AND, MOV, CNDMASK, LDEXP, PKFMA, PKMUL, PKADD, EXP, RCP, MIXLO, MIXF32,
     CVTPK, CVTPKRTZ, CVTF32F16, CVTF32F16HI, CVTPKBF16, PERM, MOVDPP, PKFMA16, FMA2SRC, CMPCND, ADDU32, LSHLADD, LSHLADD64, MADU64,
-    SILU, SPLIT_MIX, SPLIT_CVT, SPLIT_NEW,
+    SILU, SPLIT_MIX, SPLIT_CVT, SPLIT_NEW, SIGPAIR_2RCP, SIGPAIR_1RCP,
     FMA_MFMA, PKFMA_MFMA, ADD_MFMA, EXP_MFMA, NMODES
 };
 const char* kNames[NMODES] = {
@@ -29,10 +29,11 @@ const char* kNames[NMODES] = {
     "v_fma_f32 (two distinct sources)", "v_cmp_lt_f32 + v_cndmask_b32 (vcc) /2", "v_add_u32_e32", "v_lshl_add_u32", "v_lshl_add_u64", "v_mad_u64_u32",
     "SiLU (mul exp add rcp mul) /5", "split pair, 4 fma_mix /4", "split pair, mul mul cvt_pk cvt cvt sub sub cvt_pk /8",
     "split pair, mul mul cvt_pk mix_f32 mix_f32 cvt_pk /6",
+    "two sigmoids, 2 x (mul exp add rcp): cycles per PAIR", "two sigmoids, ONE rcp: r = 1/(ta tb), sa = r tb, sb = r ta: per PAIR",
     "8 v_fma_f32 + 1 mfma /8", "8 v_pk_fma_f32 + 1 mfma /8", "8 v_add_f32 + 1 mfma /8", "8 v_exp_f32 + 1 mfma /8"};
 // instructions per chain step (the sequences count all their instructions)
 const int kPerStep[NMODES] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
-                               1, 2, 1, 1, 1, 1, 5, 4, 8, 6, 1, 1, 1, 1};
+                               1, 2, 1, 1, 1, 1, 5, 4, 8, 6, 1, 1, 1, 1, 1, 1};
 
 template <int MODE, int NT>
 __global__ void __launch_bounds__(NT) k(long long* cyc, float* out, int iters) {
@@ -111,6 +112,25 @@ __global__ void __launch_bounds__(NT) k(long long* cyc, float* out, int iters) {
                     asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(w0) : "v"(x0), "v"(h[i]));
                     asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(w1) : "v"(x1), "v"(h[i]));
                     asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l[i]) : "v"(w0), "v"(w1));
+                }
+                if (MODE == SIGPAIR_2RCP || MODE == SIGPAIR_1RCP) {   // (a, b) <- (sigmoid(a), sigmoid(b))
+                    float ta, tb;
+                    asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(ta) : "v"(-1.4426950408889634f), "v"(a[i]));
+                    asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(tb) : "v"(-1.4426950408889634f), "v"(b[i]));
+                    asm volatile("v_exp_f32 %0, %0" : "+v"(ta));
+                    asm volatile("v_exp_f32 %0, %0" : "+v"(tb));
+                    asm volatile("v_add_f32_e32 %0, 1.0, %0" : "+v"(ta));
+                    asm volatile("v_add_f32_e32 %0, 1.0, %0" : "+v"(tb));
+                    if (MODE == SIGPAIR_2RCP) {
+                        asm volatile("v_rcp_f32 %0, %1" : "=v"(a[i]) : "v"(ta));
+                        asm volatile("v_rcp_f32 %0, %1" : "=v"(b[i]) : "v"(tb));
+                    } else {
+                        float r;
+                        asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(ta), "v"(tb));
+                        asm volatile("v_rcp_f32 %0, %0" : "+v"(r));
+                        asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(a[i]) : "v"(r), "v"(tb));
+                        asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(b[i]) : "v"(r), "v"(ta));
+                    }
                 }
                 if (MODE == SILU) {   // a <- a * sigmoid(a): mul, exp, add, rcp, mul
                     float t;
@@ -196,10 +216,15 @@ struct Sweep<NMODES> {
     static void go(long long*, float*) {}
 };
 
-int main() {
+int main(int argc, char** argv) {
     long long* cyc; float* out;
     (void)hipMalloc(&cyc, 512 * sizeof(long long));
     (void)hipMalloc(&out, 256 * 1024 * sizeof(float));
+    if (argc > 1 && argv[1][0] == 's') {      // "sigmoid": only the rows a sigmoid is made of
+        all_w<EXP>(cyc, out); all_w<RCP>(cyc, out); all_w<SILU>(cyc, out);
+        all_w<SIGPAIR_2RCP>(cyc, out); all_w<SIGPAIR_1RCP>(cyc, out);
+        return 0;
+    }
     Sweep<0>::go(cyc, out);
     return 0;
 }
