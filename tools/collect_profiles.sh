@@ -28,5 +28,6 @@ cp $src/dynamic_range.txt $dst/${tag}_dynamic_range.txt
 cp $src/parity_margins.txt $dst/${tag}_parity_margins.txt
 ls $dst | grep "^${tag}_" | wc -l
 python3 tools/pmc_header.py $dst/${tag}_cfg2_pmc_sq.txt cfg2 > /dev/null; python3 tools/pmc_header.py $dst/${tag}_cfg3_pmc_sq.txt cfg3 > /dev/null
+cp $src/real_shape_eager.json $dst/${tag}_real_shape_eager.json; cp $src/real_shape_graph.json $dst/${tag}_real_shape_graph.json; cp $src/step_timeline_real4A.txt $dst/${tag}_step_timeline_real4A.txt 2>/dev/null
 # the commit the counters were taken at (bench.py: roofline.limiter_commit; this script runs where .git is)
 for c in cfg2 cfg3; do f=$dst/${tag}_${c}_pmc_sq.txt; [ -f $f ] && ! grep -q '^commit:' $f && sed -i "1i commit: $(git rev-parse --short HEAD)" $f; done
