@@ -44,7 +44,7 @@ python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_parity.py -q 
 python3 bench.py --config real4A --steps 50 --warmup 10 --graph 0 --no-cpu-baseline 2>/dev/null | line > $out/real_shape_eager.json
 python3 bench.py --config real4A --steps 50 --warmup 10 --graph 1 --no-cpu-baseline 2>/dev/null | line > $out/real_shape_graph.json
 rocprofv3 --kernel-trace --output-format csv -d $out/trace_real4A -- python3 bench.py --config real4A --steps 3 --warmup 2 --graph 0 --no-cpu-baseline > /dev/null 2>&1
-python3 tools/step_timeline.py $(ls $out/trace_real4A/*/*kernel_trace.csv | head -1) > $out/step_timeline_real4A.txt 2>&1
+python3 tools/step_timeline.py $out/trace_real4A > $out/step_timeline_real4A.txt 2>&1
 find $out/trace_real4A -name '*.csv' -size +1M -delete
 python3 -m pytest tests/test_gpu_lazy_scales.py tests/test_gpu_properties.py -q -m gpu -k "lazy or tile_magnitudes or bias_sums or dynamic_range or binades" > $out/lazy_tests.log 2>&1
 tools/micro/valu_issue_bench.bin sigmoid > $out/micro_sigmoid.txt 2>&1
