@@ -164,7 +164,8 @@ __device__ __forceinline__ void wgrad_tile_f16_acc(const unsigned short* __restr
 struct F16Cfg {
     static constexpr int kThreadsPerBlock = 512;                          // two waves per SIMD
     static constexpr int kWavesPerBlock = kThreadsPerBlock / 64;
-    static constexpr int kTS = kH;                                        // g_z1 tile: unpadded rows, rotated quads (pvs_tile_quad_off)
+    static constexpr int kTS = kH + 4;                                    // g_z1 tile row stride (floats) of the padded form; the
+                                                                          // BASELINE instantiation uses unpadded rows with rotated quads
     // per wave: a1 image, m image, gradient image (4 KB each), SiLU'(z1) (4 KB)
     static constexpr int kWaveBytes = 3 * kImg2 * 2 + 16 * 64 * 4;
     // shared: W2 and Wc1 images (hi + lo), tables, two ones columns, 4 words of weight maxima, one all-zero image
@@ -236,6 +237,10 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
     float* d1b = reinterpret_cast<float*>(GI + kImg2);         // SiLU'(z1), X layout, lane-private
     // once the m and gradient images are dead (after the W2 weight gradient) their slots hold the g_z1 tile
     float* T1 = reinterpret_cast<float*>(MI);
+    // The conflict-free tile layout (pvs_tile_quad_off: four write addresses that differ by an XOR, i.e. three more
+    // lane constants than base + immediate) only where the registers are there: the BASELINE instantiation. The others
+    // went from 1 / 3 / 9 / 28 to 5 / 11 / 15 / 30 spilled VGPRs with it (+3...16 % per launch) and keep the padded rows.
+    constexpr bool TSWZ = ERK == 0 && !EATT;
     float* tx = T1 + kTile * Cfg::kTS;
     int* rowbuf = reinterpret_cast<int*>(tx + kTile * 4);
 
@@ -609,11 +614,11 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             // ---- g_z1 edge-major, then whole rows to HBM + the row-side sums from the same reads ----
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq)
-                *reinterpret_cast<float4*>(T1 + pvs_tile_quad_off<1>(j, 2 * gq + hh)) =
+                *reinterpret_cast<float4*>(T1 + (TSWZ ? pvs_tile_quad_off<1>(j, 2 * gq + hh) : j * Cfg::kTS + 8 * gq + 4 * hh)) =
                     make_float4(g_z1[0][4 * gq], g_z1[0][4 * gq + 1], g_z1[0][4 * gq + 2], g_z1[0][4 * gq + 3]);
             pvs_wave_lds_sync();
 #ifndef PVS_ABL_F_NOREDUCE
-            reduce_rows_tile<1, false, true, true>(T1, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
+            reduce_rows_tile<1, false, true, TSWZ>(T1, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
                                 [&](int rl, int q, const float4& v) {
                                     if (e0 + rl < e_this_end) {  // streamed once: non-temporal
 #if defined(PVS_ABL_F_SCATTER) || !PVS_SA_STORE
