@@ -121,3 +121,27 @@ def test_model_selection_metrics_follow_the_reference(tmp_path):
     r, p = regression_pearson(aff)
     r0, p0 = pearsonr(y, yp)
     assert r == pytest.approx(r0, abs=1e-3) and p < 0.05 and p0 < 0.05
+
+
+def test_bench_limiter_label_follows_the_parsed_shares(tmp_path, monkeypatch):
+    """bench.py's roofline.limiter is derived from the shares of the newest SQ counter summary (every
+    resource over its threshold - VALU or matrix pipe >= 50 % busy, a wave >= 30 % parked in s_waitcnt - else the largest
+    share), not a constant; the file's first line names the commit it was measured at."""
+    import bench
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    line = ('  {k}: kernel 1e+06 cycles per launch; VALU busy {v}% of SIMD time, matrix pipe {m}% (10% of it under VALU work); '
+            'per wave: issuing 40%, issue-stalled {st}%, in s_waitcnt {w}%; LDS busy 20% of CU time (0% of it bank conflicts)')
+    (prof / 'r07_cfg2_pmc_sq.txt').write_text('commit: abc1234\nheader\n' + line.format(k='k_a<0>', v=58, m=18, st=20, w=37) + '\n' +
+                                              line.format(k='k_b<1>', v=82, m=11, st=39, w=24) + '\n' +
+                                              line.format(k='k_c', v=30, m=62, st=5, w=12) + '\n' +
+                                              line.format(k='k_d', v=20, m=10, st=5, w=25) + '\n')
+    (prof / 'r06_cfg2_pmc_sq.txt').write_text(line.format(k='k_a<0>', v=99, m=99, st=0, w=0) + '\n')     # older: ignored
+    monkeypatch.setattr(bench, 'ROOT', tmp_path)
+    a = bench.measured_limiter('cfg2', 'k_a')
+    assert a['limiter'] == 'valu_issue+wave_stalls' and a['valu_busy'] == 0.58 and a['waitcnt_share'] == 0.37
+    assert a['limiter_source'] == 'r07_cfg2_pmc_sq.txt' and a['limiter_commit'] == 'abc1234'
+    assert bench.measured_limiter('cfg2', 'k_b')['limiter'] == 'valu_issue'
+    assert bench.measured_limiter('cfg2', 'k_c')['limiter'] == 'matrix_pipe'
+    assert bench.measured_limiter('cfg2', 'k_d')['limiter'] == 'wave_stalls'         # nothing over a threshold: the largest share
+    assert bench.measured_limiter('cfg9', 'k_a')['limiter'] is None

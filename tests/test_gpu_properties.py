@@ -1229,3 +1229,36 @@ def test_counting_transpose_stays_in_bounds_on_broken_layout_tables(breakage):
         assert v.min() >= 0 and v.max() < n, name
     rowptr = pg.t['rowptr'].cpu().numpy()
     assert rowptr[0] >= 0 and rowptr[-1] <= e and np.all(np.diff(rowptr) >= 0)
+
+
+def test_profile_hook_reports_every_launch():
+    """pvs_profile_read_each (round 5; bench.py's roofline.avg_launch_ms_full_work): with the edge-backward group enabled, a
+    3-layer training step records exactly three launches, their per-launch times sum to pvs_profile_read's total, and
+    the first one - the last layer's backward, which has no coordinate branch - is the shortest."""
+    import ctypes as C
+    from pointvs_amd import _lib
+    from pointvs_amd.graph import Batch
+    from pointvs_amd.synthetic import synthetic_graph
+    lib = _lib.lib()
+    model, _ = make_model(seed=1, num_layers=3)
+    g = Batch.from_data_list([synthetic_graph(40 + k, n_nodes=1200, n_lig=20, edge_radius=8.0) for k in range(4)])
+    gpu_run(model, g)                                   # warm-up (allocations, first-use work)
+    lib.pvs_profile_reset()
+    lib.pvs_profile_enable(1 << 2)                      # group 1 = edge_bwd
+    try:
+        gpu_run(model, g)
+        torch.cuda.synchronize()
+    finally:
+        lib.pvs_profile_enable(0)
+    tot, cnt = C.c_double(0.0), C.c_int64(0)
+    assert lib.pvs_profile_read(b'edge_bwd', C.byref(tot), C.byref(cnt)) == 0
+    buf, n = (C.c_double * 8)(), C.c_int64(0)
+    assert lib.pvs_profile_read_each(b'edge_bwd', buf, 8, C.byref(n)) == 0
+    each = [buf[k] for k in range(n.value)]
+    assert cnt.value == 3 and n.value == 3, (cnt.value, n.value)
+    assert abs(sum(each) - tot.value) < 1e-6 and all(t > 0 for t in each)
+    assert each[0] < min(each[1:]), each
+    none, zero = (C.c_double * 1)(), C.c_int64(-1)
+    assert lib.pvs_profile_read_each(b'edge_fwd', none, 1, C.byref(zero)) == 0 and zero.value == 0      # group not enabled
+    assert lib.pvs_profile_read_each(b'no_such_group', none, 1, C.byref(zero)) == -1
+    lib.pvs_profile_reset()
