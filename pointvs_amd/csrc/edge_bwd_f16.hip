@@ -718,7 +718,8 @@ int pvs_launch_edge_bwd_f16(hipStream_t s, int H, const PvsGraph& g, const PvsEd
     int blocks, n_chunks;
     {
         const int E = e_hi - e_lo;
-        long long b = ((long long)E + (long long)nw * 512 - 1) / ((long long)nw * 512);   // fill the chip first
+        const long long per = pvs_edges_per_wave();
+        long long b = ((long long)E + (long long)nw * per - 1) / ((long long)nw * per);   // fill the chip first
         if (b < 1) b = 1;
         if (b > 256) b = 256;                      // one workgroup per CU (LDS)
         const long long waves = b * nw;

@@ -899,7 +899,8 @@ int pvs_launch_edge_bwd_h64(hipStream_t s, const PvsGraph& g, const PvsEdgeW& w,
     int blocks, n_chunks;
     {
         const int E = e_hi - e_lo;
-        long long b = ((long long)E + (long long)nw * 512 - 1) / ((long long)nw * 512);   // fill the chip first
+        const long long per = pvs_edges_per_wave();
+        long long b = ((long long)E + (long long)nw * per - 1) / ((long long)nw * per);   // fill the chip first
         if (b < 1) b = 1;
         if (b > 256) b = 256;                      // one workgroup per CU (registers: one wave per SIMD)
         const long long waves = b * nw;

@@ -1063,7 +1063,8 @@ int pvs_launch_edge_bwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
     {
         const int E = e_hi - e_lo;
         const int max_blocks = pvs_edge_bwd_mfma_max_blocks(H);       // H = 32: 2 x 256 threads per CU
-        long long b = ((long long)E + (long long)nw * 512 - 1) / ((long long)nw * 512);   // fill the chip first
+        const long long per = pvs_edges_per_wave();
+        long long b = ((long long)E + (long long)nw * per - 1) / ((long long)nw * per);   // fill the chip first
         if (b < 1) b = 1;
         if (b > max_blocks) b = max_blocks;
         const long long waves = b * nw;

@@ -757,10 +757,20 @@ int set_lds(K kernel, size_t lds) {
     return 0;
 }
 
+// Edges a wave gets before the grid grows by another workgroup. 512 until round 5 (sixteen tiles amortise a workgroup's
+// weight staging): right for BASELINE-size batches, whose grids are capped by the CU count anyway, and wrong for small ones
+// - at the reference's default shape (32 graphs of 500 atoms, r = 4 A: 176k edges) the backward ran on 43 of 256 CUs.
+// Two tiles per wave: edge forward 0.62 -> 0.20 ms, edge backward 0.81 -> 0.28 ms per 6-layer step there (32: 0.19 / 0.28;
+// profiles/r05_ab_small_batch_grid.txt). PVS_EDGES_PER_WAVE overrides it (A/B).
+inline int pvs_edges_per_wave() {
+    static const int v = [] { const char* e = getenv("PVS_EDGES_PER_WAVE"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 64; }();
+    return v;
+}
+
 void pick_grid(int E, int* blocks, int* n_chunks, int nw = kWaves, int max_blocks = 1024) {
-    // fill the chip first: a wave gets >= ~512 edges (16 tiles amortise the weight staging of its
-    // block) where the range allows; chunks of <= ~4096 edges; every wave gets the same number of chunks
-    long long b = ((long long)E + (long long)nw * 512 - 1) / ((long long)nw * 512);
+    // fill the chip first: a wave gets >= pvs_edges_per_wave() edges where the range allows; chunks of <= ~4096 edges; every wave gets the same number of chunks
+    const long long per = pvs_edges_per_wave();
+    long long b = ((long long)E + (long long)nw * per - 1) / ((long long)nw * per);
     if (b < 1) b = 1;
     if (b > max_blocks) b = max_blocks;
     const long long waves = b * nw;

@@ -165,6 +165,35 @@ class EGNNLayer(nn.Module):
             None if natt is None else natt.weight, None if natt is None else natt.bias,
             getattr(self, 'edge_gate_parameter', None), getattr(self, 'node_gate_parameter', None))
 
+    def _params_cached(self):
+        """(parameter tuple, PvsLayerParams) built once per layer: 35 module look-ups, 20 contiguity checks and a ctypes
+        struct per call otherwise (small batches are host-bound: tools/host_profile.py). The parameters are updated in
+        place (Adam, load_state_dict), so tensors and addresses stay; the cache is dropped by `_apply` (.to / .cuda /
+        .float), by assigning a parameter or sub-module of the layer, and whenever an address differs from the one the
+        struct was built with (`p.data = ...`) or the first parameter is no longer the same object."""
+        cached = self.__dict__.get('_pcache')
+        if cached is not None:
+            params, pstruct, ptrs = cached
+            if params[0] is self.edge_mlp[0].weight and ptrs == tuple(p.data_ptr() for p in params if p is not None):
+                return params, pstruct
+        params = self._params()
+        ok = all(p is None or (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()) for p in params)
+        if not ok:
+            self.__dict__.pop('_pcache', None)
+            return params, None
+        pstruct = _lib.PvsLayerParams(*[_lib.ptr(p) for p in params])
+        self.__dict__['_pcache'] = (params, pstruct, tuple(p.data_ptr() for p in params if p is not None))
+        return params, pstruct
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop('_pcache', None)
+        return super()._apply(fn, *args, **kwargs)
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (torch.nn.Parameter, torch.nn.Module)):
+            self.__dict__.pop('_pcache', None)
+        super().__setattr__(name, value)
+
     _KERNEL_WIDTHS = (16, 32, 64, 128)
 
     def _fused_width_ok(self):
@@ -231,8 +260,9 @@ class EGNNLayer(nn.Module):
         if self.hidden_nf not in self._KERNEL_WIDTHS:
             h_out, x_out, m_sorted, att, natt = self._padded_call(pg, h, coord, m_prev_sorted, need_m, desc[2])
         else:
+            params, pstruct = self._params_cached()
             h_out, x_out, m_sorted, att, natt = PF.egnn_layer(
-                h, coord, m_prev_sorted, pg, desc, need_m, self._params())
+                h, coord, m_prev_sorted, pg, desc, need_m, params, pstruct)
         self._att_src = None if att is None else (
             lambda: PF.rows_to_input_order(att.detach()[:pg.n_edges].reshape(-1, 1), pg))
         self._natt_src = None if natt is None else (lambda: natt.detach().reshape(-1, 1))

@@ -58,12 +58,20 @@ class _EGNNLayerFn(torch.autograd.Function):
     """One EGNNLayer.forward (egnn_satorras.py:189-206) and its backward, sorted edge order."""
 
     @staticmethod
-    def forward(ctx, h, x, m_prev, pg, desc_tuple, need_m, *params):
+    def forward(ctx, h, x, m_prev, pg, desc_tuple, need_m, pstruct, *params):
+        # pstruct: the layer's PvsLayerParams built ONCE for these very parameter tensors (EGNNLayer._params_cached:
+        # fp32, contiguous, on the device - checked when it was built), or None (padded / ad-hoc parameter tensors).
+        # Host time matters here: at the reference's default shape (32 graphs of 500 atoms) a training step is ~70
+        # launches of a few microseconds and the step is bound by this Python (tools/host_profile.py).
         lib = _lib.lib()
         hidden, n_attr, flags, act = desc_tuple
         h, x, m_prev = _f32c(h), _f32c(x), _f32c(m_prev)
-        params = tuple(_f32c(p) for p in params)
-        _lib.require_hip(h, x, m_prev, *params)
+        if pstruct is None:
+            params = tuple(_f32c(p) for p in params)
+            _lib.require_hip(h, x, m_prev, *params)
+            pstruct = _lib.PvsLayerParams(*[_lib.ptr(p) for p in params])
+        else:
+            _lib.require_hip(h, x, m_prev)
         dev = h.device
         n, e = pg.n_nodes, pg.n_edges
         if h.shape != (n, hidden) or x.shape != (n, 3):
@@ -73,7 +81,6 @@ class _EGNNLayerFn(torch.autograd.Function):
             raise ValueError(f'layer built with edges_in_d={n_attr} but edge_attr has '
                              f'{pg.n_edge_attr} columns')
         desc = _lib.PvsLayerDesc(hidden, n_attr, flags, act)
-        pstruct = _lib.PvsLayerParams(*[_lib.ptr(p) for p in params])
         eatt = bool(flags & _lib.EDGE_ATTENTION)
         natt = bool(flags & _lib.NODE_ATTENTION)
         eres = bool(flags & _lib.EDGE_RESIDUAL) and m_prev is not None
@@ -93,16 +100,16 @@ class _EGNNLayerFn(torch.autograd.Function):
         _lib.check(rc, 'pvs_egnn_layer_fwd')
         ctx.pg, ctx.desc_tuple, ctx.eres = pg, desc_tuple, eres
         ctx.n_params = len(params)
+        ctx.pstruct = pstruct      # (the backward reads the same parameter tensors: saved below, so they cannot have moved)
         ctx.save_for_backward(h, x, m_prev if eres else None, att, saved, *params)
         ctx.set_materialize_grads(False)
-        outs = (h_out, x_out,
-                m_out if m_out is not None else h.new_empty(0),
-                att if att is not None else h.new_empty(0),
-                node_att if node_att is not None else h.new_empty(0))
-        ctx.mark_non_differentiable(outs[3], outs[4])
-        if m_out is None:
-            ctx.mark_non_differentiable(outs[2])
-        return outs
+        # absent outputs are None, not empty tensors (h.new_empty(0) cost 22 us apiece on the host: 0.4 ms per step of a
+        # 6-layer model)
+        if att is not None:
+            ctx.mark_non_differentiable(att)
+        if node_att is not None:
+            ctx.mark_non_differentiable(node_att)
+        return h_out, x_out, m_out, att, node_att
 
     @staticmethod
     def backward(ctx, g_h_out, g_x_out, g_m_out, _g_att, _g_natt):
@@ -113,7 +120,7 @@ class _EGNNLayerFn(torch.autograd.Function):
         dev = h.device
         n, e = pg.n_nodes, pg.n_edges
         desc = _lib.PvsLayerDesc(hidden, n_attr, flags, act)
-        pstruct = _lib.PvsLayerParams(*[_lib.ptr(p) for p in params])
+        pstruct = ctx.pstruct
         g_h_out = torch.zeros_like(h) if g_h_out is None else _f32c(g_h_out)
         g_x_out = _f32c(g_x_out)       # None => the caller never used x_out (last layer)
         g_m_out = _f32c(g_m_out) if (g_m_out is not None and g_m_out.numel()) else None
@@ -141,15 +148,12 @@ class _EGNNLayerFn(torch.autograd.Function):
             _lib.ptr(g_m_out), _lib.ptr(g_h), _lib.ptr(g_x), _lib.ptr(g_m_prev), C.byref(gstruct),
             _lib.ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, 'pvs_egnn_layer_bwd')
-        return (g_h, g_x, g_m_prev, None, None, None, *grads)
+        return (g_h, g_x, g_m_prev, None, None, None, None, *grads)
 
 
-def egnn_layer(h, x, m_prev_sorted, pg, desc_tuple, need_m, params):
-    """Returns (h_out, x_out, m_sorted|None, att_sorted|None, node_att|None)."""
-    h_out, x_out, m, att, natt = _EGNNLayerFn.apply(h, x, m_prev_sorted, pg, desc_tuple, need_m,
-                                                    *params)
-    return (h_out, x_out, m if need_m else None, att if att.numel() else None,
-            natt if natt.numel() else None)
+def egnn_layer(h, x, m_prev_sorted, pg, desc_tuple, need_m, params, pstruct=None):
+    """Returns (h_out, x_out, m_sorted|None, att_sorted|None, node_att|None). pstruct: see _EGNNLayerFn.forward."""
+    return _EGNNLayerFn.apply(h, x, m_prev_sorted, pg, desc_tuple, need_m, pstruct, *params)
 
 
 class _LinearFn(torch.autograd.Function):

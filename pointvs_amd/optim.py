@@ -31,40 +31,51 @@ class FusedClipAdam(torch.optim.Adam):
                     return False
         return True
 
+    def zero_grad(self, set_to_none=True):
+        """torch's zero_grad walks hooks, profiler ranges and foreach groups (~100 us on the host for 34 parameters);
+        with set_to_none this is all it does."""
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for group in self.param_groups:
+            for p in group['params']:
+                p.grad = None
+
+    def load_state_dict(self, state_dict):
+        self._fast = None              # new state tensors, other step counts
+        return super().load_state_dict(state_dict)
+
     @torch.no_grad()
     def step(self, closure=None, clip_value=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if not self._fusable():
+        # Host time counts (small batches are bound by it: tools/host_profile.py): the work list - which parameters
+        # have gradients, their state tensors, their common step count, the fusability verdict - is kept from step to
+        # step and re-derived only when the set of parameters with gradients (or the groups, or the state) changes;
+        # the step counters (one CPU tensor per parameter: torch's state_dict layout) advance with one foreach call.
+        live = [p.grad is not None for group in self.param_groups for p in group['params']]
+        fast = getattr(self, '_fast', None)
+        if fast is None or fast['live'] != live or fast['n_groups'] != len(self.param_groups):
+            fast = self._plan(live)
+        if not (fast['fusable'] and self._gradients_fusable(fast)):
+            self._fast = None
             if clip_value is not None:
                 torch.nn.utils.clip_grad_value_([p for g in self.param_groups for p in g['params']], clip_value)
             super().step()
             return loss
         lib = _lib.lib()
-        for group in self.param_groups:
+        for group, works in zip(self.param_groups, fast['groups']):
             beta1, beta2 = group['betas']
-            by_step = {}
-            for p in group['params']:
-                if p.grad is None:
-                    continue
-                state = self.state[p]
-                if len(state) == 0:      # torch.optim.Adam._init_group, non-capturable flavour
-                    state['step'] = torch.tensor(0.0, dtype=torch.float32)
-                    state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                state['step'] += 1
-                by_step.setdefault(float(state['step']), []).append((p, state))
-            for step, items in by_step.items():
-                n = len(items)
-                dev = items[0][0].device
+            for work in works:            # one launch per distinct step count (one, unless the gradient set changed mid-run)
+                torch._foreach_add_(work['steps'], 1)
+                work['step'] += 1
+                step, items, n, dev = work['step'], work['items'], work['n'], work['dev']
                 if not self._ring or self._ring[0][0].shape[0] < n:
                     cap = max(n, 64)
                     self._ring = [[torch.empty((cap, 5), dtype=torch.int64).pin_memory(),
                                    torch.empty((cap, 5), dtype=torch.int64, device=dev), None] for _ in range(8)]
-                rows = [[p.data_ptr(), p.grad.data_ptr(), s['exp_avg'].data_ptr(), s['exp_avg_sq'].data_ptr(),
-                         p.numel()] for p, s in items]
+                rows = [[p.data_ptr(), p.grad.data_ptr(), ea.data_ptr(), es.data_ptr(), p.numel()] for p, ea, es in items]
                 last = getattr(self, '_last_table', None)
                 if last is not None and last[0] == rows and last[1].device == dev:
                     # the same addresses as in the previous step (the caching allocator hands the gradients the same
@@ -81,7 +92,7 @@ class FusedClipAdam(torch.optim.Adam):
                     slot[2] = torch.cuda.Event()
                     slot[2].record(torch.cuda.current_stream(dev))
                     # (a ring slot is rewritten only after len(ring) - 1 other uploads, i.e. after this entry stopped
-                    # being `_last_table`; several step groups per call simply miss each other)
+                    # being `_last_table`; several launches per call simply miss each other)
                     self._last_table = (rows, table_dev)
                 _lib.check(lib.pvs_adam_clip_step(
                     _lib.ptr(table_dev), n, float(group['lr']), float(beta1), float(beta2),
@@ -90,5 +101,48 @@ class FusedClipAdam(torch.optim.Adam):
                     torch.cuda.current_stream(dev).cuda_stream), 'pvs_adam_clip_step')
                 # the kernel wrote through raw pointers: tell autograd (and anything that caches by
                 # version, e.g. ReceptorScreen) that the parameters changed, as an in-place op would
-                torch.autograd.graph.increment_version([p for p, _ in items])
+                torch.autograd.graph.increment_version(work['params'])
         return loss
+
+    def _plan(self, live):
+        """The work list of step(): per group, per distinct step count, the parameters with gradients and their state
+        (created as torch.optim.Adam._init_group does, non-capturable flavour)."""
+        groups, fusable = [], self._fusable()
+        if not fusable:       # (torch's own step creates whatever state its flavour - capturable, amsgrad ... - needs)
+            self._fast = {'live': live, 'n_groups': len(self.param_groups), 'groups': [], 'fusable': False}
+            return self._fast
+        for group in self.param_groups:
+            by_step = {}
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                state = self.state[p]
+                if len(state) == 0:
+                    state['step'] = torch.tensor(0.0, dtype=torch.float32)
+                    state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if not isinstance(state['step'], torch.Tensor) or state['step'].is_cuda:
+                    fusable = False        # (a capturable optimiser's state: torch's own step handles it)
+                    continue
+                by_step.setdefault(float(state['step']), []).append((p, state))
+            works = []
+            for count, members in by_step.items():
+                works.append({'items': [(p, st['exp_avg'], st['exp_avg_sq']) for p, st in members],
+                              'steps': [st['step'] for _, st in members], 'step': int(count), 'n': len(members),
+                              'dev': members[0][0].device, 'params': [p for p, _ in members]})
+            groups.append(works)
+        self._fast = {'live': live, 'n_groups': len(self.param_groups), 'groups': groups, 'fusable': fusable}
+        return self._fast
+
+    def _gradients_fusable(self, fast):
+        """What can change from step to step under an unchanged plan: the learning rate becoming a tensor, a gradient
+        that is not a dense contiguous tensor."""
+        for group, works in zip(self.param_groups, fast['groups']):
+            if isinstance(group['lr'], torch.Tensor):
+                return False
+            for work in works:
+                for p in work['params']:
+                    g = p.grad
+                    if g.is_sparse or not g.is_contiguous():
+                        return False
+        return True

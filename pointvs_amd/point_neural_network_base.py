@@ -34,6 +34,118 @@ def _rank_world():
     return 0, 1
 
 
+class _StepReplayer:
+    """train_model(capture=True): whole training steps (graph preparation, forward, loss, backward, clip + Adam) as
+    hipGraphs, one per batch that comes back with the same device tensors. A batch runs eagerly on its first visit
+    (which also warms up whatever its shapes need), is captured and replayed on its second, replayed from then on; at
+    most `max_graphs` batches are captured, the rest stay eager. Everything - eager steps too - runs on ONE side stream:
+    autograd's AccumulateGrad nodes remember the stream of their first backward, and a capture on another stream than
+    earlier eager steps faults in hipStreamEndCapture (ROCm 7.2 / torch 2.10; bench.py --graph 1 does the same).
+    The optimiser runs as torch's capturable Adam for the duration (step counters on the device; FusedClipAdam's
+    kernel takes its bias corrections as host scalars, which a replay would freeze) and is restored on close()."""
+
+    def __init__(self, model, max_graphs=64):
+        if not torch.cuda.is_available():
+            raise RuntimeError('train_model(capture=True) needs a GPU')
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            raise NotImplementedError('train_model(capture=True) is single-process (the gradient exchange is not captured)')
+        if model.scheduler is not None:
+            raise NotImplementedError('train_model(capture=True) with a learning-rate scheduler (the rate is baked '
+                                      'into the captured optimiser step)')
+        if not isinstance(model.optimiser, torch.optim.Adam):
+            raise NotImplementedError('train_model(capture=True) needs the Adam optimiser')
+        self.model, self.max_graphs = model, max_graphs
+        # one side stream per model, kept across calls (AccumulateGrad nodes remember the stream of their first backward)
+        if getattr(model, '_capture_stream', None) is None:
+            model._capture_stream = torch.cuda.Stream(DEVICE)
+        self.stream = model._capture_stream
+        self.seen, self.graphs = {}, {}
+        self.stats = {'eager': 0, 'captured': 0, 'replayed': 0}
+        model.last_capture_stats = self.stats
+        self._was = []
+        for group in model.optimiser.param_groups:
+            self._was.append(group.get('capturable', False))
+            group['capturable'] = True
+            for p in group['params']:
+                st = model.optimiser.state.get(p)
+                if st and isinstance(st.get('step'), torch.Tensor) and not st['step'].is_cuda:
+                    st['step'] = st['step'].to(device=p.device, dtype=torch.float32)
+        model.optimiser._fast = None
+
+    def close(self):
+        torch.cuda.current_stream(DEVICE).wait_stream(self.stream)
+        self.graphs.clear()
+        opt = self.model.optimiser
+        for group, was in zip(opt.param_groups, self._was):
+            group['capturable'] = was
+            if not was:
+                for p in group['params']:
+                    st = opt.state.get(p)
+                    if st and isinstance(st.get('step'), torch.Tensor) and st['step'].is_cuda:
+                        st['step'] = st['step'].cpu()
+        opt._fast = None
+
+    @staticmethod
+    def _key(graph, task):
+        key = [task]
+        for name in ('x', 'pos', 'edge_index', 'edge_attr', 'batch', 'y'):
+            t = getattr(graph, name, None)
+            if t is None:
+                key.append(None)
+                continue
+            if not torch.is_tensor(t) or not t.is_cuda:
+                return None                  # host tensors are copied to new device tensors every step: nothing to replay
+            key.append((t.data_ptr(), t._version, tuple(t.shape)))
+        return tuple(key)
+
+    def _eager(self, graph):
+        y_pred, y_true, _, _ = self.model.unpack_input_data_and_predict(graph)
+        return self.model.backprop(y_true, y_pred, sync=False)
+
+    @staticmethod
+    def _make_capturable(graph):
+        """What the forward would otherwise derive from the batch vector with data-dependent ops (a bincount, a
+        maximum read on the host): done once, outside any capture, and left on the batch object."""
+        batch = getattr(graph, 'batch', None)
+        if batch is None:
+            return
+        if getattr(graph, 'num_graphs', None) is None:
+            graph.num_graphs = int(batch.max()) + 1
+        if getattr(graph, 'ptr', None) is None:
+            counts = torch.bincount(batch, minlength=graph.num_graphs)
+            graph.ptr = torch.cat([counts.new_zeros(1), counts.cumsum(0)])
+
+    def step(self, graph):
+        from . import graph as pgraph
+        key = self._key(graph, self.model.model_task)
+        hit = self.graphs.get(key) if key is not None else None
+        if hit is not None:
+            hit[0].replay()
+            self.stats['replayed'] += 1
+            return hit[1].clone()
+        visits = self.seen.get(key, 0) if key is not None else 0
+        if key is None or visits == 0 or len(self.graphs) >= self.max_graphs:
+            if key is not None:
+                self.seen[key] = visits + 1
+                self._make_capturable(graph)
+            self.stats['eager'] += 1
+            return self._eager(graph)
+        # second visit: capture. The batch's CSR / CSC preparation is captured too (its tensors then live in the
+        # graph's private pool: a cached PreparedGraph could be evicted and freed under the captured launches).
+        cache_was, pgraph.CACHE_ENABLED = pgraph.CACHE_ENABLED, False
+        try:
+            self.stream.synchronize()
+            hip_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(hip_graph, stream=self.stream):
+                static_loss = self._eager(graph)
+        finally:
+            pgraph.CACHE_ENABLED = cache_was
+        self.graphs[key] = (hip_graph, static_loss, graph)      # (holds the batch: its addresses stay unique)
+        hip_graph.replay()
+        self.stats['captured'] += 1
+        return static_loss.clone()
+
+
 class PointNeuralNetworkBase(nn.Module):
     """Base (abstract) class of the point-cloud networks."""
 
@@ -143,11 +255,28 @@ class PointNeuralNetworkBase(nn.Module):
         init_epoch = self.a_epoch if 'regression' in self.model_task else self.p_epoch
         return init_epoch, time.time()
 
-    def train_model(self, data_loader, epochs=1, epoch_end_validation_set=None, top1_on_end=False):
+    def train_model(self, data_loader, epochs=1, epoch_end_validation_set=None, top1_on_end=False, capture=False):
         """Training loop (:136-205): per batch predict + backprop, per epoch checkpoint (+ optional
         validation, :470-490). No host synchronisation inside the loop: losses are drained every
-        `log_interval` steps."""
+        `log_interval` steps.
+        capture=True (no reference counterpart, opt-in): batches that COME BACK - the same device tensors epoch after
+        epoch, e.g. a list of pre-collated batches resident on the GPU - are replayed from a hipGraph of their whole
+        step from their third visit on (`_StepReplayer`). For small graphs the eager step is bound by the host
+        (~70 launches of a few microseconds: 16.8k -> 25.7k graphs/s at the reference's default shape,
+        profiles/r05_real_shape.txt); for BASELINE-size batches it buys nothing. Single process, no learning-rate
+        scheduler, Adam; anything else raises."""
         init_epoch, _ = self.training_setup(data_loader=data_loader, epochs=epochs)
+        if capture:
+            replayer = _StepReplayer(self)
+            try:
+                with torch.cuda.stream(replayer.stream):
+                    return self._train_epochs(data_loader, init_epoch, epochs, epoch_end_validation_set, top1_on_end,
+                                              replayer)
+            finally:
+                replayer.close()
+        return self._train_epochs(data_loader, init_epoch, epochs, epoch_end_validation_set, top1_on_end, None)
+
+    def _train_epochs(self, data_loader, init_epoch, epochs, epoch_end_validation_set, top1_on_end, replayer):
         losses = []
         sampler = getattr(data_loader, 'sampler', None)
         for epoch in range(init_epoch, epochs):
@@ -156,10 +285,13 @@ class PointNeuralNetworkBase(nn.Module):
                 sampler.set_epoch(epoch)
             pending = []
             for self.batch, graph in enumerate(data_loader):
-                y_pred, y_true, _, _ = self.unpack_input_data_and_predict(graph)
-                if hasattr(self.grad_sync, 'set_weight'):     # uneven shards: weight by local graphs
-                    self.grad_sync.set_weight(float(y_pred.numel()))
-                pending.append(self.backprop(y_true, y_pred, sync=False))
+                if replayer is not None:
+                    pending.append(replayer.step(graph))
+                else:
+                    y_pred, y_true, _, _ = self.unpack_input_data_and_predict(graph)
+                    if hasattr(self.grad_sync, 'set_weight'):     # uneven shards: weight by local graphs
+                        self.grad_sync.set_weight(float(y_pred.numel()))
+                    pending.append(self.backprop(y_true, y_pred, sync=False))
                 if self.scheduler is not None:
                     self.scheduler.step()
                 self.global_iter += 1

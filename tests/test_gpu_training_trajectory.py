@@ -94,3 +94,53 @@ def test_training_trajectory_matches_the_reference(name, tmp_path):
         moved = np.abs(ref - z[f'sd0/{k}'].astype(np.float64))
         assert np.median(d) <= 1e-3 * max(float(np.median(moved)), 1e-6) + 1e-6, (k, float(np.median(d)), float(np.median(moved)))
     print(f'{name}: worst loss rel {rel.max():.2e}, 99th percentile weight distance {worst:.2e}')
+
+
+from tests._golden import needs_caching_allocator  # noqa: E402
+
+
+@needs_caching_allocator
+@pytest.mark.parametrize('name', ['default', 'multitask'])
+def test_captured_training_steps_follow_the_reference_trajectory(name, tmp_path):
+    """train_model(capture=True) (round 5, opt-in, no reference counterpart): batches that come back with the same
+    device tensors are replayed from a hipGraph of their whole step. On the reference's trajectories (4 batches x 3
+    epochs per phase) every batch runs eagerly in its first epoch, is captured in its second and replayed in its third;
+    losses, learning rates, counters, checkpoints and optimiser step counts must be the eager run's = the reference's,
+    and the optimiser must be back in its fused, non-capturable form afterwards."""
+    from pointvs_amd.egnn_multitask import MultitaskSatorrasEGNN
+    from pointvs_amd.egnn_satorras import SartorrasEGNN
+    from pointvs_amd.optim import FusedClipAdam
+    z, meta = _load(name)
+    cls = SartorrasEGNN if meta['class'] == 'SartorrasEGNN' else MultitaskSatorrasEGNN
+    torch.manual_seed(meta['seed'])
+    np.random.seed(meta['seed'])
+    model = cls(tmp_path, meta['lr'], meta['wd'], None, None, silent=True, **meta['ctor'], **meta['kwargs'])
+    losses, stats = [], []
+    for (task, n_batches, epochs), loader in zip(meta['phases'], _loaders(z, meta)):
+        model.set_task(task)
+        loader = [b.to('cuda') for b in loader]              # resident batches: the same tensors every epoch
+        losses += [float(v) for v in model.train_model(loader, epochs=epochs, capture=True)]
+        stats.append((dict(model.last_capture_stats), n_batches, epochs))
+    for st, n_batches, epochs in stats:
+        assert st['eager'] == n_batches and st['captured'] == (n_batches if epochs > 1 else 0), st
+        assert st['replayed'] == n_batches * max(epochs - 2, 0), st
+    ref_loss = z['loss']
+    assert len(losses) == len(ref_loss)
+    rel = np.abs(np.asarray(losses) - ref_loss) / np.abs(ref_loss)
+    assert rel.max() < 1e-4, (rel.tolist(), losses, ref_loss.tolist())
+    assert (model.p_epoch, model.a_epoch, model.global_iter) == (meta['p_epoch'], meta['a_epoch'], meta['global_iter'])
+    ckpts = sorted(str(p.relative_to(tmp_path)) for p in tmp_path.rglob('*.pt'))
+    assert ckpts == meta['checkpoints']
+    ck = torch.load(tmp_path / ckpts[-1], map_location='cpu', weights_only=False)
+    opt_steps = sorted({int(s['step']) for s in ck['optimiser_state_dict']['state'].values()})
+    assert opt_steps == meta['optimiser_steps_in_last_checkpoint']
+    for k, v in model.state_dict().items():
+        ref = z[f'sd1/{k}']
+        if np.issubdtype(ref.dtype, np.floating):
+            assert np.abs(v.detach().cpu().numpy().astype(np.float64) - ref).max() <= len(losses) * 2e-3 * 1.001, k
+    # back to the fused optimiser: host-side step counters, not capturable, and a further eager step works
+    assert isinstance(model.optimiser, FusedClipAdam)
+    assert not any(g.get('capturable') for g in model.optimiser.param_groups)
+    assert all(not s['step'].is_cuda for s in model.optimiser.state.values())
+    more = model.train_model([_loaders(z, meta)[-1][0]], epochs=model.a_epoch + model.p_epoch + 1)
+    assert len(more) >= 0 and all(np.isfinite(more))
