@@ -157,3 +157,15 @@ def require_hip(*tensors):
             raise RuntimeError(
                 'pointvs_amd kernels run on a HIP device only (got a CPU tensor); there is no CPU '
                 'path in the product - the CPU oracle lives in oracle/ and is test-only')
+
+
+def stream(dev):
+    """Raw handle (hipStream_t as an int) of torch's CURRENT stream on `dev`, as every C-ABI call takes it. The raw
+    accessor, not torch.cuda.current_stream(dev).cuda_stream: that builds a Stream object (5 us a call on the host, a
+    dozen calls per training step of a small batch)."""
+    import torch
+    idx = dev.index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx)
+

@@ -263,17 +263,19 @@ class EGNNLayer(nn.Module):
             params, pstruct = self._params_cached()
             h_out, x_out, m_sorted, att, natt = PF.egnn_layer(
                 h, coord, m_prev_sorted, pg, desc, need_m, params, pstruct)
-        self._att_src = None if att is None else (
+        # (plain attributes through __dict__: nn.Module.__setattr__ costs 2-3 us a piece on the host, three per layer call)
+        d = self.__dict__
+        d['_att_src'] = None if att is None else (
             lambda: PF.rows_to_input_order(att.detach()[:pg.n_edges].reshape(-1, 1), pg))
-        self._natt_src = None if natt is None else (lambda: natt.detach().reshape(-1, 1))
+        d['_natt_src'] = None if natt is None else (lambda: natt.detach().reshape(-1, 1))
         if skip_coords:
             def coords_on_demand(h=h.detach(), coord=coord.detach(),
                                  mp=None if m_prev_sorted is None else m_prev_sorted.detach()):
                 with torch.no_grad():
                     return self.forward_prepared(pg, h, coord, mp, need_m=False)[1]
-            self._coords_src = coords_on_demand
-        else:
-            self._coords_src = (lambda: x_out.detach()) if self.use_coords else self._coords_src
+            d['_coords_src'] = coords_on_demand
+        elif self.use_coords:
+            d['_coords_src'] = lambda: x_out.detach()
         return h_out, x_out, m_sorted
 
     def _decomposed_call(self, pg, h, coord, m_prev_sorted, skip_coords):

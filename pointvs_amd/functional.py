@@ -11,7 +11,7 @@ from . import _lib
 
 
 def _stream(dev):
-    return torch.cuda.current_stream(dev).cuda_stream
+    return _lib.stream(dev)
 
 
 def _ws(nbytes, dev):
@@ -364,7 +364,7 @@ def dropout_adj(edge_index, edge_attr=None, p=0.5, force_undirected=True, traini
     if edge_attr is not None:
         edge_attr = edge_attr.long().contiguous()
         n_attr = int(edge_attr.shape[1])
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    stream = _lib.stream(dev)
     pos = torch.empty(n_edges + 1, dtype=torch.int32, device=dev)
     ws_bytes = lib.pvs_dropout_adj_workspace_bytes(n_edges)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

@@ -208,7 +208,7 @@ def prepare_graph(edge_index, edge_attr, n_nodes, need_backward=None, layout=Non
         t['etype'] = torch.empty(e_alloc, dtype=torch.uint8, device=dev)
     if need_backward:
         t['colptr'], t['cedge'] = torch.empty(n_nodes + 1, **i32), torch.empty(e_alloc, **i32)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    stream = _lib.stream(dev)
     outputs = (_lib.ptr(t['rowptr']), _lib.ptr(t['row']), _lib.ptr(t['col']), _lib.ptr(t.get('etype')),
                _lib.ptr(t['perm']), _lib.ptr(t.get('colptr')), _lib.ptr(t.get('cedge')), _lib.ptr(t['inv_deg']),
                _lib.ptr(t['status']))

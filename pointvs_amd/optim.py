@@ -98,7 +98,7 @@ class FusedClipAdam(torch.optim.Adam):
                     _lib.ptr(table_dev), n, float(group['lr']), float(beta1), float(beta2),
                     float(group['eps']), float(group['weight_decay']), 1.0 - beta1 ** step, 1.0 - beta2 ** step,
                     float(clip_value) if clip_value is not None else 0.0,
-                    torch.cuda.current_stream(dev).cuda_stream), 'pvs_adam_clip_step')
+                    _lib.stream(dev)), 'pvs_adam_clip_step')
                 # the kernel wrote through raw pointers: tell autograd (and anything that caches by
                 # version, e.g. ReceptorScreen) that the parameters changed, as an in-place op would
                 torch.autograd.graph.increment_version(work['params'])

@@ -15,7 +15,7 @@ from .graph import PreparedGraph
 
 
 def _stream(dev):
-    return torch.cuda.current_stream(dev).cuda_stream
+    return _lib.stream(dev)
 
 
 def radius_graph(pos, bp, graph_ptr=None, inter_radius=4.0, intra_radius=None, max_graph_nodes=None,

@@ -19,7 +19,7 @@ from .radius_graph import PoseBatcher, radius_graph
 
 
 def _stream(dev):
-    return torch.cuda.current_stream(dev).cuda_stream
+    return _lib.stream(dev)
 
 
 class ReceptorScreen:
