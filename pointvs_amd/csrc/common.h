@@ -70,6 +70,29 @@ __device__ __forceinline__ float pvs_sigmoid(float v) { return fmaf(0.1f, v, 0.5
 __device__ __forceinline__ float pvs_sigmoid(float v) { return pvs_rcp(1.0f + pvs_exp(-v)); }
 #endif
 __device__ __forceinline__ float pvs_silu(float v) { return v * pvs_sigmoid(v); }
+// The same on PAIRS of values in adjacent registers (round 5). A wave issues at most one instruction per ~5 cycles
+// whatever it is (profiles/r03_micro_valu_issue.txt: "a wave alone"), and the two-waves-per-SIMD kernels are bound by
+// that, not by the ALU: a v_pk_*_f32 produces two results in one issue slot. The compiler's SLP pass packs some of
+// this by itself but leaves the multiply by a literal (VOP3P takes no literal) and the add behind the scalar
+// v_exp_f32 results unpacked; written on two-element vectors they are packed. Same operations, same roundings.
+typedef float pvs_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pvs_f2 pvs_fma2(pvs_f2 a, pvs_f2 b, pvs_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#ifdef PVS_ABL_NO_SILU
+__device__ __forceinline__ pvs_f2 pvs_sigmoid2(pvs_f2 v) { return pvs_fma2(v, pvs_f2{0.1f, 0.1f}, pvs_f2{0.5f, 0.5f}); }
+#else
+__device__ __forceinline__ pvs_f2 pvs_sigmoid2(pvs_f2 v) {
+    pvs_f2 t = v * -1.4426950408889634f;
+    t = pvs_f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+    return pvs_f2{pvs_rcp(t.x), pvs_rcp(t.y)};
+}
+#endif
+__device__ __forceinline__ pvs_f2 pvs_silu2(pvs_f2 z) { return z * pvs_sigmoid2(z); }
+// a = SiLU(z), d = SiLU'(z) = s + z s (1 - s)
+__device__ __forceinline__ void pvs_silu_grad2(pvs_f2 z, pvs_f2& a, pvs_f2& d) {
+    const pvs_f2 sg = pvs_sigmoid2(z);
+    a = z * sg;
+    d = pvs_fma2(a, 1.0f - sg, sg);
+}
 // d/dv [v*sigmoid(v)] given s = sigmoid(v)
 __device__ __forceinline__ float pvs_silu_grad(float v, float s) { return s * (1.0f + v * (1.0f - s)); }
 __device__ __forceinline__ float pvs_tanh(float v) {

@@ -33,7 +33,52 @@
 #define PVS_SA_STORE 0
 #endif
 
+#ifndef PVS_GATHER_AHEAD
+#define PVS_GATHER_AHEAD 0
+#endif
+// (tools/micro/glds_offset_test.hip: does the immediate offset of global_load_lds move the LDS address as well?)
+#ifndef PVS_GLDS_OFFSET_MOVES_LDS
+#define PVS_GLDS_OFFSET_MOVES_LDS 1
+#endif
+
 namespace {
+
+// ---- the next tile's node rows, fetched one tile ahead by LDS-DMA (round 5) ------------------------------------------
+// A tile's gather (P_i, Q_j, x_i, x_j) used to be issued at its top and waited for at once: ~1,450 cycles per tile with
+// nothing else for the wave to do, and the vector-memory counter completes in order, so the wait also sat out the
+// previous tile's five row stores (tools/tile_trace.py). The registers to hold a tile's rows across the row reduction
+// are not there (255 of 256), but the LDS is: when g_z1 has been formed the a1 image and the SiLU'(z1) slot are dead.
+// So the rows of tile t + 1 are requested BEFORE tile t's stores, as global_load_lds (no register destination: lane l's
+// 16 bytes land at M0 + 16 l, the lane-private [piece][lane] order the X layout reads back), and waited for at the top of
+// tile t + 1 with a COUNTED s_waitcnt that leaves the stores in flight. hipcc does not see an asm load in its own
+// s_waitcnt bookkeeping, which only makes its waits conservative (it believes fewer operations are outstanding than are).
+// Layout per wave: Q pieces in the a1 image slot, P pieces in the SiLU'(z1) slot, x_i (lanes 0-31) / x_j (lanes 32-63)
+// behind the g_z1 tile's row buffer.
+constexpr int kAheadQ = 0, kAheadP = 12288, kAheadX = 4096 + 5248;     // byte offsets from the wave's LDS base
+constexpr int kGldsK = PVS_GLDS_OFFSET_MOVES_LDS ? 32 : 0;
+#define PVS_STR2(x) #x
+#define PVS_STR(x) PVS_STR2(x)
+__device__ __forceinline__ void pvs_gather_ahead_issue(const float* pp, const float* qp, const float* xp, unsigned lds_wave) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_add_i32 m0, %4, %5\n\t s_nop 0\n\t global_load_lds_dwordx4 %1, off\n\t"
+        "s_add_i32 m0, %4, %6\n\t s_nop 0\n\t global_load_lds_dwordx4 %1, off offset:32\n\t"
+        "s_add_i32 m0, %4, %7\n\t s_nop 0\n\t global_load_lds_dwordx4 %1, off offset:64\n\t"
+        "s_add_i32 m0, %4, %8\n\t s_nop 0\n\t global_load_lds_dwordx4 %1, off offset:96\n\t"
+        "s_add_i32 m0, %4, %9\n\t s_nop 0\n\t global_load_lds_dwordx4 %2, off\n\t"
+        "s_add_i32 m0, %4, %10\n\t s_nop 0\n\t global_load_lds_dwordx4 %2, off offset:32\n\t"
+        "s_add_i32 m0, %4, %11\n\t s_nop 0\n\t global_load_lds_dwordx4 %2, off offset:64\n\t"
+        "s_add_i32 m0, %4, %12\n\t s_nop 0\n\t global_load_lds_dwordx4 %2, off offset:96\n\t"
+        "s_add_i32 m0, %4, %13\n\t s_nop 0\n\t global_load_lds_dwordx3 %3, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(pp), "v"(qp), "v"(xp), "s"(lds_wave),
+          "i"(kAheadP), "i"(kAheadP + 1024 - kGldsK), "i"(kAheadP + 2 * (1024 - kGldsK)), "i"(kAheadP + 3 * (1024 - kGldsK)),
+          "i"(kAheadQ), "i"(kAheadQ + 1024 - kGldsK), "i"(kAheadQ + 2 * (1024 - kGldsK)), "i"(kAheadQ + 3 * (1024 - kGldsK)),
+          "i"(kAheadX)
+        : "memory");
+}
 
 // timing-only ablation (tools/variant_obj.sh -DPVS_ABL_F_SCATTER): the per-edge outputs at scattered positions of a
 // 256k-edge region, the access pattern of a by-column layout
@@ -45,6 +90,25 @@ __device__ __forceinline__ int pvs_abl_scr(int e, int E) {
 }
 #else
 #define PVS_ABL_SCR(e) (e)
+#endif
+
+// timing-only instrumentation (tools/variant_obj.sh -DPVS_TILE_TRACE, tools/tile_trace.py): workgroup 0 writes the shader
+// clock at phase boundaries of its first tiles; every point is a scheduling barrier, so the traced kernel is the
+// phase-by-phase form of the shipped one (the tool reports both tile times)
+#ifdef PVS_TILE_TRACE
+constexpr int kTraceTiles = 128, kTracePoints = 24;
+__device__ unsigned long long pvs_trace_buf[8 * kTraceTiles * kTracePoints];
+#define PVS_TP(k)                                                                                        \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if ((k) == 1 || (k) == 21) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* 1: the gather has landed; 21: the previous tile's stores have */ \
+        const unsigned long long t_ = __builtin_readcyclecounter();                                      \
+        if (blockIdx.x == 0 && lane == 0 && tile_no < kTraceTiles)                                       \
+            pvs_trace_buf[(wv * kTraceTiles + tile_no) * kTracePoints + (k)] = t_;                       \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    } while (0)
+#else
+#define PVS_TP(k) ((void)0)
 #endif
 
 constexpr int kH = 32;
@@ -171,7 +235,8 @@ struct F16Cfg {
     // shared: W2 and Wc1 images (hi + lo), tables, two ones columns, 4 words of weight maxima, one all-zero image
     // (what a weight-gradient product reads in place of an operand it must not add: pvs_rescale_acc)
     static constexpr int kSharedBytes = 2 * kImg2 * 2 + (5 + PVS_MAX_EDGE_ATTR) * kH * 4 + 2 * 64 * 16 + 16 + kImg2 * 2;
-    static_assert(kTile * kTS * 4 + kTile * 16 + kTile * 4 <= 2 * kImg2 * 2, "g_z1 tile + tx + rowbuf must fit the m + gradient images");
+    static_assert(kTile * kTS * 4 + kTile * 16 + kTile * 4 + 64 * 12 <= 2 * kImg2 * 2, "g_z1 tile + tx + rowbuf + the next tile's x must fit the m + gradient images");
+    static_assert(kTile * kTS * 4 + kTile * 16 + kTile * 4 == 5248, "kAheadX");
 };
 
 // ERK: edge residual kind - 0 none; 1 the plain sum m + m_prev (nothing of the residual has to survive the tile's
@@ -288,6 +353,9 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
     AccUnits u_w2{-1}, u_b2{-1}, u_wc1{-1}, u_bc1{-1};
 
     const int total_waves = gridDim.x * NW;
+#ifdef PVS_TILE_TRACE
+    int tile_no = 0;
+#endif
     for (int chunk = pvs_xcd_block(blockIdx.x, gridDim.x) * NW + wv; chunk < n_chunks; chunk += total_waves) {
         // (wave-uniform values that come out of global loads: into scalar registers, the vector file is full)
         const int e_begin = __builtin_amdgcn_readfirstlane(chunk_begin(g, chunk, n_chunks, e_lo, e_hi));
@@ -332,14 +400,29 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             return Loaded{t.i, t.jn, t.ty, t.prev_row};
         };
         Loaded I = load_idx(e_begin, t_end);
+        // (the BASELINE instantiation only: the others pay for the request's address registers with 5-10 more spilled ones)
+        constexpr bool AHEAD = PVS_GATHER_AHEAD != 0 && ERK == 0 && !EATT;
+        const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)A1I);
+        auto ahead = [&](const Loaded& L) {
+            pvs_gather_ahead_issue(io.PQ + (size_t)L.i * 2 * H + 4 * hh, io.PQ + (size_t)L.jn * 2 * H + H + 4 * hh,
+                                   io.x + 3 * (size_t)(hh ? L.jn : L.i), lds_wave);
+        };
+        bool stores5 = false;        // the previous tile issued its five per-edge stores behind the request (a full tile)
+        if (AHEAD && e_begin < e_end) ahead(I);
         for (int e0 = e_begin; e0 < e_end;) {
             const int e_this_end = t_end;
+            if constexpr (AHEAD) {
+                if (stores5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            PVS_TP(21);
             // the next tile: starts where this one ends; past a graph boundary the next boundary applies
             if (g.graph_eptr)    // (empty graphs repeat a boundary)
                 while (gk < g.n_graphs && gb <= e_this_end) { ++gk; gb = __builtin_amdgcn_readfirstlane(g.graph_eptr[gk]); }
             const int e_next = e_this_end < e_end ? e_this_end : e0;
             const int n_end = e_this_end < e_end ? tile_end(e_this_end, gb) : e_this_end;
             const Loaded In = load_idx(e_next, n_end);
+            PVS_TP(0);
             const int e = e0 + j, i = I.i, ty = I.ty;
             const bool valid = e < e_this_end;
             const int ee = min(max(valid ? e : e_this_end - 1, 0), g.n_edges - 1);   // (as load_tile_idx clamps)
@@ -355,14 +438,41 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 TileGather<1> G;
                 TileIdx Ig;
                 Ig.i = I.i; Ig.jn = I.jn;
-                if (PVS_SA_GATHER) gather_tile32<1>(io.PQ, io.x, Ig, hh, G); else gather_tile<1>(io.PQ, io.x, Ig, hh, G);
+#ifdef PVS_ABL_F_QHOT          // timing-only: the column-side rows come from a 256 KB window (what hiding their latency could give)
+                Ig.jn &= 1023;
+#endif
+                if constexpr (AHEAD) {
+                    const float* pfP = reinterpret_cast<const float*>(reinterpret_cast<const char*>(A1I) + kAheadP);
+                    const float* pfQ = reinterpret_cast<const float*>(reinterpret_cast<const char*>(A1I) + kAheadQ);
+                    const float* pfX = reinterpret_cast<const float*>(reinterpret_cast<const char*>(A1I) + kAheadX);
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const float4 pv = *reinterpret_cast<const float4*>(pfP + (gq * 64 + lane) * 4);
+                        const float4 qv = *reinterpret_cast<const float4*>(pfQ + (gq * 64 + lane) * 4);
+                        G.P[0][4 * gq] = pv.x; G.P[0][4 * gq + 1] = pv.y; G.P[0][4 * gq + 2] = pv.z; G.P[0][4 * gq + 3] = pv.w;
+                        G.Q[0][4 * gq] = qv.x; G.Q[0][4 * gq + 1] = qv.y; G.Q[0][4 * gq + 2] = qv.z; G.Q[0][4 * gq + 3] = qv.w;
+                    }
+                    G.d0 = pfX[3 * j] - pfX[3 * (32 + j)];
+                    G.d1 = pfX[3 * j + 1] - pfX[3 * (32 + j) + 1];
+                    G.d2 = pfX[3 * j + 2] - pfX[3 * (32 + j) + 2];
+                } else if (PVS_SA_GATHER) gather_tile32<1>(io.PQ, io.x, Ig, hh, G); else gather_tile<1>(io.PQ, io.x, Ig, hh, G);
                 d0 = G.d0; d1 = G.d1; d2 = G.d2;
                 rho = d0 * d0 + d1 * d1 + d2 * d2;
                 float a1[1][16];
                 assemble_z1<1>(G, attrt, wrhot, ty, hh, rho, a1);
+                PVS_TP(1);
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     float dd[4];
+#if PVS_PAIR_MATH
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2) {
+                        pvs_f2 av, dv;
+                        pvs_silu_grad2(pvs_f2{a1[0][4 * gq + q], a1[0][4 * gq + q + 1]}, av, dv);
+                        a1[0][4 * gq + q] = av.x; a1[0][4 * gq + q + 1] = av.y;
+                        dd[q] = dv.x; dd[q + 1] = dv.y;
+                    }
+#else
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float z = a1[0][4 * gq + q];
@@ -371,11 +481,16 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                         dd[q] = fmaf(av, 1.0f - sg, sg);       // SiLU'(z) = s + z s (1 - s)
                         a1[0][4 * gq + q] = av;
                     }
+#endif
                     *reinterpret_cast<float4*>(d1b + (gq * 64 + lane) * 4) = make_float4(dd[0], dd[1], dd[2], dd[3]);
                 }
+                PVS_TP(18);
                 const float sa1 = LAZY ? lazy_scale(a1[0], kXa1, &inv_sa1) : pvs_tile_scale(a1[0], &inv_sa1);
-                split_f16x2(a1[0], sa1, pb);
+                PVS_TP(19);
+                split_f16x2<PVS_PAIR_MATH>(a1[0], sa1, pb);
+                PVS_TP(20);
                 write_image_f16(A1I, j, hh, pb);
+                PVS_TP(2);
                 f32x16 acc2;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
@@ -383,17 +498,35 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 float bias[1][16];
                 load_tab<1>(b2t, hh, bias);
                 const float k2 = inv_sa1 * inv_sw2;
+#if PVS_PAIR_MATH
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const pvs_f2 z = pvs_fma2(pvs_f2{acc2[r], acc2[r + 1]}, pvs_f2{k2, k2}, pvs_f2{bias[0][r], bias[0][r + 1]});
+                    z2[r] = z.x; z2[r + 1] = z.y;
+                }
+#else
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z2[r] = fmaf(acc2[r], k2, bias[0][r]);
+#endif
+                PVS_TP(3);
             }
             float dz2[16], m[1][16];          // SiLU'(z2) and the message
             float m_new[ERK >= 2 ? 16 : 1], mp[1][16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float sg = pvs_sigmoid(z2[r]);
-                m[0][r] = z2[r] * sg;
-                dz2[r] = fmaf(m[0][r], 1.0f - sg, sg);
-                if constexpr (ERK >= 2) m_new[r] = m[0][r];
+            for (int r = 0; r < 16; r += 2) {
+#if PVS_PAIR_MATH
+                pvs_f2 mv, dv;
+                pvs_silu_grad2(pvs_f2{z2[r], z2[r + 1]}, mv, dv);
+                m[0][r] = mv.x; m[0][r + 1] = mv.y;
+                dz2[r] = dv.x; dz2[r + 1] = dv.y;
+#else
+                for (int t = r; t < r + 2; ++t) {
+                    const float sg = pvs_sigmoid(z2[t]);
+                    m[0][t] = z2[t] * sg;
+                    dz2[t] = fmaf(m[0][t], 1.0f - sg, sg);
+                }
+#endif
+                if constexpr (ERK >= 2) { m_new[r] = m[0][r]; m_new[r + 1] = m[0][r + 1]; }
             }
             if constexpr (ERES) {
                 load_x<1>(io.m_prev + (size_t)ee * H, hh, mp);
@@ -407,6 +540,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             // ---- gradient wrt m: the coordinate branch's term comes from the matrix core first; the external,
             // aggregated-message and attention terms are added AFTER it (g_m is then not live across the
             // coordinate branch) ----
+            PVS_TP(4);
             float gm[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) gm[r] = 0.f;
@@ -470,8 +604,11 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 const float* gT = PVS_SA_ROW ? pvs_off(io.gxagg, 12u * (unsigned)i) : io.gxagg + 3 * i;
                 gT0 = gT[0]; gT1 = gT[1]; gT2 = gT[2];
                 const float sm = LAZY ? lazy_scale(m[0], kXm, &inv_sm) : pvs_tile_scale(m[0], &inv_sm);
-                split_f16x2(m[0], sm, pb);
+                PVS_TP(16);
+                split_f16x2<PVS_PAIR_MATH>(m[0], sm, pb);
+                PVS_TP(17);
                 write_image_f16(MI, j, hh, pb);
+                PVS_TP(5);
                 f32x16 accc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accc[r] = 0.f;
@@ -483,12 +620,25 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 float q[16], dq[16];
                 float s = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float zc = fmaf(accc[r], kc, bias2[0][r]);   // zc = Wc1 m + bc1
-                    const float sg = pvs_sigmoid(zc);
-                    q[r] = zc * sg;
-                    dq[r] = fmaf(q[r], 1.0f - sg, sg);
+                for (int r = 0; r < 16; r += 2) {
+#if PVS_PAIR_MATH
+                    const pvs_f2 zc = pvs_fma2(pvs_f2{accc[r], accc[r + 1]}, pvs_f2{kc, kc}, pvs_f2{bias2[0][r], bias2[0][r + 1]});
+                    pvs_f2 qv, dv;
+                    pvs_silu_grad2(zc, qv, dv);
+                    q[r] = qv.x; q[r + 1] = qv.y;
+                    dq[r] = dv.x; dq[r + 1] = dv.y;
+#else
+                    for (int t = r; t < r + 2; ++t) {
+                        const float zc = fmaf(accc[t], kc, bias2[0][t]);   // zc = Wc1 m + bc1
+                        const float sg = pvs_sigmoid(zc);
+                        q[t] = zc * sg;
+                        dq[t] = fmaf(q[t], 1.0f - sg, sg);
+                    }
+#endif
+                    // (one running sum: a pair of partial sums, or a wave-uniform fast path for full tiles behind the
+                    // chain, each cost this instantiation 3-5 spilled registers)
                     s = fmaf(wc2x[0][r], q[r], s);
+                    s = fmaf(wc2x[0][r + 1], q[r + 1], s);
                 }
                 s = pvs_xor32_sum(s);
                 float dact = 1.f;
@@ -502,10 +652,12 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                     g_zc[r] = g_s * wc2x[0][r] * dq[r];
                     g_wc2x[r] = fmaf(g_s, q[r], g_wc2x[r]);
                 }
+                PVS_TP(6);
                 float inv_sg;
                 const float sg_ = LAZY ? lazy_scale(g_zc, kXg, &inv_sg) : pvs_tile_scale(g_zc, &inv_sg);
-                split_f16x2(g_zc, sg_, pb);
+                split_f16x2<PVS_PAIR_MATH>(g_zc, sg_, pb);
                 write_image_f16(GI, j, hh, pb);
+                PVS_TP(7);
                 f32x16 accg;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accg[r] = 0.f;
@@ -513,6 +665,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 const float kg = inv_sg * inv_swc1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gm[r] = accg[r] * kg;
+                PVS_TP(8);
                 pvs_wave_lds_sync();                                  // the m and g_zc images are complete
                 // gWc1 += g_zc (x) m ; g_bc1 += sum_e g_zc
                 if constexpr (LAZY) {
@@ -527,6 +680,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             } else {
                 load_row_terms();
             }
+            PVS_TP(9);
             add_row_terms();
             // ---- edge residual; g_z2 = g_m_new * SiLU'(z2) ----
             float g_z2[16];
@@ -564,15 +718,17 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 if (valid) store_x<1>(io.g_m_prev + (size_t)e * H, hh, mp);
             }
             // ---- g_a1 = W2^T g_z2 ; gW2 += g_z2 (x) a1 ; g_b2 += sum_e g_z2 ; g_z1 = g_a1 * SiLU'(z1) ----
+            PVS_TP(10);
             float inv_sg2;
             const float sg2 = LAZY ? lazy_scale(g_z2, kXg2, &inv_sg2) : pvs_tile_scale(g_z2, &inv_sg2);
-            split_f16x2(g_z2, sg2, pb);
+            split_f16x2<PVS_PAIR_MATH>(g_z2, sg2, pb);
             pvs_wave_lds_sync();                                      // the g_zc image has been read
             write_image_f16(GI, j, hh, pb);
             f32x16 ga1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ga1[r] = 0.f;
             chain_f16<true>(W2i, lane, pb, ga1);
+            PVS_TP(11);
             pvs_wave_lds_sync();                                      // the a1 and g_z2 images are complete
             if constexpr (LAZY) {
                 const int what = pvs_rescale_acc(gW2, gB, j == 1, u_w2, u_b2, lazy_e(kXg2), lazy_e(kXa1));
@@ -580,6 +736,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             } else {
                 F16_WGRAD(GI, A1I, ones1, lane, inv_sg2 * inv_sa1, inv_sg2, gW2, gB);
             }
+            PVS_TP(12);
             float g_z1[1][16];
             const float k1g = inv_sg2 * inv_sw2;
 #pragma unroll
@@ -595,7 +752,12 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             const float gd0 = fmaf(k1, gT0, 2.f * d0 * g_rho);
             const float gd1 = fmaf(k1, gT1, 2.f * d1 * g_rho);
             const float gd2 = fmaf(k1, gT2, 2.f * d2 * g_rho);
+            PVS_TP(13);
             pvs_wave_lds_sync();          // every read of the m / gradient images (their slots become the g_z1 tile) is done
+            if constexpr (AHEAD) {        // (the a1 image and SiLU'(z1) are dead too: the next tile's rows go there)
+                ahead(In);
+                stores5 = e_this_end - e0 == kTile;
+            }
             // per edge: grad wrt (x_row - x_col) and rho, 16 B, for the node gather kernel
             if (hh == 0) {
                 *reinterpret_cast<float4*>(tx + j * 4) = make_float4(gd0, gd1, gd2, 0.f);
@@ -617,6 +779,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 *reinterpret_cast<float4*>(T1 + (TSWZ ? pvs_tile_quad_off<1>(j, 2 * gq + hh) : j * Cfg::kTS + 8 * gq + 4 * hh)) =
                     make_float4(g_z1[0][4 * gq], g_z1[0][4 * gq + 1], g_z1[0][4 * gq + 2], g_z1[0][4 * gq + 3]);
             pvs_wave_lds_sync();
+            PVS_TP(14);
 #ifndef PVS_ABL_F_NOREDUCE
             reduce_rows_tile<1, false, true, TSWZ>(T1, tx, rowbuf, bmask, lane, acc, accx, cur_row, flush,
                                 [&](int rl, int q, const float4& v) {
@@ -636,9 +799,14 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             e0 = e_this_end;
             t_end = n_end;
             pvs_wave_lds_sync();
+            PVS_TP(15);
+#ifdef PVS_TILE_TRACE
+            ++tile_no;
+#endif
         }
         flush(cur_row);
     }
+    if (PVS_GATHER_AHEAD && ERK == 0 && !EATT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the last request of a chunk is never read)
 
     // ---- block reduction into one slab, fixed order ----
     const PvsSlabLayout L = pvs_slab_layout(H);
@@ -705,6 +873,12 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 }
 
 }  // namespace
+
+#ifdef PVS_TILE_TRACE
+extern "C" int pvs_debug_tile_trace(unsigned long long* dst, size_t count) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pvs_trace_buf), count * sizeof(unsigned long long));
+}
+#endif
 
 // Same contract as pvs_launch_edge_bwd_mfma (edge_mfma.hip). H = 32 only.
 int pvs_launch_edge_bwd_f16(hipStream_t s, int H, const PvsGraph& g, const PvsEdgeW& w, uint32_t flags, int att_act,

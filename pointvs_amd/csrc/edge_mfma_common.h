@@ -127,17 +127,40 @@ __device__ __forceinline__ float pvs_xor_sum(float v) {
     else return pvs_xor32_sum(v);
 }
 
+// Pair arithmetic (common.h pvs_f2): the elementwise work of the edge kernels on two adjacent registers per instruction.
+#ifndef PVS_PAIR_MATH
+#define PVS_PAIR_MATH 1
+#endif
+// H = 32 only. At 128 channels register pairs cost the softmax forward its second wave per SIMD; the 64-channel forward
+// (768 threads, 168 registers) was 1.4 % SLOWER with it and its results were wrong and changed from run to run (26 of the
+// 212 GPU tests, all 64-channel cases: profiles/r05_ab_pair_math.txt) - the second time that kernel breaks under a change
+// that is arithmetic-neutral in the source (32-bit lane offsets, PVS_FWD_SADDR, was the first).
+template <int HB> constexpr bool pvs_pair_math = PVS_PAIR_MATH && HB == 1;
+
 template <int HB>
 __device__ __forceinline__ float dot_tab(const float* __restrict__ tab, int hh, const float (&v)[HB][16]) {
     float s = 0.f;
+    if constexpr (pvs_pair_math<HB>) {
+        pvs_f2 s2{0.f, 0.f};            // (even and odd channels apart: half the instructions of one running sum)
 #pragma unroll
-    for (int b = 0; b < HB; ++b)
+        for (int b = 0; b < HB; ++b)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 w = *reinterpret_cast<const float4*>(tab + 32 * b + 8 * g + 4 * hh);
-            s = fmaf(w.x, v[b][4 * g], s); s = fmaf(w.y, v[b][4 * g + 1], s);
-            s = fmaf(w.z, v[b][4 * g + 2], s); s = fmaf(w.w, v[b][4 * g + 3], s);
-        }
+            for (int g = 0; g < 4; ++g) {
+                const float4 w = *reinterpret_cast<const float4*>(tab + 32 * b + 8 * g + 4 * hh);
+                s2 = pvs_fma2(pvs_f2{w.x, w.y}, pvs_f2{v[b][4 * g], v[b][4 * g + 1]}, s2);
+                s2 = pvs_fma2(pvs_f2{w.z, w.w}, pvs_f2{v[b][4 * g + 2], v[b][4 * g + 3]}, s2);
+            }
+        s = s2.x + s2.y;
+    } else {
+#pragma unroll
+        for (int b = 0; b < HB; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 w = *reinterpret_cast<const float4*>(tab + 32 * b + 8 * g + 4 * hh);
+                s = fmaf(w.x, v[b][4 * g], s); s = fmaf(w.y, v[b][4 * g + 1], s);
+                s = fmaf(w.z, v[b][4 * g + 2], s); s = fmaf(w.w, v[b][4 * g + 3], s);
+            }
+    }
     return pvs_xor32_sum(s);            // other half holds the other 16 channels of each block
 }
 
@@ -269,6 +292,15 @@ __device__ __forceinline__ void assemble_z1(const TileGather<HB>& G, const float
         for (int gq = 0; gq < 4; ++gq) {
             const float4 a = *reinterpret_cast<const float4*>(At + 32 * b + 8 * gq);
             const float4 r = *reinterpret_cast<const float4*>(Rt + 32 * b + 8 * gq);
+            if constexpr (pvs_pair_math<HB>) {
+                const pvs_f2 rho2{rho, rho};
+                const pvs_f2 lo = pvs_f2{G.P[b][4 * gq], G.P[b][4 * gq + 1]} + pvs_f2{G.Q[b][4 * gq], G.Q[b][4 * gq + 1]} +
+                                  pvs_fma2(pvs_f2{r.x, r.y}, rho2, pvs_f2{a.x, a.y});
+                const pvs_f2 hi = pvs_f2{G.P[b][4 * gq + 2], G.P[b][4 * gq + 3]} + pvs_f2{G.Q[b][4 * gq + 2], G.Q[b][4 * gq + 3]} +
+                                  pvs_fma2(pvs_f2{r.z, r.w}, rho2, pvs_f2{a.z, a.w});
+                z1[b][4 * gq] = lo.x; z1[b][4 * gq + 1] = lo.y; z1[b][4 * gq + 2] = hi.x; z1[b][4 * gq + 3] = hi.y;
+                continue;
+            }
             z1[b][4 * gq] = G.P[b][4 * gq] + G.Q[b][4 * gq] + fmaf(r.x, rho, a.x);
             z1[b][4 * gq + 1] = G.P[b][4 * gq + 1] + G.Q[b][4 * gq + 1] + fmaf(r.y, rho, a.y);
             z1[b][4 * gq + 2] = G.P[b][4 * gq + 2] + G.Q[b][4 * gq + 2] + fmaf(r.z, rho, a.z);
@@ -315,7 +347,14 @@ __device__ __forceinline__ void reduce_rows_tile(const float* __restrict__ T, co
         const unsigned upto = rl == 31 ? 0xffffffffu : ((2u << rl) - 1u);
         seg[k] = __popc(bmask & upto);
     }
-    auto add4 = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    auto add4 = [](float4& a, const float4& b) {
+        if constexpr (pvs_pair_math<HB>) {
+            const pvs_f2 lo = pvs_f2{a.x, a.y} + pvs_f2{b.x, b.y}, hi = pvs_f2{a.z, a.w} + pvs_f2{b.z, b.w};
+            a.x = lo.x; a.y = lo.y; a.z = hi.x; a.w = hi.y;
+        } else {
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+    };
     if (bmask == 0u) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) { add4(acc, v[k]); add4(accx, dx[k]); }
@@ -515,8 +554,15 @@ __device__ __forceinline__ unsigned pvs_f16_lo2(float x0, float x1, float s, uns
 // against 22.9 for  y = x s (2 x v_mul, exact: s is a power of two), h = cvt_pk(y0, y1) (round to nearest even,
 // the rounding of mixlo), r = y - f32(h half) (v_fma_mix_f32: exact, the difference has at most 13 significant
 // bits), l = cvt_pk(r0, r1). Bit for bit the words of pvs_f16_hi2 / pvs_f16_lo2.
+template <bool PAIR = false>
 __device__ __forceinline__ void pvs_f16_split2(float x0, float x1, float s, unsigned& h, unsigned& l) {
-    const float y0 = x0 * s, y1 = x1 * s;
+    float y0, y1;
+    if constexpr (PAIR) {
+        const pvs_f2 y = pvs_f2{x0, x1} * s;        // one v_pk_mul_f32
+        y0 = y.x; y1 = y.y;
+    } else {
+        y0 = x0 * s; y1 = x1 * s;
+    }
     float r0, r1;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(y0), "v"(y1));
     asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(y0), "v"(h));
@@ -524,6 +570,7 @@ __device__ __forceinline__ void pvs_f16_split2(float x0, float x1, float s, unsi
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(r0), "v"(r1));
 }
 
+template <bool PAIR = false>
 __device__ __forceinline__ void split_f16x2(const float (&v)[16], float s, F16Parts& out) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -537,7 +584,7 @@ __device__ __forceinline__ void split_f16x2(const float (&v)[16], float s, F16Pa
             h[q] = pvs_f16_hi2(x0, x1, s);
             l[q] = pvs_f16_lo2(x0, x1, s, h[q]);
 #else
-            pvs_f16_split2(x0, x1, s, h[q], l[q]);
+            pvs_f16_split2<PAIR>(x0, x1, s, h[q], l[q]);
 #endif
         }
         out.hi[ks] = __builtin_bit_cast(f16x8, ph);
@@ -594,7 +641,7 @@ __device__ __forceinline__ void mfma_chain_f16x2_blocks(const unsigned* __restri
 #pragma unroll
     for (int bi = 0; bi < HB; ++bi) {
         F16Parts b;
-        split_f16x2(v[bi], s_v, b);
+        split_f16x2<pvs_pair_math<HB>>(v[bi], s_v, b);
 #pragma unroll
         for (int bo = 0; bo < HB; ++bo) {
             const unsigned* Wblk = Wb + (bo * HB + bi) * (4 * 64 * 4);

@@ -182,7 +182,14 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
 #pragma unroll
             for (int b = 0; b < HB; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a1[b][r] = pvs_silu(a1[b][r]);
+                for (int r = 0; r < 16; r += 2) {
+                    if constexpr (pvs_pair_math<HB>) {
+                        const pvs_f2 av = pvs_silu2(pvs_f2{a1[b][r], a1[b][r + 1]});
+                        a1[b][r] = av.x; a1[b][r + 1] = av.y;
+                    } else {
+                        a1[b][r] = pvs_silu(a1[b][r]); a1[b][r + 1] = pvs_silu(a1[b][r + 1]);
+                    }
+                }
             // ---- second layer on the matrix cores: m = SiLU(W2 a1 + b2) ----
             {
                 f32x16 acc2[HB];
@@ -201,7 +208,15 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
 #pragma unroll
                     for (int b = 0; b < HB; ++b)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) m[b][r] = pvs_silu(fmaf(acc2[b][r], k2, bias[b][r]));
+                        for (int r = 0; r < 16; r += 2) {
+                            if constexpr (pvs_pair_math<HB>) {
+                                const pvs_f2 mv = pvs_silu2(pvs_fma2(pvs_f2{acc2[b][r], acc2[b][r + 1]}, pvs_f2{k2, k2}, pvs_f2{bias[b][r], bias[b][r + 1]}));
+                                m[b][r] = mv.x; m[b][r + 1] = mv.y;
+                            } else {
+                                m[b][r] = pvs_silu(fmaf(acc2[b][r], k2, bias[b][r]));
+                                m[b][r + 1] = pvs_silu(fmaf(acc2[b][r + 1], k2, bias[b][r + 1]));
+                            }
+                        }
                 } else {
 #pragma unroll
                     for (int b = 0; b < HB; ++b)
@@ -258,7 +273,15 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
 #pragma unroll
                     for (int b = 0; b < HB; ++b)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) q[b][r] = pvs_silu(fmaf(accc[b][r], kc, bias[b][r]));
+                        for (int r = 0; r < 16; r += 2) {
+                            if constexpr (pvs_pair_math<HB>) {
+                                const pvs_f2 qv = pvs_silu2(pvs_fma2(pvs_f2{accc[b][r], accc[b][r + 1]}, pvs_f2{kc, kc}, pvs_f2{bias[b][r], bias[b][r + 1]}));
+                                q[b][r] = qv.x; q[b][r + 1] = qv.y;
+                            } else {
+                                q[b][r] = pvs_silu(fmaf(accc[b][r], kc, bias[b][r]));
+                                q[b][r + 1] = pvs_silu(fmaf(accc[b][r + 1], kc, bias[b][r + 1]));
+                            }
+                        }
                 } else {
 #pragma unroll
                     for (int b = 0; b < HB; ++b)
@@ -312,9 +335,16 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
             for (int b = 0; b < HB; ++b)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq)
-                    *reinterpret_cast<float4*>(tile + j * TS + 32 * b + 8 * gq + 4 * hh) =
-                        make_float4(wgt * m[b][4 * gq], wgt * m[b][4 * gq + 1], wgt * m[b][4 * gq + 2],
-                                    wgt * m[b][4 * gq + 3]);
+                {
+                    if constexpr (pvs_pair_math<HB>) {
+                        const pvs_f2 lo = pvs_f2{m[b][4 * gq], m[b][4 * gq + 1]} * wgt, hi = pvs_f2{m[b][4 * gq + 2], m[b][4 * gq + 3]} * wgt;
+                        *reinterpret_cast<float4*>(tile + j * TS + 32 * b + 8 * gq + 4 * hh) = make_float4(lo.x, lo.y, hi.x, hi.y);
+                    } else {
+                        *reinterpret_cast<float4*>(tile + j * TS + 32 * b + 8 * gq + 4 * hh) =
+                            make_float4(wgt * m[b][4 * gq], wgt * m[b][4 * gq + 1], wgt * m[b][4 * gq + 2],
+                                        wgt * m[b][4 * gq + 3]);
+                    }
+                }
             }
             if (hh == 0) {
                 const float sv = valid ? s : 0.f;
