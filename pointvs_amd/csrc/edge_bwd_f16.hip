@@ -33,52 +33,7 @@
 #define PVS_SA_STORE 0
 #endif
 
-#ifndef PVS_GATHER_AHEAD
-#define PVS_GATHER_AHEAD 0
-#endif
-// (tools/micro/glds_offset_test.hip: does the immediate offset of global_load_lds move the LDS address as well?)
-#ifndef PVS_GLDS_OFFSET_MOVES_LDS
-#define PVS_GLDS_OFFSET_MOVES_LDS 1
-#endif
-
 namespace {
-
-// ---- the next tile's node rows, fetched one tile ahead by LDS-DMA (round 5) ------------------------------------------
-// A tile's gather (P_i, Q_j, x_i, x_j) used to be issued at its top and waited for at once: ~1,450 cycles per tile with
-// nothing else for the wave to do, and the vector-memory counter completes in order, so the wait also sat out the
-// previous tile's five row stores (tools/tile_trace.py). The registers to hold a tile's rows across the row reduction
-// are not there (255 of 256), but the LDS is: when g_z1 has been formed the a1 image and the SiLU'(z1) slot are dead.
-// So the rows of tile t + 1 are requested BEFORE tile t's stores, as global_load_lds (no register destination: lane l's
-// 16 bytes land at M0 + 16 l, the lane-private [piece][lane] order the X layout reads back), and waited for at the top of
-// tile t + 1 with a COUNTED s_waitcnt that leaves the stores in flight. hipcc does not see an asm load in its own
-// s_waitcnt bookkeeping, which only makes its waits conservative (it believes fewer operations are outstanding than are).
-// Layout per wave: Q pieces in the a1 image slot, P pieces in the SiLU'(z1) slot, x_i (lanes 0-31) / x_j (lanes 32-63)
-// behind the g_z1 tile's row buffer.
-constexpr int kAheadQ = 0, kAheadP = 12288, kAheadX = 4096 + 5248;     // byte offsets from the wave's LDS base
-constexpr int kGldsK = PVS_GLDS_OFFSET_MOVES_LDS ? 32 : 0;
-#define PVS_STR2(x) #x
-#define PVS_STR(x) PVS_STR2(x)
-__device__ __forceinline__ void pvs_gather_ahead_issue(const float* pp, const float* qp, const float* xp, unsigned lds_wave) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_add_i32 m0, %4, %5\n\t s_nop 0\n\t global_load_lds_dwordx4 %1, off\n\t"
-        "s_add_i32 m0, %4, %6\n\t s_nop 0\n\t global_load_lds_dwordx4 %1, off offset:32\n\t"
-        "s_add_i32 m0, %4, %7\n\t s_nop 0\n\t global_load_lds_dwordx4 %1, off offset:64\n\t"
-        "s_add_i32 m0, %4, %8\n\t s_nop 0\n\t global_load_lds_dwordx4 %1, off offset:96\n\t"
-        "s_add_i32 m0, %4, %9\n\t s_nop 0\n\t global_load_lds_dwordx4 %2, off\n\t"
-        "s_add_i32 m0, %4, %10\n\t s_nop 0\n\t global_load_lds_dwordx4 %2, off offset:32\n\t"
-        "s_add_i32 m0, %4, %11\n\t s_nop 0\n\t global_load_lds_dwordx4 %2, off offset:64\n\t"
-        "s_add_i32 m0, %4, %12\n\t s_nop 0\n\t global_load_lds_dwordx4 %2, off offset:96\n\t"
-        "s_add_i32 m0, %4, %13\n\t s_nop 0\n\t global_load_lds_dwordx3 %3, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(pp), "v"(qp), "v"(xp), "s"(lds_wave),
-          "i"(kAheadP), "i"(kAheadP + 1024 - kGldsK), "i"(kAheadP + 2 * (1024 - kGldsK)), "i"(kAheadP + 3 * (1024 - kGldsK)),
-          "i"(kAheadQ), "i"(kAheadQ + 1024 - kGldsK), "i"(kAheadQ + 2 * (1024 - kGldsK)), "i"(kAheadQ + 3 * (1024 - kGldsK)),
-          "i"(kAheadX)
-        : "memory");
-}
 
 // timing-only ablation (tools/variant_obj.sh -DPVS_ABL_F_SCATTER): the per-edge outputs at scattered positions of a
 // 256k-edge region, the access pattern of a by-column layout
@@ -235,8 +190,7 @@ struct F16Cfg {
     // shared: W2 and Wc1 images (hi + lo), tables, two ones columns, 4 words of weight maxima, one all-zero image
     // (what a weight-gradient product reads in place of an operand it must not add: pvs_rescale_acc)
     static constexpr int kSharedBytes = 2 * kImg2 * 2 + (5 + PVS_MAX_EDGE_ATTR) * kH * 4 + 2 * 64 * 16 + 16 + kImg2 * 2;
-    static_assert(kTile * kTS * 4 + kTile * 16 + kTile * 4 + 64 * 12 <= 2 * kImg2 * 2, "g_z1 tile + tx + rowbuf + the next tile's x must fit the m + gradient images");
-    static_assert(kTile * kTS * 4 + kTile * 16 + kTile * 4 == 5248, "kAheadX");
+    static_assert(kTile * kTS * 4 + kTile * 16 + kTile * 4 <= 2 * kImg2 * 2, "g_z1 tile + tx + rowbuf must fit the m + gradient images");
 };
 
 // ERK: edge residual kind - 0 none; 1 the plain sum m + m_prev (nothing of the residual has to survive the tile's
@@ -400,21 +354,8 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             return Loaded{t.i, t.jn, t.ty, t.prev_row};
         };
         Loaded I = load_idx(e_begin, t_end);
-        // (the BASELINE instantiation only: the others pay for the request's address registers with 5-10 more spilled ones)
-        constexpr bool AHEAD = PVS_GATHER_AHEAD != 0 && ERK == 0 && !EATT;
-        const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)A1I);
-        auto ahead = [&](const Loaded& L) {
-            pvs_gather_ahead_issue(io.PQ + (size_t)L.i * 2 * H + 4 * hh, io.PQ + (size_t)L.jn * 2 * H + H + 4 * hh,
-                                   io.x + 3 * (size_t)(hh ? L.jn : L.i), lds_wave);
-        };
-        bool stores5 = false;        // the previous tile issued its five per-edge stores behind the request (a full tile)
-        if (AHEAD && e_begin < e_end) ahead(I);
         for (int e0 = e_begin; e0 < e_end;) {
             const int e_this_end = t_end;
-            if constexpr (AHEAD) {
-                if (stores5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
             PVS_TP(21);
             // the next tile: starts where this one ends; past a graph boundary the next boundary applies
             if (g.graph_eptr)    // (empty graphs repeat a boundary)
@@ -441,21 +382,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 #ifdef PVS_ABL_F_QHOT          // timing-only: the column-side rows come from a 256 KB window (what hiding their latency could give)
                 Ig.jn &= 1023;
 #endif
-                if constexpr (AHEAD) {
-                    const float* pfP = reinterpret_cast<const float*>(reinterpret_cast<const char*>(A1I) + kAheadP);
-                    const float* pfQ = reinterpret_cast<const float*>(reinterpret_cast<const char*>(A1I) + kAheadQ);
-                    const float* pfX = reinterpret_cast<const float*>(reinterpret_cast<const char*>(A1I) + kAheadX);
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const float4 pv = *reinterpret_cast<const float4*>(pfP + (gq * 64 + lane) * 4);
-                        const float4 qv = *reinterpret_cast<const float4*>(pfQ + (gq * 64 + lane) * 4);
-                        G.P[0][4 * gq] = pv.x; G.P[0][4 * gq + 1] = pv.y; G.P[0][4 * gq + 2] = pv.z; G.P[0][4 * gq + 3] = pv.w;
-                        G.Q[0][4 * gq] = qv.x; G.Q[0][4 * gq + 1] = qv.y; G.Q[0][4 * gq + 2] = qv.z; G.Q[0][4 * gq + 3] = qv.w;
-                    }
-                    G.d0 = pfX[3 * j] - pfX[3 * (32 + j)];
-                    G.d1 = pfX[3 * j + 1] - pfX[3 * (32 + j) + 1];
-                    G.d2 = pfX[3 * j + 2] - pfX[3 * (32 + j) + 2];
-                } else if (PVS_SA_GATHER) gather_tile32<1>(io.PQ, io.x, Ig, hh, G); else gather_tile<1>(io.PQ, io.x, Ig, hh, G);
+                if (PVS_SA_GATHER) gather_tile32<1>(io.PQ, io.x, Ig, hh, G); else gather_tile<1>(io.PQ, io.x, Ig, hh, G);
                 d0 = G.d0; d1 = G.d1; d2 = G.d2;
                 rho = d0 * d0 + d1 * d1 + d2 * d2;
                 float a1[1][16];
@@ -754,10 +681,6 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             const float gd2 = fmaf(k1, gT2, 2.f * d2 * g_rho);
             PVS_TP(13);
             pvs_wave_lds_sync();          // every read of the m / gradient images (their slots become the g_z1 tile) is done
-            if constexpr (AHEAD) {        // (the a1 image and SiLU'(z1) are dead too: the next tile's rows go there)
-                ahead(In);
-                stores5 = e_this_end - e0 == kTile;
-            }
             // per edge: grad wrt (x_row - x_col) and rho, 16 B, for the node gather kernel
             if (hh == 0) {
                 *reinterpret_cast<float4*>(tx + j * 4) = make_float4(gd0, gd1, gd2, 0.f);
@@ -806,7 +729,6 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
         }
         flush(cur_row);
     }
-    if (PVS_GATHER_AHEAD && ERK == 0 && !EATT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the last request of a chunk is never read)
 
     // ---- block reduction into one slab, fixed order ----
     const PvsSlabLayout L = pvs_slab_layout(H);
