@@ -23,6 +23,13 @@
 // Reference semantics: autograd of EGNNLayer.edge_model / coord_model / node_model's aggregation,
 // /root/reference/point_vs/models/geometric/egnn_satorras.py:123-206 (SURVEY.md §8a "Backward spec").
 #include "edge_mfma_common.h"
+// Pair arithmetic (common.h pvs_f2) in the elementwise blocks that have no product to run beside: one wave per SIMD
+// issues one instruction per ~5 cycles whatever it is, so two results per instruction is two issue slots for one
+// (cfg3: -1...1.7 % per launch). NOT in the block woven beside the gW2 product (wgrad16_beside): paired there, the
+// pinned units no longer fill the MFMAs' shadows evenly (23 more s_nop, +0.5 % instead of -1 %).
+#ifndef PVS_PAIR_H64
+#define PVS_PAIR_H64 1
+#endif
 
 namespace {
 
@@ -418,7 +425,14 @@ __device__ __forceinline__ void reduce_rows16(const float* __restrict__ T, const
         store_row(rl, quad, v[k]);
         seg[k] = __popc(bmask & ((2u << rl) - 1u));
     }
-    auto add4 = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    auto add4 = [](float4& a, const float4& b) {
+#if PVS_PAIR_H64
+        const pvs_f2 lo = pvs_f2{a.x, a.y} + pvs_f2{b.x, b.y}, hi = pvs_f2{a.z, a.w} + pvs_f2{b.z, b.w};
+        a.x = lo.x; a.y = lo.y; a.z = hi.x; a.w = hi.y;
+#else
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+#endif
+    };
     if (bmask == 0u) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { add4(acc, v[k]); add4(accx, dx[k]); }
@@ -652,12 +666,21 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             float dz2[16], m[16];             // SiLU'(z2) and the message
             float m_new[ERK == 2 ? 16 : 1];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float z2 = acc2[r >> 2][r & 3];
-                const float sg = pvs_sigmoid(z2);
-                m[r] = z2 * sg;
-                dz2[r] = fmaf(m[r], 1.0f - sg, sg);
-                if constexpr (ERK == 2) m_new[r] = m[r];
+            for (int r = 0; r < 16; r += 2) {
+#if PVS_PAIR_H64
+                pvs_f2 mv, dv;
+                pvs_silu_grad2(pvs_f2{acc2[r >> 2][r & 3], acc2[r >> 2][(r & 3) + 1]}, mv, dv);
+                m[r] = mv.x; m[r + 1] = mv.y;
+                dz2[r] = dv.x; dz2[r + 1] = dv.y;
+#else
+                for (int t = r; t < r + 2; ++t) {
+                    const float z2 = acc2[t >> 2][t & 3];
+                    const float sg = pvs_sigmoid(z2);
+                    m[t] = z2 * sg;
+                    dz2[t] = fmaf(m[t], 1.0f - sg, sg);
+                }
+#endif
+                if constexpr (ERK == 2) { m_new[r] = m[r]; m_new[r + 1] = m[r + 1]; }
             }
             if constexpr (ERES) {
 #pragma unroll
@@ -689,6 +712,18 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 load_y(wc2t, gr, wc2y);
                 float q[16], dq[16];
                 float s = 0.f;
+#if PVS_PAIR_H64
+                pvs_f2 s2{0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    pvs_f2 qv, dv;
+                    pvs_silu_grad2(pvs_f2{accc[r >> 2][r & 3], accc[r >> 2][(r & 3) + 1]}, qv, dv);
+                    q[r] = qv.x; q[r + 1] = qv.y;
+                    dq[r] = dv.x; dq[r + 1] = dv.y;
+                    s2 = pvs_fma2(pvs_f2{wc2y[r], wc2y[r + 1]}, qv, s2);
+                }
+                s = s2.x + s2.y;
+#else
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float zc = accc[r >> 2][r & 3];
@@ -697,6 +732,7 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                     dq[r] = fmaf(q[r], 1.0f - sg, sg);
                     s = fmaf(wc2y[r], q[r], s);
                 }
+#endif
                 s = sum_groups(s);
                 float dact = 1.f;
                 if (flags & PVS_TANH) { s = pvs_tanh(s); dact = 1.f - s * s; }
@@ -705,10 +741,21 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 const float g_s = (d0 * gT0 + d1 * gT1 + d2 * gT2) * nrm * dact * vm;
                 float g_zc[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    g_zc[r] = g_s * wc2y[r] * dq[r];
-                    g_wc2y[r] = fmaf(g_s, q[r], g_wc2y[r]);
-                    g_bc1y[r] += g_zc[r];
+                for (int r = 0; r < 16; r += 2) {
+#if PVS_PAIR_H64
+                    const pvs_f2 gz = pvs_f2{wc2y[r], wc2y[r + 1]} * g_s * pvs_f2{dq[r], dq[r + 1]};
+                    const pvs_f2 gw = pvs_fma2(pvs_f2{q[r], q[r + 1]}, pvs_f2{g_s, g_s}, pvs_f2{g_wc2y[r], g_wc2y[r + 1]});
+                    const pvs_f2 gb = pvs_f2{g_bc1y[r], g_bc1y[r + 1]} + gz;
+                    g_zc[r] = gz.x; g_zc[r + 1] = gz.y;
+                    g_wc2y[r] = gw.x; g_wc2y[r + 1] = gw.y;
+                    g_bc1y[r] = gb.x; g_bc1y[r + 1] = gb.y;
+#else
+                    for (int t = r; t < r + 2; ++t) {
+                        g_zc[t] = g_s * wc2y[t] * dq[t];
+                        g_wc2y[t] = fmaf(g_s, q[t], g_wc2y[t]);
+                        g_bc1y[t] += g_zc[t];
+                    }
+#endif
                 }
                 load_y(io.gM + (size_t)i * H, gr, gMi);               // (in flight behind the two products below)
                 H64_CHAINS(true, Wc1i, lane, g_zc, pb, gm);            // g_m += Wc1^T g_zc
@@ -729,24 +776,53 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                     float way[16];
                     load_y(wat, gr, way);
                     float logit = 0.f, dot = 0.f;
+#if PVS_PAIR_H64
+                    pvs_f2 l2{0.f, 0.f}, d2p{0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const pvs_f2 mv{m[r], m[r + 1]};
+                        l2 = pvs_fma2(pvs_f2{way[r], way[r + 1]}, mv, l2);
+                        d2p = pvs_fma2(mv, pvs_f2{gMi[r], gMi[r + 1]}, d2p);
+                    }
+                    logit = l2.x + l2.y;
+                    dot = d2p.x + d2p.y;
+#else
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         logit = fmaf(way[r], m[r], logit);
                         dot = fmaf(m[r], gMi[r], dot);
                     }
+#endif
                     logit = sum_groups(logit) + bac;
                     dot = sum_groups(dot);
                     const float g_l = (flags & PVS_SOFTMAX_ATT) ? aval * (dot - softd) * vm     // softD = M_i . g_M_i
                                                                 : pvs_att_act_grad(att_act, logit, aval) * dot * vm;
                     if (gr == 0) g_ba += g_l;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        gm[r >> 2][r & 3] += (aval * vm) * gMi[r] + g_l * way[r];
-                        g_way[r] = fmaf(g_l, m[r], g_way[r]);
+                    for (int r = 0; r < 16; r += 2) {
+#if PVS_PAIR_H64
+                        const pvs_f2 t = pvs_fma2(pvs_f2{gMi[r], gMi[r + 1]}, pvs_f2{aval * vm, aval * vm}, pvs_f2{way[r], way[r + 1]} * g_l);
+                        const pvs_f2 gw = pvs_fma2(pvs_f2{m[r], m[r + 1]}, pvs_f2{g_l, g_l}, pvs_f2{g_way[r], g_way[r + 1]});
+                        gm[r >> 2][r & 3] += t.x; gm[r >> 2][(r & 3) + 1] += t.y;
+                        g_way[r] = gw.x; g_way[r + 1] = gw.y;
+#else
+                        for (int t = r; t < r + 2; ++t) {
+                            gm[t >> 2][t & 3] += (aval * vm) * gMi[t] + g_l * way[t];
+                            g_way[t] = fmaf(g_l, m[t], g_way[t]);
+                        }
+#endif
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) gm[r >> 2][r & 3] = fmaf(vm, gMi[r], gm[r >> 2][r & 3]);
+                    for (int r = 0; r < 16; r += 2) {
+#if PVS_PAIR_H64
+                        const pvs_f2 t = pvs_fma2(pvs_f2{gMi[r], gMi[r + 1]}, pvs_f2{vm, vm}, pvs_f2{gm[r >> 2][r & 3], gm[r >> 2][(r & 3) + 1]});
+                        gm[r >> 2][r & 3] = t.x; gm[r >> 2][(r & 3) + 1] = t.y;
+#else
+                        gm[r >> 2][r & 3] = fmaf(vm, gMi[r], gm[r >> 2][r & 3]);
+                        gm[(r + 1) >> 2][(r + 1) & 3] = fmaf(vm, gMi[r + 1], gm[(r + 1) >> 2][(r + 1) & 3]);
+#endif
+                    }
                 }
             }
             // ---- software pipeline: the node rows of tile t+1 and the indices of tile t+2 are fetched from here
@@ -776,7 +852,16 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                     }
                 }
                 g_z2[r] = gnew * dz2[r];
-                g_b2y[r] += g_z2[r];
+                if (!(PVS_PAIR_H64 && ERK == 0)) g_b2y[r] += g_z2[r];
+            }
+            if constexpr (PVS_PAIR_H64 && ERK == 0) {      // (g_z2 = g_m * SiLU'(z2) again, two at a time: the loop above folds away)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const pvs_f2 z = pvs_f2{gm[r >> 2][r & 3], gm[r >> 2][(r & 3) + 1]} * pvs_f2{dz2[r], dz2[r + 1]};
+                    const pvs_f2 b = pvs_f2{g_b2y[r], g_b2y[r + 1]} + z;
+                    g_z2[r] = z.x; g_z2[r + 1] = z.y;
+                    g_b2y[r] = b.x; g_b2y[r + 1] = b.y;
+                }
             }
             if constexpr (ERES) {
                 if (valid) store_y(io.g_m_prev + (size_t)e * H, gr, mp);
@@ -793,14 +878,29 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             // (gW2 += g_z2 (x) a1: at the top of the next tile / behind the loop)
             float g_z1[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) g_z1[r] = ga1[r >> 2][r & 3] * d1r[r];
+            for (int r = 0; r < 16; r += 2) {
+#if PVS_PAIR_H64
+                const pvs_f2 z = pvs_f2{ga1[r >> 2][r & 3], ga1[r >> 2][(r & 3) + 1]} * pvs_f2{d1r[r], d1r[r + 1]};
+                g_z1[r] = z.x; g_z1[r + 1] = z.y;
+#else
+                g_z1[r] = ga1[r >> 2][r & 3] * d1r[r];
+                g_z1[r + 1] = ga1[(r + 1) >> 2][(r + 1) & 3] * d1r[r + 1];
+#endif
+            }
             float g_rho;
             {
                 float rr[16];
                 load_y(wrhot, gr, rr);
                 float s = 0.f;
+#if PVS_PAIR_H64
+                pvs_f2 s2{0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) s2 = pvs_fma2(pvs_f2{rr[r], rr[r + 1]}, pvs_f2{g_z1[r], g_z1[r + 1]}, s2);
+                s = s2.x + s2.y;
+#else
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s = fmaf(rr[r], g_z1[r], s);
+#endif
                 g_rho = sum_groups(s);
             }
             const float k1 = s_coord * nrm * vm;
