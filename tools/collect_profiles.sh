@@ -31,3 +31,4 @@ python3 tools/pmc_header.py $dst/${tag}_cfg2_pmc_sq.txt cfg2 > /dev/null; python
 cp $src/real_shape_eager.json $dst/${tag}_real_shape_eager.json; cp $src/real_shape_graph.json $dst/${tag}_real_shape_graph.json; cp $src/step_timeline_real4A.txt $dst/${tag}_step_timeline_real4A.txt 2>/dev/null
 # the commit the counters were taken at (bench.py: roofline.limiter_commit; this script runs where .git is)
 for c in cfg2 cfg3; do f=$dst/${tag}_${c}_pmc_sq.txt; [ -f $f ] && ! grep -q '^commit:' $f && sed -i "1i commit: $(git rev-parse --short HEAD)" $f; done
+cp $src/tile_trace.txt $dst/${tag}_tile_trace_h32_backward.txt 2>/dev/null; cp $src/micro_glds_offset.txt $dst/${tag}_micro_glds_offset.txt 2>/dev/null

@@ -49,3 +49,6 @@ find $out/trace_real4A -name '*.csv' -size +1M -delete
 python3 -m pytest tests/test_gpu_lazy_scales.py tests/test_gpu_properties.py -q -m gpu -k "lazy or tile_magnitudes or bias_sums or dynamic_range or binades" > $out/lazy_tests.log 2>&1
 tools/micro/valu_issue_bench.bin sigmoid > $out/micro_sigmoid.txt 2>&1
 
+# the H = 32 backward phase by phase (needs the -DPVS_TILE_TRACE build: tools/variant_obj.sh trace edge_bwd_f16.hip "-DPVS_TILE_TRACE"), LDS-DMA addressing
+[ -f pointvs_amd/libpvs_egnn_trace.so ] && PVS_EGNN_LIB=pointvs_amd/libpvs_egnn_trace.so python3 tools/tile_trace.py 2>&1 | grep -v amdgpu.ids > $out/tile_trace.txt
+[ -x tools/micro/glds_offset_test.bin ] && tools/micro/glds_offset_test.bin > $out/micro_glds_offset.txt 2>&1
