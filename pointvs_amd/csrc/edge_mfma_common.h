@@ -135,7 +135,10 @@ __device__ __forceinline__ float pvs_xor_sum(float v) {
 // (768 threads, 168 registers) was 1.4 % SLOWER with it and its results were wrong and changed from run to run (26 of the
 // 212 GPU tests, all 64-channel cases: profiles/r05_ab_pair_math.txt) - the second time that kernel breaks under a change
 // that is arithmetic-neutral in the source (32-bit lane offsets, PVS_FWD_SADDR, was the first).
-template <int HB> constexpr bool pvs_pair_math = PVS_PAIR_MATH && HB == 1;
+#ifndef PVS_PAIR_MAX_HB
+#define PVS_PAIR_MAX_HB 1
+#endif
+template <int HB> constexpr bool pvs_pair_math = PVS_PAIR_MATH && HB <= PVS_PAIR_MAX_HB;
 
 template <int HB>
 __device__ __forceinline__ float dot_tab(const float* __restrict__ tab, int hh, const float (&v)[HB][16]) {
