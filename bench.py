@@ -605,7 +605,9 @@ def training_bench(args, rank, world, dev):
     params = list(model.parameters())
     use_graph = bool(args.graph) and not distributed and not args.build_graph and not args.host_inputs
     if use_graph:   # same Adam, step counter kept on the device so the step can be captured
-        model.optimiser = torch.optim.Adam(params, lr=2e-3, weight_decay=1e-4, capturable=True)
+        from pointvs_amd.optim import FusedClipAdam
+        cls = torch.optim.Adam if os.environ.get('PVS_BENCH_TORCH_ADAM') else FusedClipAdam
+        model.optimiser = cls(params, lr=2e-3, weight_decay=1e-4, capturable=True)
     # exchange of the late layers' gradients starts from backward hooks, the rest after the backward
     elif os.environ.get('PVS_BENCH_TORCH_ADAM'):   # A/B: torch's multi-tensor Adam + clip_grad_value_
         model.optimiser = torch.optim.Adam(params, lr=2e-3, weight_decay=1e-4)

@@ -354,6 +354,13 @@ typedef struct PvsAdamEntry {
 int pvs_adam_clip_step(const PvsAdamEntry* table, int32_t n_tensors, float lr, float beta1, float beta2,
                        float eps, float weight_decay, float bias_correction1, float bias_correction2,
                        float clip, pvs_stream_t stream);
+/* The same with the step count on the DEVICE: `step` points at one fp32 value, the number of this step (>= 1; the
+ * caller advances it on the stream before the call), from which the kernel forms both bias corrections (in double, from the betas as doubles: `1 - beta ** step` as the host
+ * form's caller evaluates it in Python; the update itself uses the betas rounded to fp32 like the host form). This is what
+ * torch.optim.Adam(capturable=True) does (adam.py `_multi_tensor_adam`, capturable branch: step tensors on the device) so
+ * that a captured training step can be replayed; nothing about the launch depends on host state that changes per step. */
+int pvs_adam_clip_step_dev(const PvsAdamEntry* table, int32_t n_tensors, float lr, double beta1, double beta2,
+                           float eps, float weight_decay, const float* step, float clip, pvs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * unsorted_segment_sum / unsorted_segment_mean (egnn_satorras.py:332-337 / :340-347) as standalone

@@ -443,9 +443,23 @@ int pvs_sum_vec(hipStream_t s, const float* v, int n, float* out) {
 
 // ---- clip + Adam for every parameter tensor in one launch (include/pvs_egnn.h) ----
 namespace {
+// STEP_DEV: the step count is a float on the device (torch's capturable Adam keeps it there, so that a captured step can be
+// replayed): every workgroup forms the two bias corrections from it - in double, as the host form does in Python.
+template <bool STEP_DEV>
 __global__ void __launch_bounds__(256)
 k_adam_clip(const PvsAdamEntry* __restrict__ table, float lr, float beta1, float beta2, float eps, float wd,
-            float bc1, float bc2, float clip) {
+            float bc1, float bc2, float clip, const float* __restrict__ step_dev, double beta1_d, double beta2_d) {
+    if constexpr (STEP_DEV) {
+        __shared__ float bc[2];
+        if (threadIdx.x == 0) {      // (from the betas as the caller holds them - doubles in Python - like `1 - beta ** step` there)
+            const double t = (double)step_dev[0];
+            bc[0] = (float)(1.0 - pow(beta1_d, t));
+            bc[1] = (float)(1.0 - pow(beta2_d, t));
+        }
+        __syncthreads();
+        bc1 = bc[0];
+        bc2 = bc[1];
+    }
     const PvsAdamEntry e = table[blockIdx.y];
     const float step_size = lr / bc1;
     const float bc2_sqrt = sqrtf(bc2);
@@ -475,7 +489,17 @@ extern "C" int pvs_adam_clip_step(const PvsAdamEntry* table, int32_t n, float lr
     PVS_REQUIRE(table && n >= 0, "pvs_adam_clip_step: bad arguments");
     PVS_REQUIRE(bc1 > 0.f && bc2 > 0.f, "pvs_adam_clip_step: bias corrections must be positive (step >= 1)");
     if (n == 0) return 0;
-    k_adam_clip<<<dim3(8, n), 256, 0, (hipStream_t)stream>>>(table, lr, beta1, beta2, eps, wd, bc1, bc2, clip);
+    k_adam_clip<false><<<dim3(8, n), 256, 0, (hipStream_t)stream>>>(table, lr, beta1, beta2, eps, wd, bc1, bc2, clip, nullptr, 0.0, 0.0);
+    PVS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pvs_adam_clip_step_dev(const PvsAdamEntry* table, int32_t n, float lr, double beta1, double beta2,
+                                      float eps, float wd, const float* step, float clip, pvs_stream_t stream) {
+    PVS_REQUIRE(table && step && n >= 0, "pvs_adam_clip_step_dev: bad arguments");
+    if (n == 0) return 0;
+    k_adam_clip<true><<<dim3(8, n), 256, 0, (hipStream_t)stream>>>(table, lr, (float)beta1, (float)beta2, eps, wd, 1.f, 1.f, clip, step,
+                                                                   beta1, beta2);
     PVS_CHECK_LAUNCH();
     return 0;
 }

@@ -11,17 +11,21 @@ from . import _lib
 class FusedClipAdam(torch.optim.Adam):
     """Drop-in `torch.optim.Adam`; `step(clip_value=c)` first clamps every gradient to [-c, c] in
     place. Falls back to torch's own implementation whenever a feature the kernel does not cover is
-    on (amsgrad, maximize, capturable, differentiable, non-CUDA / non-fp32 parameters)."""
+    on (amsgrad, maximize, differentiable, a tensor learning rate, non-CUDA / non-fp32 parameters).
+    `capturable=True` (round 5) keeps the step counters on the device exactly as torch's capturable Adam does (same
+    `state_dict`), advances them with one foreach launch and lets the kernel form the bias corrections from them
+    (`pvs_adam_clip_step_dev`): the whole step is then two launches that a hipGraph can replay."""
 
     def __init__(self, params, **kwargs):
         super().__init__(params, **kwargs)
         # pointer tables travel through a small ring of pinned buffers: a slot is only rewritten once
         # the copy that read it has run (the host may be several steps ahead of the device)
         self._ring, self._slot = [], 0
+        self._capture_pool, self._capture_next, self._captured_tables = None, 0, []
 
     def _fusable(self):
         for group in self.param_groups:
-            if group.get('amsgrad') or group.get('maximize') or group.get('capturable') \
+            if group.get('amsgrad') or group.get('maximize') \
                     or group.get('differentiable') or group.get('decoupled_weight_decay') \
                     or isinstance(group['lr'], torch.Tensor):
                 return False
@@ -30,6 +34,15 @@ class FusedClipAdam(torch.optim.Adam):
                                            or not p.is_contiguous() or not p.grad.is_contiguous()):
                     return False
         return True
+
+    def reserve_capture_tables(self, k):
+        """Pinned pointer tables for `k` more captured steps (pinned memory cannot be allocated while a capture is open,
+        and a captured upload must keep its source for as long as the graph is replayed)."""
+        rows = max(64, sum(len(g['params']) for g in self.param_groups))
+        left = 0 if self._capture_pool is None else self._capture_pool.shape[0] - self._capture_next
+        if left < k:
+            self._capture_pool = torch.empty((k, rows, 5), dtype=torch.int64).pin_memory()   # (tables handed out stay alive
+            self._capture_next = 0                                                            # in _captured_tables)
 
     def zero_grad(self, set_to_none=True):
         """torch's zero_grad walks hooks, profiler ranges and foreach groups (~100 us on the host for 34 parameters);
@@ -56,7 +69,8 @@ class FusedClipAdam(torch.optim.Adam):
         # the step counters (one CPU tensor per parameter: torch's state_dict layout) advance with one foreach call.
         live = [p.grad is not None for group in self.param_groups for p in group['params']]
         fast = getattr(self, '_fast', None)
-        if fast is None or fast['live'] != live or fast['n_groups'] != len(self.param_groups):
+        capt = [bool(g.get('capturable')) for g in self.param_groups]
+        if fast is None or fast['live'] != live or fast['capt'] != capt:
             fast = self._plan(live)
         if not (fast['fusable'] and self._gradients_fusable(fast)):
             self._fast = None
@@ -68,16 +82,31 @@ class FusedClipAdam(torch.optim.Adam):
         for group, works in zip(self.param_groups, fast['groups']):
             beta1, beta2 = group['betas']
             for work in works:            # one launch per distinct step count (one, unless the gradient set changed mid-run)
-                torch._foreach_add_(work['steps'], 1)
+                torch._foreach_add_(work['steps'], 1)        # (CPU tensors: host arithmetic; capturable: one device launch)
                 work['step'] += 1
                 step, items, n, dev = work['step'], work['items'], work['n'], work['dev']
+                capturing = work['on_device'] and torch.cuda.is_current_stream_capturing()
                 if not self._ring or self._ring[0][0].shape[0] < n:
                     cap = max(n, 64)
                     self._ring = [[torch.empty((cap, 5), dtype=torch.int64).pin_memory(),
                                    torch.empty((cap, 5), dtype=torch.int64, device=dev), None] for _ in range(8)]
                 rows = [[p.data_ptr(), p.grad.data_ptr(), ea.data_ptr(), es.data_ptr(), p.numel()] for p, ea, es in items]
                 last = getattr(self, '_last_table', None)
-                if last is not None and last[0] == rows and last[1].device == dev:
+                if work['on_device'] and not capturing and self._capture_pool is None:
+                    self.reserve_capture_tables(8)
+                if capturing:
+                    # a captured upload is replayed from its pinned source: that buffer belongs to the capture and is
+                    # never rewritten (a ring slot would be, by the next eager step)
+                    if self._capture_pool is None or self._capture_next >= self._capture_pool.shape[0]:
+                        raise RuntimeError('FusedClipAdam: no pinned table left for this capture - call '
+                                           'reserve_capture_tables(k) (or run one eager capturable step) before capturing')
+                    table_host = self._capture_pool[self._capture_next]
+                    self._capture_next += 1
+                    table_host[:n] = torch.tensor(rows, dtype=torch.int64)
+                    table_dev = torch.empty((n, 5), dtype=torch.int64, device=dev)
+                    table_dev.copy_(table_host[:n], non_blocking=True)
+                    self._captured_tables.append((table_host, table_dev))
+                elif last is not None and last[0] == rows and last[1].device == dev:
                     # the same addresses as in the previous step (the caching allocator hands the gradients the same
                     # blocks step after step): the table already on the device is this step's table - no upload
                     table_dev = last[1]
@@ -94,11 +123,18 @@ class FusedClipAdam(torch.optim.Adam):
                     # (a ring slot is rewritten only after len(ring) - 1 other uploads, i.e. after this entry stopped
                     # being `_last_table`; several launches per call simply miss each other)
                     self._last_table = (rows, table_dev)
-                _lib.check(lib.pvs_adam_clip_step(
-                    _lib.ptr(table_dev), n, float(group['lr']), float(beta1), float(beta2),
-                    float(group['eps']), float(group['weight_decay']), 1.0 - beta1 ** step, 1.0 - beta2 ** step,
-                    float(clip_value) if clip_value is not None else 0.0,
-                    _lib.stream(dev)), 'pvs_adam_clip_step')
+                if work['on_device']:
+                    _lib.check(lib.pvs_adam_clip_step_dev(
+                        _lib.ptr(table_dev), n, float(group['lr']), float(beta1), float(beta2),
+                        float(group['eps']), float(group['weight_decay']), work['steps'][0].data_ptr(),
+                        float(clip_value) if clip_value is not None else 0.0,
+                        _lib.stream(dev)), 'pvs_adam_clip_step_dev')
+                else:
+                    _lib.check(lib.pvs_adam_clip_step(
+                        _lib.ptr(table_dev), n, float(group['lr']), float(beta1), float(beta2),
+                        float(group['eps']), float(group['weight_decay']), 1.0 - beta1 ** step, 1.0 - beta2 ** step,
+                        float(clip_value) if clip_value is not None else 0.0,
+                        _lib.stream(dev)), 'pvs_adam_clip_step')
                 # the kernel wrote through raw pointers: tell autograd (and anything that caches by
                 # version, e.g. ReceptorScreen) that the parameters changed, as an in-place op would
                 torch.autograd.graph.increment_version(work['params'])
@@ -109,7 +145,8 @@ class FusedClipAdam(torch.optim.Adam):
         (created as torch.optim.Adam._init_group does, non-capturable flavour)."""
         groups, fusable = [], self._fusable()
         if not fusable:       # (torch's own step creates whatever state its flavour - capturable, amsgrad ... - needs)
-            self._fast = {'live': live, 'n_groups': len(self.param_groups), 'groups': [], 'fusable': False}
+            self._fast = {'live': live, 'capt': [bool(g.get('capturable')) for g in self.param_groups], 'groups': [],
+                          'fusable': False}
             return self._fast
         for group in self.param_groups:
             by_step = {}
@@ -117,21 +154,27 @@ class FusedClipAdam(torch.optim.Adam):
                 if p.grad is None:
                     continue
                 state = self.state[p]
+                capturable = bool(group.get('capturable'))
                 if len(state) == 0:
-                    state['step'] = torch.tensor(0.0, dtype=torch.float32)
+                    state['step'] = (torch.zeros((), dtype=torch.float32, device=p.device) if capturable
+                                     else torch.tensor(0.0, dtype=torch.float32))
                     state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                if not isinstance(state['step'], torch.Tensor) or state['step'].is_cuda:
-                    fusable = False        # (a capturable optimiser's state: torch's own step handles it)
+                if (not isinstance(state['step'], torch.Tensor) or state['step'].dtype != torch.float32
+                        or state['step'].is_cuda != capturable):
+                    fusable = False        # (a state the other flavour left behind: torch's own step sorts it out)
                     continue
-                by_step.setdefault(float(state['step']), []).append((p, state))
+                # (capturable: one host read per parameter when the plan is made - never under capture, the plan exists
+                # from the eager steps before it)
+                by_step.setdefault((float(state['step']), capturable), []).append((p, state))
             works = []
-            for count, members in by_step.items():
+            for (count, on_device), members in by_step.items():
                 works.append({'items': [(p, st['exp_avg'], st['exp_avg_sq']) for p, st in members],
                               'steps': [st['step'] for _, st in members], 'step': int(count), 'n': len(members),
-                              'dev': members[0][0].device, 'params': [p for p, _ in members]})
+                              'dev': members[0][0].device, 'params': [p for p, _ in members], 'on_device': on_device})
             groups.append(works)
-        self._fast = {'live': live, 'n_groups': len(self.param_groups), 'groups': groups, 'fusable': fusable}
+        self._fast = {'live': live, 'capt': [bool(g.get('capturable')) for g in self.param_groups], 'groups': groups,
+                      'fusable': fusable}
         return self._fast
 
     def _gradients_fusable(self, fast):

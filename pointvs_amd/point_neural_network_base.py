@@ -41,8 +41,8 @@ class _StepReplayer:
     most `max_graphs` batches are captured, the rest stay eager. Everything - eager steps too - runs on ONE side stream:
     autograd's AccumulateGrad nodes remember the stream of their first backward, and a capture on another stream than
     earlier eager steps faults in hipStreamEndCapture (ROCm 7.2 / torch 2.10; bench.py --graph 1 does the same).
-    The optimiser runs as torch's capturable Adam for the duration (step counters on the device; FusedClipAdam's
-    kernel takes its bias corrections as host scalars, which a replay would freeze) and is restored on close()."""
+    The optimiser runs in its capturable form for the duration (step counters on the device, as torch's capturable Adam
+    keeps them; FusedClipAdam then forms the bias corrections in its kernel: optim.py) and is restored on close()."""
 
     def __init__(self, model, max_graphs=64):
         if not torch.cuda.is_available():
@@ -71,6 +71,8 @@ class _StepReplayer:
                 if st and isinstance(st.get('step'), torch.Tensor) and not st['step'].is_cuda:
                     st['step'] = st['step'].to(device=p.device, dtype=torch.float32)
         model.optimiser._fast = None
+        if hasattr(model.optimiser, 'reserve_capture_tables'):
+            model.optimiser.reserve_capture_tables(max_graphs)
 
     def close(self):
         torch.cuda.current_stream(DEVICE).wait_stream(self.stream)

@@ -678,6 +678,60 @@ def test_fused_clip_adam_matches_torch_adam():
         assert rel_err(sa[k]['exp_avg_sq'].cpu().numpy(), sb[k]['exp_avg_sq'].cpu().numpy()) < 1e-6
 
 
+def test_capturable_fused_clip_adam_matches_the_host_counted_form_eagerly_and_replayed():
+    """FusedClipAdam(capturable=True): step counters on the device as torch's capturable Adam keeps them (the same
+    state_dict), the bias corrections formed in the kernel (pvs_adam_clip_step_dev). Six steps - three eager, then the
+    step captured in a hipGraph and replayed three times on new gradients written into the same tensors - must leave
+    the parameters, moments and counters of the host-counted fused form (bit for bit: the same arithmetic on the same
+    correction factors) and of clip_grad_value_ + torch.optim.Adam(capturable=True)."""
+    from pointvs_amd.optim import FusedClipAdam
+    torch.manual_seed(0)
+    shapes = [(32, 68), (32,), (1, 32), (64, 64)]
+    a = [torch.nn.Parameter(torch.randn(s, device='cuda')) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    c = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa = FusedClipAdam(a, lr=2e-3, weight_decay=1e-4, capturable=True)
+    ob = FusedClipAdam(b, lr=2e-3, weight_decay=1e-4)
+    oc = torch.optim.Adam(c, lr=2e-3, weight_decay=1e-4, capturable=True)
+    grads = [[torch.randn(s, generator=torch.Generator().manual_seed(10 * t + k)).cuda() * 2 for k, s in enumerate(shapes)]
+             for t in range(6)]
+    for p in a + b + c:
+        p.grad = torch.zeros_like(p)
+    stream = torch.cuda.Stream()
+    hip_graph = None
+    with torch.cuda.stream(stream):
+        for t in range(6):
+            for k in range(len(shapes)):
+                for ps in (a, b, c):
+                    ps[k].grad.copy_(grads[t][k])
+            if t < 3:
+                oa.step(clip_value=1.0)
+            elif hip_graph is None:
+                stream.synchronize()
+                hip_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(hip_graph, stream=stream):
+                    oa.step(clip_value=1.0)
+                hip_graph.replay()               # (capturing does not execute)
+            else:
+                hip_graph.replay()
+            ob.step(clip_value=1.0)
+            torch.nn.utils.clip_grad_value_(c, 1.0)
+            oc.step()
+    torch.cuda.synchronize()
+    assert oa._fast['fusable'] and oa._fast['groups'][0][0]['on_device']
+    sa, sb, sc = oa.state_dict()['state'], ob.state_dict()['state'], oc.state_dict()['state']
+    for k, (pa, pb, pc) in enumerate(zip(a, b, c)):
+        assert torch.equal(pa.detach(), pb.detach()), k
+        assert rel_err(pa.detach().cpu().numpy(), pc.detach().cpu().numpy()) < 1e-6
+        assert torch.equal(sa[k]['exp_avg'], sb[k]['exp_avg']) and torch.equal(sa[k]['exp_avg_sq'], sb[k]['exp_avg_sq'])
+        assert sa[k]['step'].is_cuda and sa[k]['step'].dtype == torch.float32 and float(sa[k]['step']) == 6.0
+        assert float(sc[k]['step']) == 6.0 and not sb[k]['step'].is_cuda
+    # the state moves between the flavours: torch's capturable Adam continues from the fused optimiser's checkpoint
+    od = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in a], lr=2e-3, weight_decay=1e-4, capturable=True)
+    od.load_state_dict(oa.state_dict())
+    assert float(od.state_dict()['state'][0]['step']) == 6.0
+
+
 @pytest.mark.parametrize('config', ['cfg2', 'cfg3'])
 def test_kernel_families_agree_at_baseline_batch_size(config):
     """BASELINE configs 2 and 3 at their full per-GPU batch of 32 graphs: MFMA kernels vs generic kernels,
