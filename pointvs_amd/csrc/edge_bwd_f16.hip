@@ -1,21 +1,22 @@
 // Edge backward for H = 32 with every product as a THREE-term fp16 product on the matrix cores ("f16x2",
-// edge_mfma_common.h), one wave per 32-edge tile, two waves per SIMD. Round 3's successor of
-// k_edge_bwd_bf16 (edge_bwd_bf16.hip: six bf16 terms per product, three parts per operand).
+// edge_mfma_common.h), one wave per 32-edge tile, two waves per SIMD (round 3; its bf16x3 predecessor needed six terms per
+// product and three parts per operand).
 //
-// What changes against the bf16x3 kernel, per 32-edge tile:
-//   * an operand is split into two fp16 parts with 2 VALU instructions per value (v_fma_mixlo/hi_f16: the
-//     power-of-two tile scale rides in the same instruction) instead of three bf16 parts with 5.5;
-//   * a chain product (W2 a1, Wc1 m, Wc1^T g_zc, W2^T g_z2) is 6 MFMAs instead of 12;
-//   * two parts per tensor are 4 KB of image per wave instead of 6 KB, which frees the LDS for a THIRD image
-//     slot: the gradient tensors (g_zc, g_z2) go to LDS as row-major [edge][channel] images like the
-//     activations, and BOTH operands of the two weight-gradient products over the edge index come back
-//     through the transposing read (ds_read_b64_tr_b16). The transposition on the matrix core (part x
-//     identity, 6 MFMAs + 24 v_perm per gradient tensor, latency-serialised: DESIGN.md §5) is gone;
-//   * a weight-gradient product is 6 MFMAs (+ 4 for the bias column) instead of 18 (+ 6).
-// 44 MFMAs per tile instead of 96. The price: every operand carries a tile scale (a wave-wide maximum, 8
-// v_max3 + 4 DPP steps per operand) and every accumulator is descaled where it is consumed; the
-// weight-gradient products of a tile go through a temporary accumulator, because their scale changes from
-// tile to tile (16 FMAs each).
+// Per 32-edge tile:
+//   * an operand is split into two fp16 parts by conversions (pvs_f16_split2: scale, v_cvt_pk, two v_fma_mix, v_cvt_pk:
+//     2.5 vector instructions per value since the scale multiply runs on register pairs); the power-of-two tile scale
+//     rides in the split;
+//   * a chain product (W2 a1, Wc1 m, Wc1^T g_zc, W2^T g_z2) is 6 MFMAs;
+//   * activations AND gradients (g_zc, g_z2) go to LDS as row-major [edge][channel] fp16 images (two parts = 4 KB per
+//     tensor and wave), and BOTH operands of the two weight-gradient products over the edge index come back through the
+//     transposing read (ds_read_b64_tr_b16);
+//   * a weight-gradient product is 6 MFMAs (+ 4 for the bias column, a product with a ones column).
+// 44 MFMAs per tile. Scales: one per operand and tile; in the instantiations without edge attention they move LAZILY and
+// the weight gradients accumulate in the MFMA accumulators at the images' scale (below: wgrad_tile_f16_acc); with edge
+// attention every tile takes its own scale from the wave-wide maximum and the products go through a temporary
+// accumulator (wgrad_tile_f16). Elementwise work (SiLU and SiLU', descales, the split's scale) is written on register
+// pairs (common.h pvs_f2). What bounds the kernel, measured phase by phase: DESIGN.md §5 / §8 item 1,
+// tools/tile_trace.py.
 //
 // Reference semantics: autograd of EGNNLayer.edge_model / coord_model / node_model's aggregation,
 // /root/reference/point_vs/models/geometric/egnn_satorras.py:123-206 (SURVEY.md §8a "Backward spec").

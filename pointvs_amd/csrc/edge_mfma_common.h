@@ -488,8 +488,9 @@ __device__ __forceinline__ bf16x8 img_fragment(const unsigned short* __restrict_
 // x*s = hi + lo with hi = fp16(x*s) (round to nearest) and lo = fp16(x*s - hi): 22 significant bits in two
 // parts instead of 24 in three, and  a*b = (hi*hi + hi*lo + lo*hi) / (s_a s_b) + O(2^-22 |a||b|)  with the
 // three terms summed in ONE fp32 accumulator of v_mfma_f32_32x32x16_f16 (same cycles as the bf16 form): half
-// the MFMAs of bf16x3 and 2 VALU instructions per split value instead of 5.5 - v_fma_mixlo/hi_f16 evaluates
-// x*s (and x*s - hi) in fp32 and rounds to fp16 into one half of a register, scaling included.
+// the MFMAs of bf16x3 and 3 VALU instructions per split value instead of 5.5 (pvs_f16_split2: scale, v_cvt_pk_f16_f32
+// for a pair, v_fma_mix_f32 for each residual, v_cvt_pk again; the quarter-rate v_fma_mixlo/hi_f16 form of round 3's
+// first version - 2 instructions per value - measured slower: profiles/r03_micro_valu_issue.txt).
 // fp16 has 5 exponent bits, so every operand is scaled by a power of two s chosen from the maximum of the
 // TILE it belongs to (activations reach 1e3, gradients 1e-9: neither fits fp16 unscaled): s * max in
 // [2^13, 2^14). Then hi never overflows and the representation error of an element is
