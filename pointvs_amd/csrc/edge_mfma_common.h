@@ -132,9 +132,7 @@ __device__ __forceinline__ float pvs_xor_sum(float v) {
 #define PVS_PAIR_MATH 1
 #endif
 // H = 32 only. At 128 channels register pairs cost the softmax forward its second wave per SIMD; the 64-channel forward
-// (768 threads, 168 registers) was 1.4 % SLOWER with it and its results were wrong and changed from run to run (26 of the
-// 212 GPU tests, all 64-channel cases: profiles/r05_ab_pair_math.txt) - the second time that kernel breaks under a change
-// that is arithmetic-neutral in the source (32-bit lane offsets, PVS_FWD_SADDR, was the first).
+// (768 threads, 168 registers) is 1 % slower with them (profiles/r05_ab_pair_math.txt; -DPVS_PAIR_MAX_HB=2 builds it).
 #ifndef PVS_PAIR_MAX_HB
 #define PVS_PAIR_MAX_HB 1
 #endif
@@ -567,11 +565,21 @@ __device__ __forceinline__ void pvs_f16_split2(float x0, float x1, float s, unsi
     } else {
         y0 = x0 * s; y1 = x1 * s;
     }
+    // The two conversions are the COMPILER's (fptrunc <2 x float> selects v_cvt_pk_f16_f32 on gfx950, round to nearest
+    // even like the instruction), not asm statements as until round 5: hipcc's hazard recognizer does not look inside
+    // inline asm, and h / l are MFMA operands - an asm-written register that an MFMA reads with nothing but an s_waitcnt or
+    // s_nop 0 in between is the "VALU write -> MFMA read" hazard unprotected, and the MFMA may take the register's old
+    // content. Every shipped kernel had such places (tools/asm_mfma_hazard_scan.py) and passed because those waits
+    // happened to stall; the 64-channel forward compiled with the pair arithmetic did not (profiles/r05_ab_pair_math.txt,
+    // section 3; the NaN rows of the withdrawn PVS_FWD_SADDR build were the same thing). Only the residuals stay asm
+    // (v_fma_mix_f32 has no pattern the compiler selects here): their consumer is the second conversion, a vector
+    // instruction the compiler does guard behind an asm definition.
+    typedef _Float16 pvs_h2 __attribute__((ext_vector_type(2)));
     float r0, r1;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(y0), "v"(y1));
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(pvs_f2{y0, y1}, pvs_h2));
     asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(y0), "v"(h));
     asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(y1), "v"(h));
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(r0), "v"(r1));
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(pvs_f2{r0, r1}, pvs_h2));
 }
 
 template <bool PAIR = false>

@@ -15,13 +15,13 @@
 //
 // Layout maps validated lane-by-lane in tools/mfma_layout_check.py.
 #include "edge_mfma_common.h"
-// Node gathers and index loads with a scalar base + 32-bit lane offset (pvs_off, edge_mfma_common.h): OFF. Measured
-// 1-2 spilled registers fewer at both widths, cfg3's forward -0.9 %, cfg5 +1.7 % poses/s, cfg2 unchanged - but one
-// register allocation of the H = 64 instantiation (0 spills instead of 4, after an unrelated edit of a shared header)
-// returned NaN rows for the 64-channel goldens, where the same source with the 64-bit lane addresses is green
-// (profiles/r05_ab_h32_backward_saddr_schedule_woven.txt, item 4). Not understood, so not shipped.
+// Node gathers and index loads with a scalar base + 32-bit lane offset (pvs_off, edge_mfma_common.h): 1-2 registers
+// fewer at both widths, the H = 32 forward -2.6 %, cfg5 +1.7 % poses/s. Withdrawn earlier in round 5 because one register
+// allocation of the H = 64 instantiation returned NaN rows; that was the unprotected inline-asm -> MFMA hazard of the
+// operand split (pvs_f16_split2 has the story, tools/asm_mfma_hazard_scan.py finds such places), which any change of
+// schedule could expose - with the conversions back in the compiler's hands the same build is green.
 #ifndef PVS_FWD_SADDR
-#define PVS_FWD_SADDR 0
+#define PVS_FWD_SADDR 1
 #endif
 
 namespace {

@@ -64,3 +64,18 @@ def test_baseline_instantiations_fit_their_register_budget(src):
         assert r['VGPRs Spill'] <= max_spill and r['SGPRs Spill'] <= SGPR_SPILL_OK.get(frag, 0), (frag, r)
         assert max_spill > 0 or r['ScratchSize [bytes/lane]'] == 0, (frag, r)
         assert r['VGPRs'] <= max_v and r['AGPRs'] <= max_a, (frag, r)
+
+
+def test_no_mfma_reads_an_inline_asm_result_without_a_gap():
+    """hipcc's hazard recognizer does not look inside inline asm: a vector instruction in an asm statement whose result an
+    MFMA reads fewer than two instructions later is the VALU-write -> MFMA-read hazard unprotected (round 5: every f16x2
+    kernel had such places after its operand split and passed while the s_waitcnt in between happened to stall; the
+    64-channel forward under a changed schedule did not). tools/asm_mfma_hazard_scan.py compiles the edge kernels as the
+    Makefile does and must find none."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('asm_mfma_hazard_scan', CSRC.parent.parent / 'tools' / 'asm_mfma_hazard_scan.py')
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+    for src in ('edge_mfma_fwd.hip', 'edge_bwd_f16.hip', 'edge_bwd_wide.hip'):      # the kernels that split operands in asm
+        hits = scan.scan(src)
+        assert not hits, (src, hits[:4])
