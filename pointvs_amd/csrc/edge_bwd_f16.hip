@@ -293,6 +293,9 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
     float g_ba = 0.f, g_gate = 0.f;
     // (LAZY) scale exponents of the four operand images and what the accumulators carry
     constexpr bool LAZY = PVS_LAZY_WSCALE && !EATT;
+    // elementwise work on register pairs (common.h pvs_f2): everywhere but gated residual + attention, the instantiation
+    // with the most live values per tile (30 spilled registers instead of 26 with it, +7 % per launch)
+    constexpr bool PAIR = PVS_PAIR_MATH && !(ERK == 3 && EATT);
     // (the four exponents share ONE scalar register, a byte each, 0 = not set yet: the kernel has no scalar register to
     // spare, and a spilled one costs a v_readlane / v_writelane pair per use)
     unsigned lazy_pack = 0u;
@@ -392,30 +395,30 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     float dd[4];
-#if PVS_PAIR_MATH
+                    if constexpr (PAIR) {
 #pragma unroll
-                    for (int q = 0; q < 4; q += 2) {
-                        pvs_f2 av, dv;
-                        pvs_silu_grad2(pvs_f2{a1[0][4 * gq + q], a1[0][4 * gq + q + 1]}, av, dv);
-                        a1[0][4 * gq + q] = av.x; a1[0][4 * gq + q + 1] = av.y;
-                        dd[q] = dv.x; dd[q + 1] = dv.y;
-                    }
-#else
+                        for (int q = 0; q < 4; q += 2) {
+                            pvs_f2 av, dv;
+                            pvs_silu_grad2(pvs_f2{a1[0][4 * gq + q], a1[0][4 * gq + q + 1]}, av, dv);
+                            a1[0][4 * gq + q] = av.x; a1[0][4 * gq + q + 1] = av.y;
+                            dd[q] = dv.x; dd[q + 1] = dv.y;
+                        }
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float z = a1[0][4 * gq + q];
-                        const float sg = pvs_sigmoid(z);
-                        const float av = z * sg;
-                        dd[q] = fmaf(av, 1.0f - sg, sg);       // SiLU'(z) = s + z s (1 - s)
-                        a1[0][4 * gq + q] = av;
+                        for (int q = 0; q < 4; ++q) {
+                            const float z = a1[0][4 * gq + q];
+                            const float sg = pvs_sigmoid(z);
+                            const float av = z * sg;
+                            dd[q] = fmaf(av, 1.0f - sg, sg);       // SiLU'(z) = s + z s (1 - s)
+                            a1[0][4 * gq + q] = av;
+                        }
                     }
-#endif
                     *reinterpret_cast<float4*>(d1b + (gq * 64 + lane) * 4) = make_float4(dd[0], dd[1], dd[2], dd[3]);
                 }
                 PVS_TP(18);
                 const float sa1 = LAZY ? lazy_scale(a1[0], kXa1, &inv_sa1) : pvs_tile_scale(a1[0], &inv_sa1);
                 PVS_TP(19);
-                split_f16x2<PVS_PAIR_MATH>(a1[0], sa1, pb);
+                split_f16x2<PAIR>(a1[0], sa1, pb);
                 PVS_TP(20);
                 write_image_f16(A1I, j, hh, pb);
                 PVS_TP(2);
@@ -426,34 +429,34 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 float bias[1][16];
                 load_tab<1>(b2t, hh, bias);
                 const float k2 = inv_sa1 * inv_sw2;
-#if PVS_PAIR_MATH
+                if constexpr (PAIR) {
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const pvs_f2 z = pvs_fma2(pvs_f2{acc2[r], acc2[r + 1]}, pvs_f2{k2, k2}, pvs_f2{bias[0][r], bias[0][r + 1]});
-                    z2[r] = z.x; z2[r + 1] = z.y;
+                    for (int r = 0; r < 16; r += 2) {
+                        const pvs_f2 z = pvs_fma2(pvs_f2{acc2[r], acc2[r + 1]}, pvs_f2{k2, k2}, pvs_f2{bias[0][r], bias[0][r + 1]});
+                        z2[r] = z.x; z2[r + 1] = z.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z2[r] = fmaf(acc2[r], k2, bias[0][r]);
                 }
-#else
-#pragma unroll
-                for (int r = 0; r < 16; ++r) z2[r] = fmaf(acc2[r], k2, bias[0][r]);
-#endif
                 PVS_TP(3);
             }
             float dz2[16], m[1][16];          // SiLU'(z2) and the message
             float m_new[ERK >= 2 ? 16 : 1], mp[1][16];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-#if PVS_PAIR_MATH
-                pvs_f2 mv, dv;
-                pvs_silu_grad2(pvs_f2{z2[r], z2[r + 1]}, mv, dv);
-                m[0][r] = mv.x; m[0][r + 1] = mv.y;
-                dz2[r] = dv.x; dz2[r + 1] = dv.y;
-#else
-                for (int t = r; t < r + 2; ++t) {
-                    const float sg = pvs_sigmoid(z2[t]);
-                    m[0][t] = z2[t] * sg;
-                    dz2[t] = fmaf(m[0][t], 1.0f - sg, sg);
+                if constexpr (PAIR) {
+                    pvs_f2 mv, dv;
+                    pvs_silu_grad2(pvs_f2{z2[r], z2[r + 1]}, mv, dv);
+                    m[0][r] = mv.x; m[0][r + 1] = mv.y;
+                    dz2[r] = dv.x; dz2[r + 1] = dv.y;
+                } else {
+                    for (int t = r; t < r + 2; ++t) {
+                        const float sg = pvs_sigmoid(z2[t]);
+                        m[0][t] = z2[t] * sg;
+                        dz2[t] = fmaf(m[0][t], 1.0f - sg, sg);
+                    }
                 }
-#endif
                 if constexpr (ERK >= 2) { m_new[r] = m[0][r]; m_new[r + 1] = m[0][r + 1]; }
             }
             if constexpr (ERES) {
@@ -533,7 +536,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 gT0 = gT[0]; gT1 = gT[1]; gT2 = gT[2];
                 const float sm = LAZY ? lazy_scale(m[0], kXm, &inv_sm) : pvs_tile_scale(m[0], &inv_sm);
                 PVS_TP(16);
-                split_f16x2<PVS_PAIR_MATH>(m[0], sm, pb);
+                split_f16x2<PAIR>(m[0], sm, pb);
                 PVS_TP(17);
                 write_image_f16(MI, j, hh, pb);
                 PVS_TP(5);
@@ -549,20 +552,20 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 float s = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-#if PVS_PAIR_MATH
-                    const pvs_f2 zc = pvs_fma2(pvs_f2{accc[r], accc[r + 1]}, pvs_f2{kc, kc}, pvs_f2{bias2[0][r], bias2[0][r + 1]});
-                    pvs_f2 qv, dv;
-                    pvs_silu_grad2(zc, qv, dv);
-                    q[r] = qv.x; q[r + 1] = qv.y;
-                    dq[r] = dv.x; dq[r + 1] = dv.y;
-#else
-                    for (int t = r; t < r + 2; ++t) {
-                        const float zc = fmaf(accc[t], kc, bias2[0][t]);   // zc = Wc1 m + bc1
-                        const float sg = pvs_sigmoid(zc);
-                        q[t] = zc * sg;
-                        dq[t] = fmaf(q[t], 1.0f - sg, sg);
+                    if constexpr (PAIR) {
+                        const pvs_f2 zc = pvs_fma2(pvs_f2{accc[r], accc[r + 1]}, pvs_f2{kc, kc}, pvs_f2{bias2[0][r], bias2[0][r + 1]});
+                        pvs_f2 qv, dv;
+                        pvs_silu_grad2(zc, qv, dv);
+                        q[r] = qv.x; q[r + 1] = qv.y;
+                        dq[r] = dv.x; dq[r + 1] = dv.y;
+                    } else {
+                        for (int t = r; t < r + 2; ++t) {
+                            const float zc = fmaf(accc[t], kc, bias2[0][t]);   // zc = Wc1 m + bc1
+                            const float sg = pvs_sigmoid(zc);
+                            q[t] = zc * sg;
+                            dq[t] = fmaf(q[t], 1.0f - sg, sg);
+                        }
                     }
-#endif
                     // (one running sum: a pair of partial sums, or a wave-uniform fast path for full tiles behind the
                     // chain, each cost this instantiation 3-5 spilled registers)
                     s = fmaf(wc2x[0][r], q[r], s);
@@ -583,7 +586,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                 PVS_TP(6);
                 float inv_sg;
                 const float sg_ = LAZY ? lazy_scale(g_zc, kXg, &inv_sg) : pvs_tile_scale(g_zc, &inv_sg);
-                split_f16x2<PVS_PAIR_MATH>(g_zc, sg_, pb);
+                split_f16x2<PAIR>(g_zc, sg_, pb);
                 write_image_f16(GI, j, hh, pb);
                 PVS_TP(7);
                 f32x16 accg;
@@ -649,7 +652,7 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
             PVS_TP(10);
             float inv_sg2;
             const float sg2 = LAZY ? lazy_scale(g_z2, kXg2, &inv_sg2) : pvs_tile_scale(g_z2, &inv_sg2);
-            split_f16x2<PVS_PAIR_MATH>(g_z2, sg2, pb);
+            split_f16x2<PAIR>(g_z2, sg2, pb);
             pvs_wave_lds_sync();                                      // the g_zc image has been read
             write_image_f16(GI, j, hh, pb);
             f32x16 ga1;
