@@ -678,6 +678,7 @@ def test_fused_clip_adam_matches_torch_adam():
         assert rel_err(sa[k]['exp_avg_sq'].cpu().numpy(), sb[k]['exp_avg_sq'].cpu().numpy()) < 1e-6
 
 
+@needs_caching_allocator
 def test_capturable_fused_clip_adam_matches_the_host_counted_form_eagerly_and_replayed():
     """FusedClipAdam(capturable=True): step counters on the device as torch's capturable Adam keeps them (the same
     state_dict), the bias corrections formed in the kernel (pvs_adam_clip_step_dev). Six steps - three eager, then the
