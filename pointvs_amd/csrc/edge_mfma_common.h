@@ -592,7 +592,8 @@ __device__ __forceinline__ void split_f16x2(const float (&v)[16], float s, F16Pa
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float x0 = v[8 * ks + 2 * q], x1 = v[8 * ks + 2 * q + 1];
-#ifdef PVS_SPLIT_MIXLO
+#ifdef PVS_SPLIT_MIXLO      // (A/B only: round 3's first form. Its parts are written by asm statements, i.e. NOT guarded against the
+            // VALU-write -> MFMA-read hazard, see pvs_f16_split2: never ship a build with this defined)
             h[q] = pvs_f16_hi2(x0, x1, s);
             l[q] = pvs_f16_lo2(x0, x1, s, h[q]);
 #else
