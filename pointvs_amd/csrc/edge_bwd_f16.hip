@@ -97,8 +97,12 @@ __device__ __forceinline__ void write_part_f16(unsigned short* __restrict__ part
     for (int s = 0; s < 2; ++s) {
         const uint4 u = __builtin_bit_cast(uint4, p[s]);
         // registers 8s..8s+3 hold channels 16s + 4hh + (0..3), registers 8s+4..8s+7 channels 16s + 8 + 4hh + (0..3)
+#if PVS_IMG_PAIRED      // (the two chunks are neighbours in the image: img_off<1>)
+        *reinterpret_cast<uint4*>(part + img_off<1>(j, 16 * s + 4 * hh)) = u;
+#else
         *reinterpret_cast<uint2*>(part + img_off<1>(j, 16 * s + 4 * hh)) = make_uint2(u.x, u.y);
         *reinterpret_cast<uint2*>(part + img_off<1>(j, 16 * s + 8 + 4 * hh)) = make_uint2(u.z, u.w);
+#endif
     }
 }
 

@@ -444,10 +444,27 @@ typedef short pvs_v4s __attribute__((ext_vector_type(4)));
 // and their swizzle. swz(r) = bits (r2, r3, r1 ^ r4) of the row is a bijection of (r1, r2, r3) for every r4 (the writes:
 // 16 rows of one group) AND of (r2, r3, r4) for every r1 (the row reads: 32 rows, 64 banks); the transposed reads take
 // four consecutive rows whole and do not care. All three conflict-free.
+#ifndef PVS_IMG_PAIRED
+#define PVS_IMG_PAIRED 1
+#endif
 template <int HB>
 __device__ __forceinline__ int img_off(int r, int c) {
     constexpr int H = 32 * HB, NCH = H / 4, RPC = 128 / H;
-    if constexpr (HB == 1) return r * H + 4 * ((c >> 2) ^ (((r >> 2) & 3) | ((((r >> 1) ^ (r >> 4)) & 1) << 2))) + (c & 3);
+    if constexpr (HB == 1) {
+#if PVS_IMG_PAIRED
+        // The two 8-byte chunks one lane's fragment is made of (channels 16 s + 4 hh + 0..3 and 16 s + 8 + 4 hh + 0..3: chunk
+        // numbers q and q + 2) sit SIDE BY SIDE: a row fragment is one ds_read_b128 and a part write one ds_write_b128
+        // instead of two 8-byte accesses each (and hipcc no longer pairs a row read with the other part image's, which cost
+        // six v_mov per k-step to sort out). The 16-byte pairs P = 2 s + hh of a row are permuted by the two row bits
+        // (r2, r1 ^ r3): conflict-free for the ds_write_b128 (8-lane groups, 32 banks), the ds_read_b128 (its own lane
+        // groups, 64 banks) and the transposing reads alike (tools/lds_conflicts.py; 144 of the 992 linear 2-bit swizzles are).
+        const int q = c >> 2, pair = ((q >> 2) << 1) | (q & 1), t = (q >> 1) & 1;
+        const int f = ((r >> 2) & 1) | ((((r >> 1) ^ (r >> 3)) & 1) << 1);
+        return r * H + 8 * (pair ^ f) + 4 * t + (c & 3);
+#else
+        return r * H + 4 * ((c >> 2) ^ (((r >> 2) & 3) | ((((r >> 1) ^ (r >> 4)) & 1) << 2))) + (c & 3);
+#endif
+    }
     return r * H + 4 * ((c >> 2) ^ ((r / RPC) & (NCH - 1))) + (c & 3);
 }
 
@@ -460,6 +477,7 @@ __device__ __forceinline__ uint4 img_fragment_bits(const unsigned short* __restr
     uint2 a, b;
     if constexpr (!TRANSPOSE) {
         const int r = 32 * bo + (lane & 31), c0 = 32 * bi + 16 * s + 4 * hh;
+        if constexpr (HB == 1 && PVS_IMG_PAIRED) return *reinterpret_cast<const uint4*>(part + img_off<HB>(r, c0));
         a = *reinterpret_cast<const uint2*>(part + img_off<HB>(r, c0));
         b = *reinterpret_cast<const uint2*>(part + img_off<HB>(r, c0 + 8));
     } else {

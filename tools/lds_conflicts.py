@@ -59,6 +59,13 @@ def img_off_r05(r, c, H=32):      # H = 32: swz(r) = bits (r2, r3, r1 ^ r4) of t
     return r * H + 4 * ((c >> 2) ^ (((r >> 2) & 3) | ((((r >> 1) ^ (r >> 4)) & 1) << 2))) + (c & 3)
 
 
+def img_off_paired(r, c, H=32):     # late round 5: 16-byte pairs of chunks (q, q + 2), permuted by row bits (r2, r1 ^ r3)
+    q = c >> 2
+    pair, t = ((q >> 2) << 1) | (q & 1), (q >> 1) & 1
+    f = ((r >> 2) & 1) | ((((r >> 1) ^ (r >> 3)) & 1) << 1)
+    return r * H + 8 * (pair ^ f) + 4 * t + (c & 3)
+
+
 img_off = img_off_r04
 
 
@@ -68,7 +75,7 @@ def report(name, kind, addr, per_tile):
     return c * per_tile, (c - ideal) * per_tile
 
 
-def h32_backward(ts=36, swz_t1=False):
+def h32_backward(ts=36, swz_t1=False, paired=False):
     tot = conf = 0
     def add(r):
         nonlocal tot, conf
@@ -78,12 +85,18 @@ def h32_backward(ts=36, swz_t1=False):
     # d1b: lane-private float4 at (gq*64 + lane)*4 floats
     add(report('SiLU\'(z1) park, write', 'w128', lambda l: (0 * 64 + l) * 16, 4))
     add(report('SiLU\'(z1) park, read', 'r128', lambda l: (0 * 64 + l) * 16, 4))
-    # image writes: part + img_off(j, 16s + 4hh) and (j, 16s + 8 + 4hh), 8 bytes each; s = 0
+    # image writes: part + img_off(j, 16s + 4hh) and (j, 16s + 8 + 4hh), 8 bytes each (paired layout: one 16-byte write)
     for s in (0, 1):
+        if paired:
+            add(report(f'image write, k-step {s}', 'w128', lambda l: 2 * img_off(j(l), 16 * s + 4 * hh(l)), 4 * 2 // 2))
+            continue
         add(report(f'image write, k-step {s}, first half', 'w64', lambda l: 2 * img_off(j(l), 16 * s + 4 * hh(l)), 4 * 2 // 2))
         add(report(f'image write, k-step {s}, second half', 'w64', lambda l: 2 * img_off(j(l), 16 * s + 8 + 4 * hh(l)), 4 * 2 // 2))
     # weight row reads (W v): row j, columns 16s + 4hh (+8)
     for s in (0, 1):
+        if paired:
+            add(report(f'weight fragment rows, k-step {s}', 'r128', lambda l: 2 * img_off(j(l), 16 * s + 4 * hh(l)), 2 * 2 // 2))
+            continue
         add(report(f'weight fragment rows, k-step {s}', 'r64', lambda l: 2 * img_off(j(l), 16 * s + 4 * hh(l)), 2 * 2 * 2 // 2))
     # transposed reads (W^T v and both weight-gradient operands)
     def tr_addr(s, second):
@@ -122,3 +135,6 @@ if __name__ == '__main__':
     print('== round 5: image swizzle bits (r2, r3, r1 ^ r4), g_z1 tile unpadded with the quads of row r rotated by r & 7 ==')
     img_off = img_off_r05
     h32_backward(32, swz_t1=True)
+    print('== late round 5: the two chunks of a fragment side by side (one 16-byte access), pairs permuted by (r2, r1 ^ r3) ==')
+    img_off = img_off_paired
+    h32_backward(32, swz_t1=True, paired=True)
