@@ -81,3 +81,28 @@ def test_no_mfma_reads_an_inline_asm_result_without_a_gap():
     for src in ('edge_mfma_fwd.hip', 'edge_bwd_f16.hip', 'edge_bwd_wide.hip'):      # the kernels that split operands in asm
         hits = scan.scan(src)
         assert not hits, (src, hits[:4])
+
+
+def test_shipped_lds_layouts_of_the_h32_backward_are_conflict_free_in_the_lane_group_model(capsys):
+    """tools/lds_conflicts.py restates the H = 32 backward's LDS address functions (img_off<1>, the g_z1 tile's rotated quads)
+    and counts cycles under the per-instruction lane-group rules of MI355X_MICROARCH.md: the shipped layout must come out at
+    zero conflict cycles (the round-4 layout, kept in the tool for comparison, has 80 of 472). The address function is
+    compared with the one in the header on a few points, so that the model cannot drift from the code unnoticed."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('lds_conflicts', CSRC.parent.parent / 'tools' / 'lds_conflicts.py')
+    lds = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lds)
+    lds.img_off = lds.img_off_paired
+    tot, conf = lds.h32_backward(32, swz_t1=True, paired=True)
+    capsys.readouterr()
+    assert conf == 0 and tot > 0
+    header = (CSRC / 'edge_mfma_common.h').read_text()
+    assert 'const int q = c >> 2, pair = ((q >> 2) << 1) | (q & 1), t = (q >> 1) & 1;' in header
+    assert 'const int f = ((r >> 2) & 1) | ((((r >> 1) ^ (r >> 3)) & 1) << 1);' in header
+    assert 'return r * H + 8 * (pair ^ f) + 4 * t + (c & 3);' in header
+    # the model's function, written out independently of the tool
+    for r, c in ((0, 0), (5, 9), (13, 30), (31, 31), (18, 12)):
+        q = c >> 2
+        pair, t = ((q >> 2) << 1) | (q & 1), (q >> 1) & 1
+        f = ((r >> 2) & 1) | ((((r >> 1) ^ (r >> 3)) & 1) << 1)
+        assert lds.img_off_paired(r, c) == r * 32 + 8 * (pair ^ f) + 4 * t + (c & 3)

@@ -127,6 +127,7 @@ def h32_backward(ts=36, swz_t1=False, paired=False):
     for k in range(4):
         add(report(f'per-edge float4 (tx) read, rows {8 * k}..', 'r128', lambda l: base_tx + 16 * (k * 8 + l // 8), 1))
     print(f'total {tot} LDS cycles per tile, {conf} of them conflicts ({100.0 * conf / tot:.0f} %)\n')
+    return tot, conf
 
 
 if __name__ == '__main__':
