@@ -22,6 +22,7 @@ class FusedClipAdam(torch.optim.Adam):
         # the copy that read it has run (the host may be several steps ahead of the device)
         self._ring, self._slot = [], 0
         self._capture_pool, self._capture_next, self._captured_tables = None, 0, []
+        self._recent = {}              # (device, the table's rows) -> ring slot that holds that table on the device
 
     def _fusable(self):
         for group in self.param_groups:
@@ -90,8 +91,8 @@ class FusedClipAdam(torch.optim.Adam):
                     cap = max(n, 64)
                     self._ring = [[torch.empty((cap, 5), dtype=torch.int64).pin_memory(),
                                    torch.empty((cap, 5), dtype=torch.int64, device=dev), None] for _ in range(8)]
+                    self._recent = {}
                 rows = [[p.data_ptr(), p.grad.data_ptr(), ea.data_ptr(), es.data_ptr(), p.numel()] for p, ea, es in items]
-                last = getattr(self, '_last_table', None)
                 if work['on_device'] and not capturing and self._capture_pool is None:
                     self.reserve_capture_tables(8)
                 if capturing:
@@ -106,23 +107,24 @@ class FusedClipAdam(torch.optim.Adam):
                     table_dev = torch.empty((n, 5), dtype=torch.int64, device=dev)
                     table_dev.copy_(table_host[:n], non_blocking=True)
                     self._captured_tables.append((table_host, table_dev))
-                elif last is not None and last[0] == rows and last[1].device == dev:
-                    # the same addresses as in the previous step (the caching allocator hands the gradients the same
-                    # blocks step after step): the table already on the device is this step's table - no upload
-                    table_dev = last[1]
+                elif (hit := self._recent.get(key := (dev, tuple(map(tuple, rows))))) is not None:
+                    # addresses seen before (the caching allocator hands the gradients the same few sets of blocks,
+                    # alternating from step to step): that table is still on the device - no upload
+                    table_dev = self._ring[hit][1]
                 else:
-                    slot = self._ring[self._slot]
+                    idx = self._slot
+                    slot = self._ring[idx]
                     self._slot = (self._slot + 1) % len(self._ring)
                     if slot[2] is not None:
                         slot[2].synchronize()
+                    # (the slot's previous table is forgotten before it is overwritten)
+                    self._recent = {k: v for k, v in self._recent.items() if v != idx}
                     table_host, table_dev = slot[0], slot[1]
                     table_host[:n] = torch.tensor(rows, dtype=torch.int64)
                     table_dev[:n].copy_(table_host[:n], non_blocking=True)
                     slot[2] = torch.cuda.Event()
                     slot[2].record(torch.cuda.current_stream(dev))
-                    # (a ring slot is rewritten only after len(ring) - 1 other uploads, i.e. after this entry stopped
-                    # being `_last_table`; several launches per call simply miss each other)
-                    self._last_table = (rows, table_dev)
+                    self._recent[key] = idx
                 if work['on_device']:
                     _lib.check(lib.pvs_adam_clip_step_dev(
                         _lib.ptr(table_dev), n, float(group['lr']), float(beta1), float(beta2),
