@@ -199,24 +199,58 @@ def visible_gpu_count(topology='/sys/class/kfd/kfd/topology/nodes'):
     return count
 
 
-def self_launch(args):
+RCCL_ENV_KEYS = ('NCCL_PROTO', 'NCCL_ALGO', 'NCCL_MIN_NCHANNELS', 'NCCL_MAX_NCHANNELS', 'NCCL_P2P_LEVEL', 'NCCL_DEBUG',
+                 'RCCL_MSCCL_ENABLE', 'RCCL_MSCCLPP_ENABLE', 'RCCL_MSCCL_FORCE_ENABLE', 'HSA_ENABLE_IPC_MODE_LEGACY')
+
+
+def apply_rccl_choice(args, env):
+    """--rccl-proto / --rccl-algo -> NCCL_PROTO / NCCL_ALGO in `env`, BEFORE any process group exists (RCCL reads them
+    when the communicator is created). The gradient exchange is one 92 KB (cfg2 / cfg4) or 1.42 MB (cfg3) fp32
+    all-reduce per step: latency-bound, the regime the LL / LL128 protocols and the tree algorithm exist for, while RCCL's
+    own tuning picks by message size and topology. Nothing is forced by default (the library's choice is the baseline
+    of the A/B); the line records what it ran under (`config.rccl_env`), so that one 8-GPU lease can compare
+    `--rccl-proto LL`, `LL128` and `Simple` and read the difference off `rank_ms_per_step`."""
+    if getattr(args, 'rccl_proto', None):
+        env['NCCL_PROTO'] = args.rccl_proto
+    if getattr(args, 'rccl_algo', None):
+        env['NCCL_ALGO'] = args.rccl_algo
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # (the host driver only supports dmabuf IPC)
+    return env
+
+
+def rccl_env_record(env=None):
+    env = os.environ if env is None else env
+    return {k: env[k] for k in RCCL_ENV_KEYS if k in env}
+
+
+def launch_command(args, port, argv=None):
+    """The 8-rank (N-rank) command line of `python bench.py --gpus N`: one process per GPU under torch.distributed.run
+    on the loopback, every rank re-running this script with the same arguments (each binds LOCAL_RANK -> its device in
+    main())."""
+    argv = sys.argv[1:] if argv is None else list(argv)
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+            '--master-addr', '127.0.0.1', '--master-port', str(port), str(Path(__file__).resolve())] + argv
+
+
+def self_launch(args, run=None, n_visible=None):
     """`python bench.py --gpus N` (N > 1) without a launcher: start N fresh ranks of this script under
     torch.distributed.run and exit with their status. Runs BEFORE torch is imported: the parent neither
     maps nor initialises HIP (a process that has initialised it must never be replaced or forked into
-    ranks), and it counts the GPUs from the KFD topology in sysfs."""
+    ranks), and it counts the GPUs from the KFD topology in sysfs. Refuses when fewer GPUs are visible than ranks
+    asked for (unless PVS_BENCH_BACKEND names the dry-run backend). `run` / `n_visible`: injected by the CPU test."""
     import socket
     import subprocess
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
-    env = dict(os.environ)
-    n_visible = visible_gpu_count()
+    env = apply_rccl_choice(args, dict(os.environ))
+    if n_visible is None:
+        n_visible = visible_gpu_count()
     if n_visible is not None and n_visible < args.gpus and 'PVS_BENCH_BACKEND' not in env:
         raise SystemExit(f'--gpus {args.gpus} but only {n_visible} GPU(s) visible; set '
                          f'PVS_BENCH_BACKEND=gloo for a dry run of the multi-rank path with ranks sharing devices')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
-           '--master-addr', '127.0.0.1', '--master-port', str(port), str(Path(__file__).resolve())] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    cmd = launch_command(args, port)
+    return (run or subprocess.run)(cmd, env=env).returncode
 
 
 def cpu_baseline(cfg, seconds_budget=12.0):
@@ -470,6 +504,11 @@ def main():
                     help='with --gpus 1: create a process group of ONE rank and run every collective of the '
                          'multi-rank path anyway (hooks, bucketed all-reduce, barriers, max-over-ranks): an '
                          'RCCL smoke on a one-GPU box; not a measured configuration')
+    ap.add_argument('--rccl-proto', choices=['LL', 'LL128', 'Simple'], default=None,
+                    help='multi-rank runs: NCCL_PROTO for the gradient all-reduce (92 KB at cfg2 / cfg4, 1.42 MB at cfg3: '
+                         'latency-bound), set before the process group is created; default: RCCL\'s own choice. The line '
+                         'records the RCCL environment it ran under (config.rccl_env)')
+    ap.add_argument('--rccl-algo', choices=['Ring', 'Tree'], default=None, help='NCCL_ALGO, likewise')
     ap.add_argument('--graph', type=int, default=None,
                     help='1: capture the whole step in a hipGraph and time replays (default: 1 for cfg5, the '
                          'configuration BASELINE names; 0 for the training configurations)')
@@ -488,6 +527,7 @@ def main():
 
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(self_launch(args))
+    apply_rccl_choice(args, os.environ)        # (a rank started by another launcher: still before init_process_group)
     _import_torch()
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -774,6 +814,7 @@ def training_bench(args, rank, world, dev):
                        'dist_backend': dist.get_backend() if distributed else None,
                        'rccl_version': ('.'.join(str(v) for v in torch.cuda.nccl.version())
                                         if distributed and dist.get_backend() == 'nccl' else None),
+                       'rccl_env': rccl_env_record() if distributed else None,
                        'rank_ms_per_step': {'min': round(min(rank_ms), 3), 'max': round(max(rank_ms), 3),
                                             'all': [round(v, 3) for v in rank_ms]},
                        'scaling_note': scaling_note(args, world, strong),

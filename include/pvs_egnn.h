@@ -367,7 +367,10 @@ int pvs_adam_clip_step_dev(const PvsAdamEntry* table, int32_t n_tensors, float l
  * operators (inside the layers these sums are fused into the edge kernels).
  *   data [E,C] fp32, ids [E] int64 in [0,N) -> out [N,C]; mean != 0 divides by max(count, 1).
  *   ptr_out [N+1] int32 (caller-owned) receives the segment offsets, needed by the backward
- *   g_data[e,:] = g_out[ids[e],:] (/ max(count,1)). status: device int32, bit0 = id out of range.
+ *   g_data[e,:] = g_out[ids[e],:] (/ max(count,1)). status: device int32, bit0 = id out of range
+ *   (the reference's scatter_add_ raises there; the kernels stay in bounds - such a row is summed into
+ *   segment 0 by the forward and reads segment 0's gradient in the backward - and the HOST must read the
+ *   status word and raise: pointvs_amd/functional.py does, at the latest in the backward).
  */
 size_t pvs_segment_workspace_bytes(int32_t n_rows, int32_t n_segments);
 int pvs_segment_reduce_fwd(const float* data, const int64_t* ids, int32_t n_rows, int32_t width,
@@ -375,7 +378,7 @@ int pvs_segment_reduce_fwd(const float* data, const int64_t* ids, int32_t n_rows
                            int32_t* status, void* workspace, size_t workspace_bytes,
                            pvs_stream_t stream);
 int pvs_segment_reduce_bwd(const float* g_out, const int64_t* ids, const int32_t* ptr, int32_t n_rows,
-                           int32_t width, int32_t mean, float* g_data, pvs_stream_t stream);
+                           int32_t width, int32_t n_segments, int32_t mean, float* g_data, pvs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement hook (no reference counterpart): when enabled, the library brackets its dominant

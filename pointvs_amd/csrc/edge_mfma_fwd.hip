@@ -32,7 +32,9 @@ namespace {
 // MODE (H = 128, where two split weight matrices do not fit in LDS beside the waves' tiles: the layer's edge forward runs
 // as two launches): 0 everything; 1 everything but the coordinate branch, with only W2 staged - the messages go to
 // io.m_out; 2 the coordinate branch alone, with only Wc1 staged - it reads the messages back from io.m_out.
-template <int HB, int NT = kThreads, bool SOFT = false, bool F16X2 = false, int MODE = 0>
+// SA32: node rows and index arrays addressed as a scalar base + a 32-bit lane offset (pvs_off: -2.6 % at H = 32); the
+// launcher takes the 64-bit instantiation when a table outgrows 32-bit byte offsets (N * 8H >= 2^32 or E >= 2^30)
+template <int HB, int NT = kThreads, bool SOFT = false, bool F16X2 = false, int MODE = 0, bool SA32 = PVS_FWD_SADDR>
 __global__ void __launch_bounds__(NT, (F16X2 && HB == 1) ? 4 : (F16X2 && NT == 768) ? 3 : 1)
 k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdIO io, int n_chunks,
                 int e_lo, int e_hi) {
@@ -150,12 +152,12 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
         };
 
         // tile t+1's indices are loaded at the top of tile t (its node rows at its own start)
-        TileIdx I = PVS_FWD_SADDR ? load_tile_idx32(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_begin, e_begin, e_end, j)
+        TileIdx I = SA32 ? load_tile_idx32(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_begin, e_begin, e_end, j)
                                   : load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_begin, e_begin, e_end, j);
         TileGather<HB> G;
         for (int e0 = e_begin; e0 < e_end; e0 += kTile) {
             const int e_next = (e0 + kTile < e_end) ? e0 + kTile : e0;
-            const TileIdx In = PVS_FWD_SADDR ? load_tile_idx32(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_next, e_begin, e_end, j)
+            const TileIdx In = SA32 ? load_tile_idx32(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_next, e_begin, e_end, j)
                                              : load_tile_idx(g, w.n_attr | ((flags & kAblNoGather) ? 0x100 : 0), e_next, e_begin, e_end, j);
             const int e = I.e, ee = I.ee, i = I.i;
             const bool valid = I.valid;
@@ -167,7 +169,7 @@ k_edge_fwd_mfma(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeFwdI
                 d1 = io.x[3 * I.i + 1] - io.x[3 * I.jn + 1];
                 d2 = io.x[3 * I.i + 2] - io.x[3 * I.jn + 2];
             } else {
-                if (PVS_FWD_SADDR) gather_tile32<HB>(io.PQ, io.x, I, hh, G); else gather_tile<HB>(io.PQ, io.x, I, hh, G);
+                if (SA32) gather_tile32<HB>(io.PQ, io.x, I, hh, G); else gather_tile<HB>(io.PQ, io.x, I, hh, G);
                 d0 = G.d0; d1 = G.d1; d2 = G.d2;
             }
             const float rho = d0 * d0 + d1 * d1 + d2 * d2;
@@ -388,9 +390,11 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
                              int att_act, const PvsEdgeFwdIO& io) {
     PVS_REQUIRE(w.n_attr <= PVS_MAX_EDGE_ATTR, "edge_attr classes %d > %d", w.n_attr,
                 PVS_MAX_EDGE_ATTR);
-    // (32-bit byte offsets into the node tables [N, 2H] fp32 and the edge index arrays: pvs_off)
-    PVS_REQUIRE((long long)g.n_nodes * 8 * H < (1ll << 32) && g.n_edges < (1 << 30),
-                "edge forward: N = %d nodes x %d channels or E = %d edges exceed the 32-bit offsets of this build", g.n_nodes, H, g.n_edges);
+    // (32-bit byte offsets into the node tables [N, 2H] fp32 and the edge index arrays: pvs_off; beyond them the 64-bit
+    // instantiation of the same kernel runs: PVS_FWD_SADDR=0 at run time forces it for the test)
+    const char* sa_env = getenv("PVS_FWD_SADDR");
+    const bool force64 = sa_env && sa_env[0] == '0';
+    const bool sa32 = PVS_FWD_SADDR && !force64 && (long long)g.n_nodes * 8 * H < (1ll << 32) && g.n_edges < (1 << 30);
     // rows without edges are never flushed: M = 0, x_out = x
     if (!io.init_done) {
         const long long threads = (long long)g.n_nodes * (H / 4);
@@ -417,19 +421,22 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
         const bool soft = (flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT);
         PvsEdgeFwdIO io1 = io;
         io1.m_out = upd ? mbuf : io.m_out;
-        if (soft) {
-            if (set_lds(k_edge_fwd_mfma<4, kThreads, true, true, 1>, lds)) return -2;
-            k_edge_fwd_mfma<4, kThreads, true, true, 1><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io1, n_chunks, 0, g.n_edges);
-        } else {
-            if (set_lds(k_edge_fwd_mfma<4, kThreads, false, true, 1>, lds)) return -2;
-            k_edge_fwd_mfma<4, kThreads, false, true, 1><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io1, n_chunks, 0, g.n_edges);
-        }
+#define PVS_FWD_WIDE(SF, MD, SA)                                                                       \
+    do {                                                                                              \
+        if (set_lds(k_edge_fwd_mfma<4, kThreads, SF, true, MD, SA>, lds)) return -2;                  \
+        k_edge_fwd_mfma<4, kThreads, SF, true, MD, SA><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io1, n_chunks, 0, g.n_edges); \
+    } while (0)
+        if (soft && sa32) PVS_FWD_WIDE(true, 1, true);
+        else if (soft) PVS_FWD_WIDE(true, 1, false);
+        else if (sa32) PVS_FWD_WIDE(false, 1, true);
+        else PVS_FWD_WIDE(false, 1, false);
         PVS_CHECK_LAUNCH();
         if (upd) {
-            if (set_lds(k_edge_fwd_mfma<4, kThreads, false, true, 2>, lds)) return -2;
-            k_edge_fwd_mfma<4, kThreads, false, true, 2><<<blocks, kThreads, lds, s>>>(g, w, flags, att_act, io1, n_chunks, 0, g.n_edges);
+            if (sa32) PVS_FWD_WIDE(false, 2, true);
+            else PVS_FWD_WIDE(false, 2, false);
             PVS_CHECK_LAUNCH();
         }
+#undef PVS_FWD_WIDE
         if (soft) return pvs_launch_softmax_finalize(s, g, io.smax, io.ssum, io.att_out);
         return 0;
     }
@@ -451,15 +458,17 @@ int pvs_launch_edge_fwd_mfma(hipStream_t s, int H, const PvsGraph& g, const PvsE
                          (size_t)nw * (kTile * (H + 4) + kTile * 4 + kTile);
     const size_t lds = words * sizeof(float);
     const bool soft = (flags & PVS_EDGE_ATTENTION) && (flags & PVS_SOFTMAX_ATT);
-#define PVS_FWD_LAUNCH(HBV, NTV, SF, F16)                                                            \
+#define PVS_FWD_LAUNCH(HBV, NTV, SF, F16, SA)                                                         \
     do {                                                                                            \
-        if (set_lds(k_edge_fwd_mfma<HBV, NTV, SF, F16>, lds)) return -2;                     \
-        k_edge_fwd_mfma<HBV, NTV, SF, F16><<<blocks, NTV, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges); \
+        if (set_lds(k_edge_fwd_mfma<HBV, NTV, SF, F16, 0, SA>, lds)) return -2;                     \
+        k_edge_fwd_mfma<HBV, NTV, SF, F16, 0, SA><<<blocks, NTV, lds, s>>>(g, w, flags, att_act, io, n_chunks, 0, g.n_edges); \
     } while (0)
-#define PVS_FWD_PICK(HBV, NTV, F16)                       \
-    do {                                                  \
-        if (soft) PVS_FWD_LAUNCH(HBV, NTV, true, F16);    \
-        else PVS_FWD_LAUNCH(HBV, NTV, false, F16);        \
+#define PVS_FWD_PICK(HBV, NTV, F16)                                   \
+    do {                                                              \
+        if (soft && sa32) PVS_FWD_LAUNCH(HBV, NTV, true, F16, true);  \
+        else if (soft) PVS_FWD_LAUNCH(HBV, NTV, true, F16, false);    \
+        else if (sa32) PVS_FWD_LAUNCH(HBV, NTV, false, F16, true);    \
+        else PVS_FWD_LAUNCH(HBV, NTV, false, F16, false);             \
     } while (0)
     if (HB == 2 && f16x2 && nw == 12) PVS_FWD_PICK(2, 768, true);
     else if (HB == 2 && f16x2) PVS_FWD_PICK(2, 512, true);

@@ -576,38 +576,43 @@ __global__ void __launch_bounds__(256) k_csc_colptr(int32_t* __restrict__ cnt, c
                                                     const int32_t* __restrict__ edge_ptr, int cpg, int stride,
                                                     int32_t* __restrict__ colptr, const int32_t* __restrict__ status) {
     __shared__ int32_t wave_tot[4], front_tot[4];
-    const int g = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     if (*status & 4) {
-        for (int i = (g * gridDim.x + blockIdx.x) * 256 + t; i <= N; i += gridDim.x * gridDim.y * 256) colptr[i] = 0;
+        for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + t; i <= N; i += gridDim.x * gridDim.y * 256) colptr[i] = 0;
         return;
     }
-    if (g == n_graphs - 1 && blockIdx.x == 0 && t == 0) colptr[N] = E;
-    const int n0 = node_ptr[g], width = min(node_ptr[g + 1] - n0, stride);
-    const int c0 = blockIdx.x * 256;
-    if (c0 >= width) return;
-    int front = 0;
-    for (int c = t; c < c0; c += 256) front += indeg[n0 + c];
-    const int c = c0 + t;
-    const int mine = c < width ? indeg[n0 + c] : 0;
-    int inc = mine;
+    // (grid.y is capped at 65535: batches of more graphs than that take several graphs per block row)
+    for (int g = blockIdx.y; g < n_graphs; g += gridDim.y) {
+        if (g == n_graphs - 1 && blockIdx.x == 0 && t == 0) colptr[N] = E;
+        const int n0 = node_ptr[g], width = min(node_ptr[g + 1] - n0, stride);
+        const int c0 = blockIdx.x * 256;
+        if (c0 >= width) continue;             // (block-uniform)
+        int front = 0;
+        for (int c = t; c < c0; c += 256) front += indeg[n0 + c];
+        const int c = c0 + t;
+        const int mine = c < width ? indeg[n0 + c] : 0;
+        int inc = mine;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += up;
-        front += __shfl_xor(front, o, 64);
-    }
-    if (lane == 63) wave_tot[wv] = inc;
-    if (lane == 0) front_tot[wv] = front;
-    __syncthreads();
-    int run = edge_ptr[g] + (front_tot[0] + front_tot[1]) + (front_tot[2] + front_tot[3]) + inc - mine;
-    for (int k = 0; k < wv; ++k) run += wave_tot[k];
-    if (c >= width) return;
-    colptr[n0 + c] = run;
-    for (int k = 0; k < cpg; ++k) {
-        int32_t* slot = cnt + ((size_t)g * cpg + k) * stride + c;
-        const int v = *slot;
-        *slot = run;
-        run += v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+            front += __shfl_xor(front, o, 64);
+        }
+        if (lane == 63) wave_tot[wv] = inc;
+        if (lane == 0) front_tot[wv] = front;
+        __syncthreads();
+        int run = edge_ptr[g] + (front_tot[0] + front_tot[1]) + (front_tot[2] + front_tot[3]) + inc - mine;
+        for (int k = 0; k < wv; ++k) run += wave_tot[k];
+        if (c < width) {
+            colptr[n0 + c] = run;
+            for (int k = 0; k < cpg; ++k) {
+                int32_t* slot = cnt + ((size_t)g * cpg + k) * stride + c;
+                const int v = *slot;
+                *slot = run;
+                run += v;
+            }
+        }
+        __syncthreads();                       // the totals are rewritten by the next graph of this block row
     }
 }
 
@@ -682,7 +687,7 @@ extern "C" int pvs_graph_prepare_runs(const int64_t* edge_index, const int64_t* 
         }
         k_csc_totals<<<(N + T - 1) / T, T, 0, stream>>>(w.csc_cnt, N, n_graphs, node_ptr, cpg, stride, w.indeg, status);
         PVS_CHECK_LAUNCH();
-        k_csc_colptr<<<dim3((max_graph_nodes + 255) / 256, n_graphs), 256, 0, stream>>>(w.csc_cnt, w.indeg, N, E, n_graphs, node_ptr,
+        k_csc_colptr<<<dim3((max_graph_nodes + 255) / 256, n_graphs < 65535 ? n_graphs : 65535), 256, 0, stream>>>(w.csc_cnt, w.indeg, N, E, n_graphs, node_ptr,
                                                                                          edge_ptr, cpg, stride, colptr, status);
         PVS_CHECK_LAUNCH();
         if (E > 0) {
@@ -881,12 +886,13 @@ k_segment_reduce(const float* __restrict__ data, const int32_t* __restrict__ per
 }
 
 __global__ void k_segment_expand(const float* __restrict__ g_out, const int64_t* __restrict__ ids,
-                                 const int32_t* __restrict__ ptr, long long total, int C, int mean,
+                                 const int32_t* __restrict__ ptr, long long total, int C, int N, int mean,
                                  float* __restrict__ g_data) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const int e = (int)(i / C), c = (int)(i % C);
-        const int n = (int)ids[e];
+        const int64_t id = ids[e];
+        const int n = id < 0 || id >= N ? 0 : (int)id;     // (as k_seg_extract clamps; the forward set status bit 0)
         float s = 1.f;
         if (mean) { const int cnt = ptr[n + 1] - ptr[n]; s = 1.0f / (float)(cnt > 1 ? cnt : 1); }
         g_data[i] = g_out[(size_t)n * C + c] * s;
@@ -937,12 +943,13 @@ extern "C" int pvs_segment_reduce_fwd(const float* data, const int64_t* ids, int
 }
 
 extern "C" int pvs_segment_reduce_bwd(const float* g_out, const int64_t* ids, const int32_t* ptr,
-                                      int32_t E, int32_t C, int32_t mean, float* g_data,
+                                      int32_t E, int32_t C, int32_t N, int32_t mean, float* g_data,
                                       pvs_stream_t stream) {
+    PVS_REQUIRE(N > 0 && C > 0, "pvs_segment_reduce_bwd: bad sizes");
     if (E <= 0) return 0;
     const long long total = (long long)E * C;
     int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    k_segment_expand<<<blocks, 256, 0, (hipStream_t)stream>>>(g_out, ids, ptr, total, C, mean, g_data);
+    k_segment_expand<<<blocks, 256, 0, (hipStream_t)stream>>>(g_out, ids, ptr, total, C, N, mean, g_data);
     PVS_CHECK_LAUNCH();
     return 0;
 }

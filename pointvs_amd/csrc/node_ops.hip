@@ -452,7 +452,9 @@ k_adam_clip(const PvsAdamEntry* __restrict__ table, float lr, float beta1, float
     if constexpr (STEP_DEV) {
         __shared__ float bc[2];
         if (threadIdx.x == 0) {      // (from the betas as the caller holds them - doubles in Python - like `1 - beta ** step` there)
-            const double t = (double)step_dev[0];
+            // (a counter below 1 - a state restored by hand, a step skipped - would make both corrections 0 and the
+            // update a division by zero: treated as the first step)
+            const double t = fmax((double)step_dev[0], 1.0);
             bc[0] = (float)(1.0 - pow(beta1_d, t));
             bc[1] = (float)(1.0 - pow(beta2_d, t));
         }

@@ -165,16 +165,57 @@ class EGNNLayer(nn.Module):
             None if natt is None else natt.weight, None if natt is None else natt.bias,
             getattr(self, 'edge_gate_parameter', None), getattr(self, 'node_gate_parameter', None))
 
+    # (container attribute, index inside it or None, parameter name) of the twenty slots of `_params()`, in its order
+    _SLOTS = (('edge_mlp', '0', 'weight'), ('edge_mlp', '0', 'bias'), ('edge_mlp', '2', 'weight'),
+              ('edge_mlp', '2', 'bias'), ('coord_mlp', '0', 'weight'), ('coord_mlp', '0', 'bias'),
+              ('coord_mlp', '2', 'weight'), ('att_mlp', '0', 'weight'), ('att_mlp', '0', 'bias'),
+              ('node_mlp', '0', 'weight'), ('node_mlp', '0', 'bias'), ('node_mlp', '3', 'weight'),
+              ('node_mlp', '3', 'bias'), ('node_mlp', '1', 'weight'), ('node_mlp', '1', 'bias'),
+              ('node_mlp', '1', 'mean_scale'), ('node_att_mlp', '0', 'weight'), ('node_att_mlp', '0', 'bias'),
+              (None, None, 'edge_gate_parameter'), (None, None, 'node_gate_parameter'))
+
+    def _slot_probes(self, params):
+        """For every non-None slot of `params` the chain of plain dicts that leads from the layer to the tensor:
+        (layer._modules, container name, container._modules, index, leaf._parameters, parameter name, tensor). Walking
+        it is seven dict look-ups per slot and sees a replaced container, a replaced leaf module and a replaced
+        parameter alike. A slot whose tensor is not a registered parameter (parametrize / weight_norm compute it on
+        access) has no chain: returns None and nothing is cached."""
+        probes = []
+        for (cont, idx, name), p in zip(self._SLOTS, params):
+            if p is None:
+                continue
+            if cont is None:
+                if self._parameters.get(name) is not p:
+                    return None
+                probes.append((None, None, None, None, self._parameters, name, p))
+                continue
+            seq = self._modules.get(cont)
+            leaf = None if seq is None else seq._modules.get(idx)
+            if leaf is None or leaf._parameters.get(name) is not p:
+                return None
+            probes.append((self._modules, cont, seq, idx, leaf, name, p))
+        return tuple(probes)
+
     def _params_cached(self):
         """(parameter tuple, PvsLayerParams) built once per layer: 35 module look-ups, 20 contiguity checks and a ctypes
         struct per call otherwise (small batches are host-bound: tools/host_profile.py). The parameters are updated in
-        place (Adam, load_state_dict), so tensors and addresses stay; the cache is dropped by `_apply` (.to / .cuda /
-        .float), by assigning a parameter or sub-module of the layer, and whenever an address differs from the one the
-        struct was built with (`p.data = ...`) or the first parameter is no longer the same object."""
+        place (Adam, load_state_dict), so tensors and addresses stay. EVERY slot is validated on every call, by
+        identity against the live modules (`_slot_probes`: plain dict look-ups, ~2 us per layer) and by address
+        (`p.data = ...`): assigning a nested parameter (`layer.node_mlp[0].weight = ...`,
+        `load_state_dict(assign=True)`), replacing a leaf module or a container all rebuild the struct. The cache is
+        also dropped by `_apply` (.to / .cuda / .float) and is never pickled or deep-copied (`__getstate__`: a ctypes
+        struct with pointers cannot be)."""
         cached = self.__dict__.get('_pcache')
         if cached is not None:
-            params, pstruct, ptrs = cached
-            if params[0] is self.edge_mlp[0].weight and ptrs == tuple(p.data_ptr() for p in params if p is not None):
+            params, pstruct, probes = cached
+            for mods, cont, seq, idx, leaf, name, p, addr in probes:
+                if mods is None:
+                    if leaf.get(name) is not p or p.data_ptr() != addr:
+                        break
+                elif (mods.get(cont) is not seq or seq._modules.get(idx) is not leaf
+                        or leaf._parameters.get(name) is not p or p.data_ptr() != addr):
+                    break
+            else:
                 return params, pstruct
         params = self._params()
         ok = all(p is None or (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()) for p in params)
@@ -182,7 +223,11 @@ class EGNNLayer(nn.Module):
             self.__dict__.pop('_pcache', None)
             return params, None
         pstruct = _lib.PvsLayerParams(*[_lib.ptr(p) for p in params])
-        self.__dict__['_pcache'] = (params, pstruct, tuple(p.data_ptr() for p in params if p is not None))
+        probes = self._slot_probes(params)
+        if probes is None:            # computed weights (parametrizations): a fresh struct per call
+            self.__dict__.pop('_pcache', None)
+        else:
+            self.__dict__['_pcache'] = (params, pstruct, tuple(pr + (pr[6].data_ptr(),) for pr in probes))
         return params, pstruct
 
     def _apply(self, fn, *args, **kwargs):
@@ -193,6 +238,17 @@ class EGNNLayer(nn.Module):
         if isinstance(value, (torch.nn.Parameter, torch.nn.Module)):
             self.__dict__.pop('_pcache', None)
         super().__setattr__(name, value)
+
+    def __getstate__(self):
+        """copy.deepcopy (EMA / SWA `AveragedModel`, snapshots) and pickling: without the ctypes struct cache (pointers
+        cannot be pickled, and a copy has its own tensors) and without the lazily evaluated side attributes (closures
+        over device tensors of the last call; `att_val` etc. read None on the copy until its own first forward)."""
+        state = self.__dict__.copy()
+        state.pop('_pcache', None)
+        for k in ('_att_src', '_natt_src', '_coords_src'):
+            if k in state:
+                state[k] = None
+        return state
 
     _KERNEL_WIDTHS = (16, 32, 64, 128)
 

@@ -303,6 +303,42 @@ def bce_with_logits_mean(y_pred, y_true):
     return _BceLogitsMeanFn.apply(y_pred, y_true)
 
 
+class _SegmentStatus:
+    """The status word of one pvs_segment_reduce_fwd call, read WITHOUT blocking the stream (as
+    graph.PreparedGraph.poll_status reads the graph preparation's): the call queues a copy into pinned memory and an
+    event; every later segment_reduce call raises for whichever earlier words have landed, and the call's own backward
+    waits for its word (it has long landed by then). The reference's scatter_add_ raises at once
+    (egnn_satorras.py:336); here the error surfaces one call late - or in the backward - but it does surface."""
+    pending = []
+
+    def __init__(self, status):
+        self.host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        self.host.copy_(status, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(status.device))
+        self.done = False
+        _SegmentStatus.pending.append(self)
+
+    def settle(self, wait):
+        if self.done:
+            return
+        if not self.event.query():
+            if not wait:
+                return
+            self.event.synchronize()
+        self.done = True
+        if self in _SegmentStatus.pending:
+            _SegmentStatus.pending.remove(self)
+        if int(self.host.item()) & 1:
+            raise IndexError('unsorted_segment_sum / unsorted_segment_mean: segment_ids contains values outside '
+                             '[0, num_segments)')
+
+    @classmethod
+    def poll(cls):
+        for st in list(cls.pending):
+            st.settle(wait=False)
+
+
 class _SegmentReduceFn(torch.autograd.Function):
     """unsorted_segment_sum / unsorted_segment_mean (egnn_satorras.py:332-347)."""
 
@@ -314,6 +350,9 @@ class _SegmentReduceFn(torch.autograd.Function):
         ids = segment_ids.long().contiguous()
         e, c = data.shape
         dev = data.device
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            _SegmentStatus.poll()           # an earlier call's out-of-range ids raise here
         out = torch.empty((num_segments, c), dtype=torch.float32, device=dev)
         ptr = torch.empty(num_segments + 1, dtype=torch.int32, device=dev)
         status = torch.empty(1, dtype=torch.int32, device=dev)
@@ -323,24 +362,33 @@ class _SegmentReduceFn(torch.autograd.Function):
             _lib.ptr(data), _lib.ptr(ids), e, c, num_segments, 1 if mean else 0, _lib.ptr(out),
             _lib.ptr(ptr), _lib.ptr(status), _lib.ptr(ws), ws_bytes, _stream(dev)),
             'pvs_segment_reduce_fwd')
+        ctx.status = None if capturing else _SegmentStatus(status)      # (no host-visible validation inside a capture)
         ctx.save_for_backward(ids, ptr)
-        ctx.mean, ctx.shape = mean, (e, c)
+        ctx.mean, ctx.shape, ctx.n_segments = mean, (e, c), num_segments
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         ids, ptr = ctx.saved_tensors
+        if ctx.status is not None and not torch.cuda.is_current_stream_capturing():
+            ctx.status.settle(wait=True)
         g_out = _f32c(g_out)
         e, c = ctx.shape
         g_data = torch.empty((e, c), dtype=torch.float32, device=g_out.device)
         _lib.check(_lib.lib().pvs_segment_reduce_bwd(
-            _lib.ptr(g_out), _lib.ptr(ids), _lib.ptr(ptr), e, c, 1 if ctx.mean else 0,
+            _lib.ptr(g_out), _lib.ptr(ids), _lib.ptr(ptr), e, c, ctx.n_segments, 1 if ctx.mean else 0,
             _lib.ptr(g_data), _stream(g_out.device)), 'pvs_segment_reduce_bwd')
         return g_data, None, None, None
 
 
 def segment_reduce(data, segment_ids, num_segments, mean=False):
     return _SegmentReduceFn.apply(data, segment_ids, int(num_segments), bool(mean))
+
+
+def segment_status_check():
+    """Wait for every pending status word of segment_reduce and raise for the first bad one (call where a sync is fine)."""
+    for st in list(_SegmentStatus.pending):
+        st.settle(wait=True)
 
 
 def dropout_adj(edge_index, edge_attr=None, p=0.5, force_undirected=True, training=True, seed=0, step=0):

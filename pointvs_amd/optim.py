@@ -180,14 +180,18 @@ class FusedClipAdam(torch.optim.Adam):
         return self._fast
 
     def _gradients_fusable(self, fast):
-        """What can change from step to step under an unchanged plan: the learning rate becoming a tensor, a gradient
-        that is not a dense contiguous tensor."""
+        """What can change from step to step under an unchanged plan: a group option the kernel does not cover switched
+        on mid-run (amsgrad, maximize, ... or a tensor learning rate), the model moved or cast after the first step
+        (`model.half()` / `.double()` / `.cpu()`: the kernel takes raw pointers as fp32 device memory), a gradient that
+        is not a dense contiguous fp32 tensor."""
         for group, works in zip(self.param_groups, fast['groups']):
-            if isinstance(group['lr'], torch.Tensor):
+            if group.get('amsgrad') or group.get('maximize') or group.get('differentiable') \
+                    or group.get('decoupled_weight_decay') or isinstance(group['lr'], torch.Tensor):
                 return False
             for work in works:
                 for p in work['params']:
                     g = p.grad
-                    if g.is_sparse or not g.is_contiguous():
+                    if (not p.is_cuda or p.dtype != torch.float32 or g.dtype != torch.float32 or g.is_sparse
+                            or not g.is_contiguous() or not p.is_contiguous()):
                         return False
         return True

@@ -8,6 +8,7 @@ Mirrors the constructor, loss, optimiser step and checkpoint format of
 Progress bars, wandb and the predictions-file writer are outside the hot-path scope and reduced to
 plain logging.
 """
+import itertools
 import math
 import os
 import re
@@ -63,6 +64,7 @@ class _StepReplayer:
         self.stats = {'eager': 0, 'captured': 0, 'replayed': 0}
         model.last_capture_stats = self.stats
         self._was = []
+        model._capturable_was = self._was       # save() writes the optimiser's OWN form, not the replayer's
         for group in model.optimiser.param_groups:
             self._was.append(group.get('capturable', False))
             group['capturable'] = True
@@ -86,10 +88,22 @@ class _StepReplayer:
                     if st and isinstance(st.get('step'), torch.Tensor) and st['step'].is_cuda:
                         st['step'] = st['step'].cpu()
         opt._fast = None
+        self.model._capturable_was = None
 
-    @staticmethod
-    def _key(graph, task):
-        key = [task]
+    _batch_ids = itertools.count(1)
+
+    @classmethod
+    def _key(cls, graph, task):
+        """A batch is 'the same batch again' when it is the same OBJECT with the same device tensors at the same
+        versions: the object carries an id stamped on its first visit (a streaming loader that yields fresh batch
+        objects whose tensors happen to reuse freed addresses is never taken for a second visit)."""
+        try:
+            bid = graph.__dict__.get('_pvs_batch_id')
+            if bid is None:
+                bid = graph.__dict__['_pvs_batch_id'] = next(cls._batch_ids)
+        except AttributeError:
+            return None
+        key = [task, bid]
         for name in ('x', 'pos', 'edge_index', 'edge_attr', 'batch', 'y'):
             t = getattr(graph, name, None)
             if t is None:
@@ -376,7 +390,33 @@ class PointNeuralNetworkBase(nn.Module):
             'learning_rate': self.lr, 'weight_decay': self.weight_decay,
             'p_epoch': self.p_epoch, 'a_epoch': self.a_epoch,
             'model_state_dict': self.state_dict(),
-            'optimiser_state_dict': self.optimiser.state_dict()}, save_path)
+            'optimiser_state_dict': self._optimiser_state_for_checkpoint()}, save_path)
+
+    def _optimiser_state_for_checkpoint(self):
+        """`optimiser.state_dict()` in the form the optimiser has OUTSIDE train_model(capture=True): the replayer
+        flips every group to `capturable=True` with the step counters on the device for the duration of the call, and a
+        checkpoint written at an epoch end in between would carry that (a resumed run would silently be capturable -
+        another FusedClipAdam path, and torch's Adam asserts on CPU parameters). The groups get their own flags back
+        and the counters go to the host, as the reference's checkpoints hold them (:501-517)."""
+        sd = self.optimiser.state_dict()
+        was = getattr(self, '_capturable_was', None)
+        if not was:
+            return sd
+        groups = []
+        for group, flag in zip(sd['param_groups'], was):
+            group = dict(group)
+            group['capturable'] = flag
+            groups.append(group)
+            if flag:
+                continue
+            for idx in group['params']:
+                st = sd['state'].get(idx)
+                if st is not None and torch.is_tensor(st.get('step')) and st['step'].is_cuda:
+                    st = dict(st)
+                    st['step'] = st['step'].detach().cpu()
+                    sd['state'][idx] = st
+        sd['param_groups'] = groups
+        return sd
 
     @staticmethod
     def _transform_names(d):

@@ -16,6 +16,17 @@ bypassed: a plain list of collated batches stands in for the DataLoader) and rec
 per step: the loss `backprop()` returned and the learning rate the step ran at; at the end: the
 `state_dict`, the epoch counters, the checkpoint file names and the keys of a checkpoint dict.
 Output: tests/golden/train_<schedule>.npz (data only).
+
+Round 6: for `default` and `k64_attention` the reference's OWN last checkpoint
+file is kept byte for byte (tests/golden/ckpt_<schedule>.pt: what its save() wrote, :501-517 - tensors, floats and
+ints in dicts only), and a RESUMED reference run is recorded beside it: a fresh reference model, `load_weights` of that
+file (:528-565), its eval-mode logits on the first batch (`resume/logits`), then ONE more `backprop()` on that batch -
+the run's 13th optimiser step - with its loss, learning rate and the weights it leaves (`resume/loss`, `resume/lr`,
+`sd13/*`). For `k64_attention` (edge + node attention) a LEGACY-NAMED variant of the checkpoint is written too
+(ckpt_k64_attention_legacy.pt): the names `_transform_names` (:519-526) maps FROM - `edge_attention_mlp` with its Linear
+at index 2 of the older four-element Sequential, `node_attention_mlp` - i.e. the inverse of the reference's own
+renaming, and it is only kept after the reference's `load_weights` has loaded it through its fallbacks and reproduced
+the plain checkpoint's logits bit for bit.
 """
 import json
 import sys
@@ -83,7 +94,75 @@ def record_training(model, phases):
     return steps
 
 
-def run(name, cls, ctor_kwargs, phases, seed=7, kw_changes=None):
+def resumed_reference_run(name, cls, ctor_kwargs, kw, run_dir, ckpt_rel, loader, seed):
+    """Keeps the reference-written checkpoint `run_dir / ckpt_rel` as tests/golden/ckpt_<name>.pt and records what the
+    REFERENCE does when it resumes from it (module docstring). Returns the arrays to add to the schedule's file."""
+    import shutil
+    src = run_dir / ckpt_rel
+    kept = HERE / f'ckpt_{name}.pt'
+    shutil.copyfile(src, kept)
+    first = next(iter(list.__iter__(loader)))
+
+    def fresh():
+        torch.manual_seed(seed + 1000)          # other initial weights than the run's: everything must come from the file
+        np.random.seed(seed + 1000)
+        tmp2 = Path(tempfile.mkdtemp())
+        return cls(tmp2, 2e-3, 1e-4, None, None, silent=True, **ctor_kwargs, **kw), tmp2
+
+    def place(tmp2, path):
+        # load_weights reads model_kwargs.yaml two levels above the file (:534-536); a model built with silent=True
+        # does not write one (:109-112), so the same dump is made here
+        import yaml
+        dst = tmp2 / 'checkpoints' / Path(ckpt_rel).name
+        dst.parent.mkdir(parents=True, exist_ok=True)
+        (tmp2 / 'model_kwargs.yaml').write_text(yaml.dump(dict(kw)))
+        shutil.copyfile(path, dst)
+        return dst
+
+    def logits_of(model):
+        model.eval()
+        with torch.no_grad():
+            y = model(mg.clone_graph(first))
+        return y.detach().reshape(-1).numpy().astype(np.float32)
+
+    model, tmp2 = fresh()
+    model.load_weights(place(tmp2, kept), silent=True)
+    out = {'resume/logits': logits_of(model),
+           'resume/p_epoch': np.array(model.p_epoch), 'resume/a_epoch': np.array(model.a_epoch)}
+    model.train()
+    model.eta = '0'
+    y_pred, y_true, _, _ = model.unpack_input_data_and_predict(mg.clone_graph(first))
+    out['resume/lr'] = np.array(float(model.optimiser.param_groups[0]['lr']))
+    out['resume/loss'] = np.array(float(model.backprop(y_true, y_pred)))
+    for k, v in model.state_dict().items():
+        out[f'sd13/{k}'] = v.detach().numpy().copy()
+    st = model.optimiser.state_dict()['state']
+    out['resume/optimiser_steps'] = np.array(sorted({int(s['step']) for s in st.values()}))
+    print(f'{name:14s} resumed: logits {out["resume/logits"]}  13th-step loss {float(out["resume/loss"]):.6f} '
+          f'lr {float(out["resume/lr"]):.3e}  {kept.name} {kept.stat().st_size / 1024:.0f} KiB')
+
+    if kw.get('edge_attention') and kw.get('node_attention'):
+        ck = torch.load(kept, map_location='cpu', weights_only=False)
+        import re
+        from collections import OrderedDict
+        legacy = OrderedDict()
+        for k, v in ck['model_state_dict'].items():      # the inverse of _transform_names + the older Sequential
+            k = re.sub(r'(^|\.)att_mlp\.0\.', r'\1edge_attention_mlp.2.', k)
+            k = k.replace('node_att_mlp', 'node_attention_mlp')
+            legacy[k] = v
+        assert any('edge_attention_mlp.2.' in k for k in legacy) and any('node_attention_mlp' in k for k in legacy)
+        ck['model_state_dict'] = legacy
+        legacy_path = HERE / f'ckpt_{name}_legacy.pt'
+        torch.save(ck, legacy_path)
+        model2, tmp3 = fresh()
+        model2.load_weights(place(tmp3, legacy_path), silent=True)     # the reference loads it (through both fallbacks)
+        again = logits_of(model2)
+        assert np.array_equal(again, out['resume/logits']), (again, out['resume/logits'])
+        print(f'{name:14s} legacy-named variant loaded by the reference: logits identical  {legacy_path.name}')
+    return out
+
+
+def run(name, cls, ctor_kwargs, phases, seed=7, kw_changes=None, keep_checkpoint=False):
     torch.manual_seed(seed)
     np.random.seed(seed)
     KW = dict(globals()['KW'], **(kw_changes or {}))
@@ -95,6 +174,9 @@ def run(name, cls, ctor_kwargs, phases, seed=7, kw_changes=None):
         ck = torch.load(Path(tmp) / ckpts[-1], map_location='cpu', weights_only=False)
         ckpt_keys = sorted(ck.keys())
         opt_steps = sorted({int(s['step']) for s in ck['optimiser_state_dict']['state'].values()})
+        resume = None
+        if keep_checkpoint:
+            resume = resumed_reference_run(name, cls, ctor_kwargs, KW, Path(tmp), ckpts[-1], phases[-1][1], seed)
     out = {'meta': np.array(json.dumps({
         'name': name, 'class': cls.__name__, 'kwargs': KW, 'ctor': ctor_kwargs, 'seed': seed, 'lr': 2e-3, 'wd': 1e-4,
         'phases': [(t, len(l), e) for t, l, e in phases], 'tasks': [s[0] for s in steps],
@@ -102,6 +184,8 @@ def run(name, cls, ctor_kwargs, phases, seed=7, kw_changes=None):
         'checkpoints': ckpts, 'checkpoint_keys': ckpt_keys, 'optimiser_steps_in_last_checkpoint': opt_steps})),
         'loss': np.array([s[1] for s in steps], dtype=np.float64),
         'lr': np.array([s[2] for s in steps], dtype=np.float64)}
+    if resume is not None:
+        out.update(resume)
     for k, v in sd0.items():
         out[f'sd0/{k}'] = v
     for k, v in model.state_dict().items():
@@ -124,14 +208,15 @@ def run(name, cls, ctor_kwargs, phases, seed=7, kw_changes=None):
 
 def main():
     pose = batches(100)
-    run('default', SartorrasEGNN, {}, [('classification', pose, 3)])
+    run('default', SartorrasEGNN, {}, [('classification', pose, 3)], keep_checkpoint=True)
     run('one_cycle', SartorrasEGNN, {'use_1cycle': True}, [('classification', batches(100), 3)])
     run('warm_restarts', SartorrasEGNN, {'warm_restarts': True}, [('classification', batches(100), 3)])
     run('multitask', MultitaskSatorrasEGNN, {},
         [('classification', batches(100), 2), ('regression', batches(500, regression=True), 1)])
     # BASELINE config 3's flag set (64 channels, sigmoid edge gate + node gate): the H = 64 kernels in a training run
     run('k64_attention', SartorrasEGNN, {'warm_restarts': True}, [('classification', batches(100), 3)],
-        kw_changes={'k': 64, 'edge_attention': True, 'node_attention': True, 'tanh': False, 'num_layers': 3})
+        kw_changes={'k': 64, 'edge_attention': True, 'node_attention': True, 'tanh': False, 'num_layers': 3},
+        keep_checkpoint=True)
 
 
 if __name__ == '__main__':

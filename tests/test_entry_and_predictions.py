@@ -104,6 +104,47 @@ def test_bench_launcher_parent_never_loads_torch_and_counts_gpus_from_sysfs(tmp_
     assert bench.visible_gpu_count(tmp_path / 'absent') is None
 
 
+def test_bench_eight_rank_launch_command_device_binding_and_rccl_choice(monkeypatch):
+    """the first real 8-GPU session must not fail on trivia. `python bench.py --gpus 8
+    --global-batch 256 --rccl-proto LL` (BASELINE config 4): the parent builds ONE torch.distributed.run command with
+    eight ranks on the loopback that re-runs bench.py with the same arguments, hands NCCL_PROTO (and the dmabuf IPC
+    switch) to the ranks' environment before any process group exists, and refuses when fewer GPUs are visible than
+    ranks - unless the dry-run backend is named. A rank binds LOCAL_RANK -> its own device (checked on the source:
+    no GPU here)."""
+    import argparse
+    import bench
+    args = argparse.Namespace(gpus=8, rccl_proto='LL', rccl_algo=None)
+    argv = ['--gpus', '8', '--global-batch', '256', '--rccl-proto', 'LL']
+    cmd = bench.launch_command(args, 29517, argv)
+    assert cmd[:4] == [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1']
+    assert '--nproc-per-node=8' in cmd and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[cmd.index('--master-port') + 1] == '29517'
+    assert cmd[-len(argv) - 1:] == [str(ROOT / 'bench.py')] + argv
+    seen = {}
+
+    class Done:
+        returncode = 0
+
+    def fake_run(cmd, env):
+        seen['cmd'], seen['env'] = cmd, env
+        return Done()
+    monkeypatch.delenv('PVS_BENCH_BACKEND', raising=False)
+    monkeypatch.delenv('NCCL_PROTO', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py'] + argv)
+    assert bench.self_launch(args, run=fake_run, n_visible=8) == 0
+    assert seen['env']['NCCL_PROTO'] == 'LL' and seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    assert 'NCCL_ALGO' not in seen['env'] and seen['cmd'][-len(argv):] == argv
+    assert bench.rccl_env_record(seen['env'])['NCCL_PROTO'] == 'LL'
+    with pytest.raises(SystemExit, match='only 1 GPU'):
+        bench.self_launch(args, run=fake_run, n_visible=1)
+    monkeypatch.setenv('PVS_BENCH_BACKEND', 'gloo')
+    assert bench.self_launch(args, run=fake_run, n_visible=1) == 0           # the dry run shares devices
+    src = (ROOT / 'bench.py').read_text()
+    assert "local_rank = int(os.environ.get('LOCAL_RANK', 0))" in src
+    assert "dev_index = local_rank if backend == 'nccl' else" in src and 'torch.cuda.set_device(dev_index)' in src
+    assert src.index('apply_rccl_choice(args, os.environ)') < src.index("dist.init_process_group('nccl'")
+
+
 def test_model_selection_metrics_follow_the_reference(tmp_path):
     """val()'s top1_on_end: top-n over receptors (analysis/top_n.py:32-49) and Pearson's r of the affinity file
     (utils.py:189-198) on predictions files in the reference's line format."""

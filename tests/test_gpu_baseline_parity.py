@@ -165,3 +165,120 @@ def test_receptor_screen_matches_oracle_at_config5_shape(flags):
                 out.append(float(orc.model_forward(sdt, ocfg, feats, pos, ei, ea, batch, n_graphs=1).reshape(-1)[0]))
     ref64, ref32 = np.array(ref64), np.array(ref32)
     assert rel_err(got, ref64) <= _bound(ref32, ref64), (got, ref64)
+
+
+def _replicate_on_device(b, times):
+    """`times` copies of a device batch as ONE batch (node ids offset per copy), built on the device: 256 BASELINE
+    graphs are 81.5 M edges = 3.3 GB of int64 inputs, which the host generator would take a minute to make."""
+    from pointvs_amd.graph import Batch
+    n = b.x.size(0)
+    per = b.num_graphs
+    off = torch.arange(times, device=b.x.device).repeat_interleave(b.edge_index.size(1)) * n
+    big = Batch(
+        x=b.x.repeat(times, 1), pos=b.pos.repeat(times, 1),
+        edge_index=b.edge_index.repeat(1, times) + off, edge_attr=b.edge_attr.repeat(times, 1),
+        y=b.y.repeat(times), lig_fname=list(b.lig_fname) * times, rec_fname=list(b.rec_fname) * times,
+        edge_layout=b.edge_layout,
+        batch=(b.batch.repeat(times) + torch.arange(times, device=b.x.device).repeat_interleave(n) * per),
+        ptr=torch.cat([b.ptr.cpu()[:-1] + k * n for k in range(times)] + [torch.tensor([times * n])]),
+        num_graphs=per * times, graph_node_counts=list(b.graph_node_counts) * times,
+        graph_edge_counts=list(b.graph_edge_counts) * times)
+    return big
+
+
+def _selected_graphs_vs_oracle(model, cfg, items, batch_dev, picks, log_name):
+    """Logits of the graphs `picks` (position in the batch -> the host item it is a copy of) against single-graph fp64
+    oracle runs (strict bound), and the batch's parameter gradients of the MEAN BCE LOSS OVER THOSE GRAPHS ONLY against
+    the mean of the oracle's per-graph gradients: the batch still runs all of its graphs forward and backward (the
+    others receive a zero upstream gradient), and the oracle never holds more than one graph."""
+    from pointvs_amd.graph import Batch
+    mean64, mean32, y64s, y32s = {}, {}, [], []
+    for _, item in picks:
+        g = Batch.from_data_list([items[item]])
+        yt = g.y.float().reshape(-1)
+        y64, _, g64, _ = _oracle(model, cfg, g, yt, torch.float64)
+        y32, _, g32, _ = _oracle(model, cfg, g, yt, torch.float32)
+        y64s.append(y64.reshape(-1)); y32s.append(y32.reshape(-1))
+        for k, v in g64.items():
+            if v is not None:
+                mean64[k] = mean64.get(k, 0.0) + v / len(picks)
+                mean32[k] = mean32.get(k, 0.0) + g32[k].astype(np.float64) / len(picks)
+    y64s, y32s = np.concatenate(y64s), np.concatenate(y32s)
+    idx = torch.tensor([p for p, _ in picks], device='cuda')
+    model.zero_grad()
+    y_pred, y_true, _, _ = model.unpack_input_data_and_predict(batch_dev)
+    got = y_pred.reshape(-1)[idx]
+    log = CaseLog(log_name)
+    assert rel_err(got.detach().cpu().numpy(), y64s) <= _bound(y32s, y64s), (got, y64s)
+    assert_strict(got.detach().cpu().numpy(), y64s, y32s, f'{log.case} logits', log=log)
+    model.get_loss(y_true.cuda().reshape(-1)[idx], got).backward()
+    floor = grad_floor(mean64)
+    for pname, p in model.named_parameters():
+        if p.grad is None:
+            assert pname not in mean64, pname
+            continue
+        gp = p.grad.detach().cpu().numpy()
+        assert rel_err(gp, mean64[pname]) <= _bound(mean32[pname], mean64[pname]), f'{log_name} grad {pname}'
+        assert_strict(gp, mean64[pname], mean32[pname], f'{log.case} grad {pname}', floor=floor, log=log)
+    log.finish()
+    return y_pred.detach().reshape(-1)
+
+
+def test_config4_one_rank_leg_256_graphs_against_the_oracle():
+    """BASELINE config 4's one-rank leg: cfg2 at 256 graphs on ONE GPU (E = 81.5 M, E * H = 2.6e9 > 2^31 elements:
+    every per-edge tensor is indexed beyond 32 bits). The batch is 8 device-side copies of 32 host-made graphs.
+      * logits of graphs 0, 17 and 255 (the last one: a copy of graph 31) and the parameter gradients of the loss over
+        those three: against the fp64 oracle's single-graph runs, strict bound;
+      * every copy's logit equals its original's within 1e-5 (nothing leaks between graphs at any offset);
+      * the parameter gradients of the MEAN loss over all 256 graphs equal those of a 32-graph run of the first 32
+        graphs (the loss is a mean over graphs, point_neural_network_base.py:362-370: 8 copies change nothing).
+    A regression of any per-edge index to 32 bits fails all three. Skips itself below 64 GB of free device memory."""
+    from pointvs_amd.synthetic import synthetic_graph
+    free, _ = torch.cuda.mem_get_info()
+    if free < 64 * 2 ** 30:
+        pytest.skip(f'{free / 2 ** 30:.0f} GB free on the device: the 256-graph batch wants 64 GB of headroom')
+    from pointvs_amd.graph import Batch
+    model, cfg = _build('cfg2', seed=5)
+    items = [synthetic_graph(1000 * cfg['cfg_id'] + k, **cfg['graph']) for k in range(32)]
+    b32 = Batch.from_data_list(items).to('cuda')
+    big = _replicate_on_device(b32, 8)
+    assert big.num_graphs == 256 and big.edge_index.size(1) * cfg['model']['k'] > 2 ** 31
+    y_all = _selected_graphs_vs_oracle(model, cfg, items, big, [(0, 0), (17, 17), (255, 31)], 'cfg4_one_rank_256')
+    y = y_all.cpu().numpy().reshape(8, 32)
+    assert np.abs(y - y[0]).max() <= TOL * max(1.0, np.abs(y[0]).max()), np.abs(y - y[0]).max()
+
+    def mean_loss_grads(batch):
+        model.zero_grad()
+        y_pred, y_true, _, _ = model.unpack_input_data_and_predict(batch)
+        model.get_loss(y_true.cuda(), y_pred).backward()
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    g256 = mean_loss_grads(big)
+    del big
+    g32 = mean_loss_grads(b32)
+    assert g256.keys() == g32.keys()
+    for n in g32:
+        a, b = g256[n].double(), g32[n].double()
+        assert float((a - b).abs().max()) <= TOL * float(b.abs().max()) + 1e-30, n
+
+
+def test_full_batch_config3_three_graphs_against_the_oracle():
+    """cfg3 (12 layers, 64 channels, edge + node attention) at its FULL batch of 32 graphs: logits of graphs 0, 17, 31
+    and the parameter gradients of the loss over those three against the fp64 oracle's single-graph runs (strict
+    bound). (test_gpu_properties' full-batch checks compare the MFMA kernels with the generic ones - HIP against HIP;
+    the oracle cannot hold 32 graphs at once, but it can hold three of them one at a time.)"""
+    from pointvs_amd.graph import Batch
+    from pointvs_amd.synthetic import synthetic_graph
+    model, cfg = _build('cfg3', seed=5)
+    items = [synthetic_graph(1000 * cfg['cfg_id'] + k, **cfg['graph']) for k in range(32)]
+    b32 = Batch.from_data_list(items).to('cuda')
+    _selected_graphs_vs_oracle(model, cfg, items, b32, [(0, 0), (17, 17), (31, 31)], 'cfg3_full_batch_32')
+
+
+def test_full_batch_config2_three_graphs_against_the_oracle():
+    """cfg2 at its full batch of 32 graphs, as above."""
+    from pointvs_amd.graph import Batch
+    from pointvs_amd.synthetic import synthetic_graph
+    model, cfg = _build('cfg2', seed=6)
+    items = [synthetic_graph(1000 * cfg['cfg_id'] + k, **cfg['graph']) for k in range(32)]
+    b32 = Batch.from_data_list(items).to('cuda')
+    _selected_graphs_vs_oracle(model, cfg, items, b32, [(0, 0), (17, 17), (31, 31)], 'cfg2_full_batch_32')

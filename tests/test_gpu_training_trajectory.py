@@ -134,6 +134,14 @@ def test_captured_training_steps_follow_the_reference_trajectory(name, tmp_path)
     ck = torch.load(tmp_path / ckpts[-1], map_location='cpu', weights_only=False)
     opt_steps = sorted({int(s['step']) for s in ck['optimiser_state_dict']['state'].values()})
     assert opt_steps == meta['optimiser_steps_in_last_checkpoint']
+    # every checkpoint - also those written at epoch ends WHILE the replayer had the optimiser in its capturable form -
+    # holds the optimiser as the reference's checkpoints do: not capturable, step counters on the host
+    for rel_path in ckpts:
+        raw = torch.load(tmp_path / rel_path, weights_only=False)        # (no map_location: devices as saved)
+        osd = raw['optimiser_state_dict']
+        assert not any(g.get('capturable') for g in osd['param_groups']), rel_path
+        assert all(not st['step'].is_cuda for st in osd['state'].values()), rel_path
+        assert all(st['exp_avg'].shape == st['exp_avg_sq'].shape for st in osd['state'].values())
     for k, v in model.state_dict().items():
         ref = z[f'sd1/{k}']
         if np.issubdtype(ref.dtype, np.floating):
@@ -144,3 +152,73 @@ def test_captured_training_steps_follow_the_reference_trajectory(name, tmp_path)
     assert all(not s['step'].is_cuda for s in model.optimiser.state.values())
     more = model.train_model([_loaders(z, meta)[-1][0]], epochs=model.a_epoch + model.p_epoch + 1)
     assert len(more) >= 0 and all(np.isfinite(more))
+
+
+
+@pytest.mark.parametrize('name,legacy', [('default', False), ('k64_attention', False), ('k64_attention', True)])
+def test_resuming_from_a_checkpoint_the_reference_wrote(name, legacy, tmp_path):
+    """SURVEY 8f row 4 pinned on the REFERENCE's output: tests/golden/ckpt_<name>.pt is the file the
+    reference's save() (:501-517) wrote after the twelve steps of the `<name>` trajectory, byte for byte;
+    ckpt_k64_attention_legacy.pt carries the older names (`edge_attention_mlp.2.*`, `node_attention_mlp.*`) and was
+    kept only after the reference's own load_weights had loaded it (tests/golden/make_golden_training.py). Here a model
+    with OTHER initial weights loads the file and must then
+      * hold the file's weights and epoch counters, and give the logits the resumed REFERENCE model gave (1e-5);
+      * hold the file's optimiser state parameter by parameter (step = 12, both moments): the reference's Adam keys its
+        state by the position of a parameter in `model.parameters()`, so this pins the registration order too;
+      * take the run's 13th optimiser step like the resumed reference did: the loss of `backprop()` on the first batch,
+        the learning rate it ran at, and the weights it leaves."""
+    import shutil
+    from pointvs_amd.egnn_satorras import SartorrasEGNN
+    z, meta = _load(name)
+    torch.manual_seed(meta['seed'] + 1000)
+    model = SartorrasEGNN(tmp_path, meta['lr'], meta['wd'], None, None, silent=True, **meta['ctor'], **meta['kwargs'])
+    src = GOLDEN / (f'ckpt_{name}_legacy.pt' if legacy else f'ckpt_{name}.pt')
+    dst = tmp_path / 'checkpoints' / 'pose_ckpt_epoch_3.pt'
+    dst.parent.mkdir(parents=True, exist_ok=True)
+    shutil.copyfile(src, dst)
+    file = torch.load(GOLDEN / f'ckpt_{name}.pt', map_location='cpu', weights_only=True)     # (plain names)
+    assert any(not np.array_equal(v.detach().cpu().numpy(), file['model_state_dict'][k].numpy())
+               for k, v in model.state_dict().items())
+    model.load_weights(dst, silent=True)
+    assert (model.p_epoch, model.a_epoch) == (int(z['resume/p_epoch']), int(z['resume/a_epoch'])) == (3, 0)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(file['model_state_dict'].keys())
+    for k, v in sd.items():
+        assert np.array_equal(v.detach().cpu().numpy(), file['model_state_dict'][k].numpy()), k
+    # optimiser state, by position in the reference's parameter order (= its state_dict order: no buffers here)
+    names = [n for n, _ in model.named_parameters()]
+    assert names == list(file['model_state_dict'].keys())
+    fstate = file['optimiser_state_dict']['state']
+    restored = 0
+    for i, (n, p) in enumerate(model.named_parameters()):
+        st = model.optimiser.state.get(p)
+        if i not in fstate:                    # (the last layer's coord_mlp never had a gradient: SURVEY Q3)
+            assert not st, n
+            continue
+        assert float(st['step']) == 12.0 and not st['step'].is_cuda, n
+        assert torch.equal(st['exp_avg'].cpu(), fstate[i]['exp_avg']), n
+        assert torch.equal(st['exp_avg_sq'].cpu(), fstate[i]['exp_avg_sq']), n
+        restored += 1
+    assert restored == len(fstate) and restored >= len(names) - 3
+
+    first = _loaders(z, meta)[0][0].to('cuda')
+    model.eval()
+    with torch.no_grad():
+        logits = model(first).reshape(-1).cpu().numpy()
+    ref_logits = z['resume/logits']
+    assert np.abs(logits - ref_logits).max() <= 1e-5 * max(1.0, np.abs(ref_logits).max()), (logits, ref_logits)
+    model.train()
+    assert float(model.optimiser.param_groups[0]['lr']) == float(z['resume/lr'])
+    y_pred, y_true, _, _ = model.unpack_input_data_and_predict(first)
+    loss = float(model.backprop(y_true, y_pred))
+    assert abs(loss - float(z['resume/loss'])) <= 1e-5 * abs(float(z['resume/loss'])), (loss, float(z['resume/loss']))
+    steps = sorted({int(st['step']) for st in model.optimiser.state.values() if st})
+    assert steps == z['resume/optimiser_steps'].tolist() == [13]
+    for k, v in model.state_dict().items():
+        got, ref = v.detach().cpu().numpy().astype(np.float64), z[f'sd13/{k}'].astype(np.float64)
+        before = file['model_state_dict'][k].numpy().astype(np.float64)
+        d, moved = np.abs(got - ref), np.abs(ref - before)
+        # one Adam step moves an entry by at most ~lr; the step itself must be the reference's to a few percent of its
+        # size (an entry whose moments are rounding noise can land anywhere within lr)
+        assert d.max() <= 2e-3 * 1.001, k
+        assert np.median(d) <= 2e-2 * float(np.median(moved)) + 1e-9, (k, float(np.median(d)), float(np.median(moved)))

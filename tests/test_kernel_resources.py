@@ -22,8 +22,8 @@ CASES = [
     # (one 8-byte lane constant parked in scratch in front of the chunk loop and reloaded behind it - nothing inside the
     # tile loop, checked in the ISA when the bound was set - and 4 scalar registers: see SGPR_SPILL_OK)
     ('edge_bwd_f16.hip', [], 'k_edge_bwd_f16ILi0ELb0E', 256, 0, 2),
-    ('edge_mfma_fwd.hip', FWD, 'k_edge_fwd_mfmaILi1ELi256ELb0ELb1ELi0E', 128, 0, 3),
-    ('edge_mfma_fwd.hip', FWD, 'k_edge_fwd_mfmaILi2ELi768ELb0ELb1ELi0E', 168, 0, 8),
+    ('edge_mfma_fwd.hip', FWD, 'k_edge_fwd_mfmaILi1ELi256ELb0ELb1ELi0ELb1E', 128, 0, 3),
+    ('edge_mfma_fwd.hip', FWD, 'k_edge_fwd_mfmaILi2ELi768ELb0ELb1ELi0ELb1E', 168, 0, 8),
     ('edge_bwd_h64.hip', [], 'k_edge_bwd_h64ILi0ELb1E', 256, 256, 0),
     ('edge_bwd_h64.hip', [], 'k_edge_bwd_h64ILi0ELb0E', 256, 256, 0),
 ]
