@@ -804,6 +804,10 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 
 }  // namespace
 
+#ifdef PVS_PAIR_PROBE
+#include "probe_pair_bwd.h"
+#endif
+
 #ifdef PVS_TILE_TRACE
 extern "C" int pvs_debug_tile_trace(unsigned long long* dst, size_t count) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pvs_trace_buf), count * sizeof(unsigned long long));
@@ -839,6 +843,18 @@ int pvs_launch_edge_bwd_f16(hipStream_t s, int H, const PvsGraph& g, const PvsEd
     if (lds < (size_t)L.total * 4) lds = (size_t)L.total * 4;
     const bool eres = (flags & PVS_EDGE_RESIDUAL) && io.m_prev != nullptr;
     const bool eatt = flags & PVS_EDGE_ATTENTION;
+#ifdef PVS_PAIR_PROBE       // timing-only: the channel-split wave-pair kernel in place of <0, false> (probe_pair_bwd.h)
+    if (!eres && !eatt) {
+        const int pblocks = 256 * PVS_PAIR_PROBE_OCC, ppairs = 2 * pblocks;
+        long long per = ((long long)(e_hi - e_lo) + (long long)ppairs * 2048 - 1) / ((long long)ppairs * 2048);
+        if (per < 1) per = 1;
+        *n_slabs = pblocks;
+        if (set_lds(pairprobe::k_edge_bwd_pair_probe, (size_t)pairprobe::kLds)) return -2;
+        pairprobe::k_edge_bwd_pair_probe<<<pblocks, 256, pairprobe::kLds, s>>>(g, w, flags, io, (int)(ppairs * per), e_lo, e_hi);
+        PVS_CHECK_LAUNCH();
+        return 0;
+    }
+#endif
 #define PVS_BWD_F16_LAUNCH(ER, EA)                                                                          \
     do {                                                                                                   \
         if (set_lds(k_edge_bwd_f16<ER, EA>, lds)) return -2;                                               \

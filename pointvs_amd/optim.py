@@ -55,8 +55,24 @@ class FusedClipAdam(torch.optim.Adam):
                 p.grad = None
 
     def load_state_dict(self, state_dict):
+        """torch's own, then the step counters where THIS optimiser keeps them: on the host for a non-capturable group
+        (a checkpoint read with `map_location=<device>` - as the reference's load_weights reads it,
+        point_neural_network_base.py:532 - brings them in as device tensors, torch keeps them there, and torch's Adam
+        then reads one counter per parameter back to the host every step; the fused step would refuse the state and fall
+        back to exactly that), on the device as fp32 for a capturable one."""
         self._fast = None              # new state tensors, other step counts
-        return super().load_state_dict(state_dict)
+        out = super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            capturable = bool(group.get('capturable'))
+            for p in group['params']:
+                st = self.state.get(p)
+                if not st or not torch.is_tensor(st.get('step')):
+                    continue
+                if capturable and (not st['step'].is_cuda or st['step'].dtype != torch.float32):
+                    st['step'] = st['step'].to(device=p.device, dtype=torch.float32)
+                elif not capturable and (st['step'].is_cuda or st['step'].dtype != torch.float32):
+                    st['step'] = st['step'].detach().to(device='cpu', dtype=torch.float32)
+        return out
 
     @torch.no_grad()
     def step(self, closure=None, clip_value=None):

@@ -214,6 +214,9 @@ def test_resuming_from_a_checkpoint_the_reference_wrote(name, legacy, tmp_path):
     assert abs(loss - float(z['resume/loss'])) <= 1e-5 * abs(float(z['resume/loss'])), (loss, float(z['resume/loss']))
     steps = sorted({int(st['step']) for st in model.optimiser.state.values() if st})
     assert steps == z['resume/optimiser_steps'].tolist() == [13]
+    # the resumed run takes the FUSED optimiser step (the file was read with map_location = the device, which brings
+    # the step counters in as device tensors: load_state_dict puts them back on the host, where this flavour counts)
+    assert model.optimiser._fast is not None and model.optimiser._fast['fusable']
     for k, v in model.state_dict().items():
         got, ref = v.detach().cpu().numpy().astype(np.float64), z[f'sd13/{k}'].astype(np.float64)
         before = file['model_state_dict'][k].numpy().astype(np.float64)

@@ -13,8 +13,13 @@ res = {n: [] for n, _ in libs}
 for r in range(rounds):
     for name, path in libs:
         e = dict(os.environ, PVS_EGNN_LIB=str(Path(path).resolve()))
-        out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--steps', '4', '--warmup', '2',
-                              '--no-cpu-baseline'] + os.environ.get('AB_ARGS', '').split(), env=e, capture_output=True, text=True)
+        try:
+            out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--steps', '4', '--warmup', '2',
+                                  '--no-cpu-baseline'] + os.environ.get('AB_ARGS', '').split(), env=e, capture_output=True,
+                                 text=True, timeout=float(os.environ.get('AB_TIMEOUT', '240')))
+        except subprocess.TimeoutExpired:
+            print(name, 'TIMED OUT')
+            continue
         line = [l for l in out.stdout.splitlines() if l.startswith('{')]
         if not line:
             print(name, 'FAILED', out.stderr[-400:])
