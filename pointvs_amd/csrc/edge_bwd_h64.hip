@@ -198,7 +198,11 @@ __device__ __forceinline__ void chain16(const unsigned short* __restrict__ img, 
 // split first and then issues the 48 MFMAs back to back with the vector ALU idle). Product order: every group of
 // four MFMAs needs only parts that are ready - (lo,0)hi (lo,1)hi (mid,0)hi (mid,0)mid (mid,1)hi (hi,0)hi (mid,1)mid
 // (hi,0)mid (hi,0)lo (hi,1)hi (hi,1)mid (hi,1)lo; fragment loads stay two groups ahead as in chain16.
-template <bool TRANSPOSE>
+// GLOBAL (timing-only probe, -DPVS_ABL_H64_WC1_GLOBAL, profiles/r06_ab_h64_lds_residency.txt): the weight's operand
+// fragments as PRE-ARRANGED 16-byte words in global memory - fragment (part, s, b) of lane l at word
+// ((part * 2 + s) * 4 + b) * 64 + l, one fully coalesced 1 KB load per fragment, what csrc/edge_bwd_wide.hip does for
+// coord_mlp.0 - instead of reads of the LDS image: what freeing that weight's 24.5 KB of LDS would cost.
+template <bool TRANSPOSE, bool GLOBAL = false>
 __device__ __forceinline__ void chain16s(const unsigned short* __restrict__ img, int lane, const float (&x)[16],
                                          Bf16Parts& pb, f32x4 (&acc)[4]) {
     const unsigned short* lo = img + 2 * kH * kH;
@@ -209,7 +213,15 @@ __device__ __forceinline__ void chain16s(const unsigned short* __restrict__ img,
     float r[16], t[16];
     auto ld = [&](const unsigned short* part, int s, bf16x8 (&f)[4]) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) f[b] = frag16<TRANSPOSE>(part, lane, b, s);
+        for (int b = 0; b < 4; ++b) {
+            if constexpr (GLOBAL) {
+                const int pi = (int)((part - img) / (kH * kH));
+                // (a wave-uniform base + the lane's 32-bit byte offset: one address register for all 24 fragments)
+                f[b] = __builtin_bit_cast(bf16x8, *pvs_off(reinterpret_cast<const uint4*>(img) + (((pi * 2 + (TRANSPOSE ? 1 : 0)) * 2 + s) * 4 + b) * 64, 16u * (unsigned)lane));
+            } else {
+                f[b] = frag16<TRANSPOSE>(part, lane, b, s);
+            }
+        }
     };
     auto res = [](float v) { return v - __uint_as_float(__float_as_uint(v) & 0xffff0000u); };
     auto part = [](const unsigned (&p)[8], int s) {
@@ -476,6 +488,15 @@ __device__ __forceinline__ void reduce_rows16(const float* __restrict__ T, const
         else { split_bf16x3(x, pb); chain16<T>(img, lane, pb, acc); }               \
     } while (0)
 #endif
+#ifdef PVS_ABL_H64_WC1_GLOBAL      // timing only (wrong numbers: the words read are node rows, not weight fragments)
+#define H64_CHAINS_WC1(T, img, lane, x, pb, acc)                                                                        \
+    do {                                                                                                                \
+        if constexpr (ERK == 0) chain16s<T, true>(reinterpret_cast<const unsigned short*>(io.PQ), lane, x, pb, acc);    \
+        else H64_CHAINS(T, img, lane, x, pb, acc);                                                                      \
+    } while (0)
+#else
+#define H64_CHAINS_WC1(T, img, lane, x, pb, acc) H64_CHAINS(T, img, lane, x, pb, acc)
+#endif
 
 // ERK: edge residual kind - 0 none; 1 the plain sum m + m_prev (nothing of the residual has to survive the tile's
 // coordinate branch); 2 rezero / gated (the gate's gradient needs the pre-residual message and m_prev at the end).
@@ -706,7 +727,7 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 #pragma unroll
                     for (int r = 0; r < 16; ++r) accc[r >> 2][r & 3] = bias2[r];
                 }
-                H64_CHAINS(false, Wc1i, lane, m, pb, accc);            // zc = Wc1 m + bc1
+                H64_CHAINS_WC1(false, Wc1i, lane, m, pb, accc);        // zc = Wc1 m + bc1
                 write_image16(MI, n, gr, pb);
                 float wc2y[16];
                 load_y(wc2t, gr, wc2y);
@@ -758,7 +779,7 @@ k_edge_bwd_h64(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
 #endif
                 }
                 load_y(io.gM + (size_t)i * H, gr, gMi);               // (in flight behind the two products below)
-                H64_CHAINS(true, Wc1i, lane, g_zc, pb, gm);            // g_m += Wc1^T g_zc
+                H64_CHAINS_WC1(true, Wc1i, lane, g_zc, pb, gm);        // g_m += Wc1^T g_zc
                 write_image16(GI, n, gr, pb);
                 pvs_wave_lds_sync();                                  // the m and g_zc images are complete
                 H64_WGRAD(GI, MI, lane, gWc1);                          // gWc1 += g_zc (x) m

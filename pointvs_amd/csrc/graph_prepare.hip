@@ -392,6 +392,67 @@ __device__ __forceinline__ CscChunk csc_chunk(int wid, int cpg, int stride, int 
     return c;
 }
 
+// One wave walks its chunk in position order, 64 positions per step, and hands every position its slot: the running
+// count of its column, which starts at tab[column]. Two lanes of one step with the same column (duplicate edges, two
+// rows in one step) take consecutive slots in LANE order - found by a byte table of "who wrote this column last" and
+// resolved group by group with ballots, so the order never depends on how the LDS serialises a conflict.
+// T: int32 (global slots) or unsigned short (slots inside a tile's LDS list).
+template <class T, class Sink>
+__device__ __forceinline__ void csc_walk_chunk(const int32_t* __restrict__ col, const CscChunk& c, int lane, T* tab,
+                                               unsigned char* tag, Sink&& sink) {
+    // kCscAhead steps' columns are fetched together (one wave walks its chunk alone: a dependent load per step would
+    // expose the whole memory latency 80 times per chunk)
+    for (int q0 = c.begin; q0 < c.end; q0 += 64 * kCscAhead) {
+        int keys[kCscAhead];
+#pragma unroll
+        for (int u = 0; u < kCscAhead; ++u)       // (unconditional loads of clamped positions: all in flight together)
+            keys[u] = col[min(q0 + 64 * u + lane, c.end - 1)];
+#pragma unroll
+        for (int u = 0; u < kCscAhead; ++u) {
+            // (a broken layout contract leaves columns outside the graph's range: clamped, so that every table access
+            // and every slot stays in bounds; the host raises on the status word)
+            const int k = min(max(keys[u] - c.node_lo, 0), c.width - 1);
+            keys[u] = q0 + 64 * u + lane < c.end ? k : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kCscAhead; ++u) {
+            const int p = q0 + 64 * u + lane;
+            const int key = keys[u];
+            const bool live = key >= 0;
+            if (q0 + 64 * u >= c.end) break;       // (wave-uniform)
+            // lanes of this step that share a column: leader = the lowest lane, rank = lanes of the group below me
+            int leader = lane, rank = 0, members = 1;
+            if (live) tag[key] = (unsigned char)lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bool lost = live && tag[key] != (unsigned char)lane;
+            unsigned long long pending = __ballot(lost);
+            while (pending) {
+                const int l0 = __builtin_ctzll(pending);
+                const int k0 = __builtin_amdgcn_readlane(key, l0);
+                const unsigned long long grp = __ballot(live && key == k0);
+                if (live && key == k0) {
+                    leader = __builtin_ctzll(grp);
+                    rank = __popcll(grp & ((1ull << lane) - 1ull));
+                    members = __popcll(grp);
+                }
+                pending &= ~grp;
+            }
+            int slot = 0;
+            if (live && rank == 0) {       // one lane per distinct column: no two lanes touch one counter
+                slot = (int)tab[key];
+                tab[key] = (T)(slot + members);
+            }
+            slot = __shfl(slot, leader, 64) + rank;
+            if (live) sink(slot, p);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
 template <bool PLACE>
 __global__ void __launch_bounds__(64 * kCscWaves)
 k_csc_pass(const int32_t* __restrict__ col, int n_graphs, int N, int E, const int32_t* __restrict__ node_ptr,
@@ -424,59 +485,22 @@ k_csc_pass(const int32_t* __restrict__ col, int n_graphs, int N, int E, const in
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (PLACE) {
+        csc_walk_chunk(col, c, lane, tab, tag, [&](int slot, int p) { cedge[min(max(slot, 0), E - 1)] = p; });   // (a slot outside [0, E) only under status bit 4)
+        return;
+    }
     // kCscAhead steps' columns are fetched together (one wave walks its chunk alone: a dependent load per step would
     // expose the whole memory latency 80 times per chunk)
     for (int q0 = c.begin; q0 < c.end; q0 += 64 * kCscAhead) {
         int keys[kCscAhead];
 #pragma unroll
-        for (int u = 0; u < kCscAhead; ++u)       // (unconditional loads of clamped positions: all in flight together)
+        for (int u = 0; u < kCscAhead; ++u)
             keys[u] = col[min(q0 + 64 * u + lane, c.end - 1)];
 #pragma unroll
         for (int u = 0; u < kCscAhead; ++u) {
-            // (a broken layout contract leaves columns outside the graph's range: clamped, so that every table access
-            // and every cedge slot stays in bounds; the host raises on the status word)
-            const int k = min(max(keys[u] - c.node_lo, 0), c.width - 1);
-            keys[u] = q0 + 64 * u + lane < c.end ? k : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < kCscAhead; ++u) {
-            const int p = q0 + 64 * u + lane;
-            const int key = keys[u];
-            const bool live = key >= 0;
             if (q0 + 64 * u >= c.end) break;       // (wave-uniform)
-            if (!PLACE) {
-                if (live) atomicAdd(&tab[key], 1);
-                continue;
-            }
-            // lanes of this step that share a column: leader = the lowest lane, rank = lanes of the group below me
-            int leader = lane, rank = 0, members = 1;
-            if (live) tag[key] = (unsigned char)lane;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const bool lost = live && tag[key] != (unsigned char)lane;
-            unsigned long long pending = __ballot(lost);
-            while (pending) {
-                const int l0 = __builtin_ctzll(pending);
-                const int k0 = __builtin_amdgcn_readlane(key, l0);
-                const unsigned long long grp = __ballot(live && key == k0);
-                if (live && key == k0) {
-                    leader = __builtin_ctzll(grp);
-                    rank = __popcll(grp & ((1ull << lane) - 1ull));
-                    members = __popcll(grp);
-                }
-                pending &= ~grp;
-            }
-            int slot = 0;
-            if (live && rank == 0) {       // one lane per distinct column: no two lanes touch one counter
-                slot = tab[key];
-                tab[key] = slot + members;
-            }
-            slot = __shfl(slot, leader, 64) + rank;
-            if (live) cedge[min(max(slot, 0), E - 1)] = p;       // (a slot outside [0, E) only under status bit 4)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int k = min(max(keys[u] - c.node_lo, 0), c.width - 1);
+            if (q0 + 64 * u + lane < c.end) atomicAdd(&tab[k], 1);
         }
     }
     if (!PLACE) {
@@ -484,6 +508,113 @@ k_csc_pass(const int32_t* __restrict__ col, int n_graphs, int N, int E, const in
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int i = lane; i < c.width; i += 64) mine[i] = tab[i];
+    }
+}
+
+// ---- pass 2 through LDS-sorted tiles (round 6) -------------------------------------------------------------------------
+// k_csc_pass<true> stores every position at its slot as it walks: 10 M scattered 4-byte stores at BASELINE size, each of
+// which leaves the L2 as a 64-byte write request of its own (650 MB of requests for 41 MB of data, 0.136 ms). Here a
+// workgroup of NW waves takes NW CONSECUTIVE chunks of one graph (a "tile": ~40 k positions at BASELINE size), the waves
+// walk their chunks exactly as before - same leader / rank resolution, so the same order inside a column - but place
+// into a tile-local list in LDS (16-bit offsets from the tile's first position), ordered by column and, inside a column,
+// by position. The list then leaves as one contiguous run per column (~19 entries = 76 bytes at BASELINE size) written
+// by 32-lane halves: 12x fewer write requests. Everything a wave needs comes from the slots k_csc_colptr left in `cnt`
+// (cnt[chunk][c] = the first cedge slot of column c's entries in that chunk): a column's entries of the tile go to
+// [cnt[first chunk][c], cnt[first chunk of the next tile][c]), the chunks' shares follow from the differences.
+// A tile longer than the LDS list (or than 16 bits) is placed the old way by the same workgroup.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
+k_csc_place_tiles(const int32_t* __restrict__ col, int n_graphs, int N, int E, const int32_t* __restrict__ node_ptr,
+                  const int32_t* __restrict__ edge_ptr, int cpg, int stride, const int32_t* __restrict__ cnt,
+                  const int32_t* __restrict__ colptr, int32_t* __restrict__ cedge, int32_t* __restrict__ status, int cap) {
+    extern __shared__ int32_t csc_lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, tid = threadIdx.x;
+    const int tpg = cpg / NW;                                  // tiles per graph
+    const int g = blockIdx.x / tpg, tl = blockIdx.x - g * tpg;
+    if (g >= n_graphs) return;
+    const int k0 = g * cpg + tl * NW;                          // the tile's first chunk
+    CscChunk c = csc_chunk(k0 + wv, cpg, stride, n_graphs, N, E, node_ptr, edge_ptr);
+    if (c.width > stride) {
+        if (lane == 0) atomicOr(status, 4);
+        c.width = stride;
+    }
+    if (c.width <= 0) return;                                  // (workgroup-uniform: the width is the graph's)
+    if (*status & 4) {                                         // broken contract: identity lists, as k_csc_pass
+        for (int p = c.begin + lane; p < c.end; p += 64) cedge[p] = p;
+        return;
+    }
+    const CscChunk first = csc_chunk(k0, cpg, stride, n_graphs, N, E, node_ptr, edge_ptr);
+    const CscChunk last = csc_chunk(k0 + NW - 1, cpg, stride, n_graphs, N, E, node_ptr, edge_ptr);
+    const int tile_begin = first.begin, tile_len = last.end - first.begin;
+    const int width = c.width;
+    if (tile_len > cap || tile_len > 65535) {
+        // the old way: a table of global slots per wave (the LDS block is large enough: 5 bytes per column and wave)
+        int32_t* tab = csc_lds + wv * (stride + stride / 4);
+        unsigned char* tag = reinterpret_cast<unsigned char*>(tab + stride);
+        const int32_t* mine = cnt + (size_t)(k0 + wv) * stride;
+        for (int i = lane; i < width; i += 64) tab[i] = mine[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        csc_walk_chunk(col, c, lane, tab, tag, [&](int slot, int p) { cedge[min(max(slot, 0), E - 1)] = p; });
+        return;
+    }
+    // LDS: lstart[stride + 64] | gbase[stride] | tab[NW][stride] (16 bit) | tag[NW][stride] (bytes) | list[cap] (16 bit)
+    int32_t* lstart = csc_lds;
+    int32_t* gbase = lstart + stride + 64;
+    unsigned short* tabs = reinterpret_cast<unsigned short*>(gbase + stride);
+    unsigned char* tags = reinterpret_cast<unsigned char*>(tabs + NW * stride);
+    unsigned short* list = reinterpret_cast<unsigned short*>(tags + NW * stride);
+    const bool last_tile = tl == tpg - 1;
+    for (int i = tid; i < width; i += 64 * NW) {
+        const int32_t* src = cnt + (size_t)k0 * stride + i;
+        const int s0 = src[0];
+        const int s_end = last_tile ? colptr[c.node_lo + i + 1] : src[(size_t)NW * stride];
+        gbase[i] = s0;
+        lstart[i] = s_end - s0;                                // the column's entries in this tile
+#pragma unroll
+        for (int k = 0; k < NW; ++k) tabs[k * stride + i] = (unsigned short)(src[(size_t)k * stride] - s0);   // ... in front of chunk k
+    }
+    __syncthreads();
+    // exclusive scan of lstart[0 .. width): PER consecutive columns per thread, wave scan, carry over the waves
+    {
+        __shared__ int32_t wave_tot[NW];
+        const int per = (width + 64 * NW - 1) / (64 * NW), a = tid * per;
+        int sum = 0;
+        for (int i = a; i < min(a + per, width); ++i) sum += lstart[i];
+        int inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) wave_tot[wv] = inc;
+        __syncthreads();
+        int run = inc - sum;
+        for (int k = 0; k < wv; ++k) run += wave_tot[k];
+        for (int i = a; i < min(a + per, width); ++i) {
+            const int v = lstart[i];
+            lstart[i] = run;
+            run += v;
+        }
+        if (tid == 64 * NW - 1) lstart[width] = run;          // (= tile_len with consistent tables)
+    }
+    __syncthreads();
+    for (int i = tid; i < width; i += 64 * NW) {
+        const int base = lstart[i];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) tabs[k * stride + i] = (unsigned short)(tabs[k * stride + i] + base);
+    }
+    __syncthreads();
+    csc_walk_chunk(col, c, lane, tabs + wv * stride, tags + wv * stride,
+                   [&](int slot, int p) { list[min(max(slot, 0), cap - 1)] = (unsigned short)(p - tile_begin); });
+    __syncthreads();
+    // one run per column, written by 32-lane halves
+    const int hw = tid >> 5, l32 = tid & 31;
+    for (int cc = hw; cc < width; cc += 2 * NW) {
+        const int a = lstart[cc], b = lstart[cc + 1], dst = gbase[cc];
+        for (int i = a + l32; i < b; i += 32)
+            cedge[min(max(dst + i - a, 0), E - 1)] = tile_begin + (int)list[min(i, cap - 1)];
     }
 }
 
@@ -691,8 +822,35 @@ extern "C" int pvs_graph_prepare_runs(const int64_t* edge_index, const int64_t* 
                                                                                          edge_ptr, cpg, stride, colptr, status);
         PVS_CHECK_LAUNCH();
         if (E > 0) {
-            k_csc_pass<true><<<blocks, 64 * kCscWaves, lds, stream>>>(col, n_graphs, N, E, node_ptr, edge_ptr, cpg, stride,
-                                                                       w.csc_cnt, cedge, status);
+            // placement through LDS-sorted tiles of NW consecutive chunks (round 6; PVS_CSC_TILES=0: the direct scatter)
+            const char* tiles_env = getenv("PVS_CSC_TILES");
+            const bool tiles_on = !(tiles_env && tiles_env[0] == '0');
+            const int budget = 160 * 1024 - 256;              // (the CU's LDS less the kernel's static words)
+            auto fixed_bytes = [&](int nw) { return (size_t)(stride + 64) * 4 + (size_t)stride * 4 + (size_t)nw * stride * 3; };
+            int nw = (cpg % 8 == 0 && fixed_bytes(8) + 2 * 32768 <= (size_t)budget) ? 8 : 4;
+            int cap = ((int)budget - (int)fixed_bytes(nw)) / 2;
+            if (cap > 65535) cap = 65535;
+            // worth it where a column's run in a tile is long enough to fill write requests: E / (N * tiles per graph)
+            // entries on average - 20 at cfg2 (r = 10 A: 0.385 -> 0.33 ms of preparation per step), 5 at cfg3 (r = 6 A),
+            // where the tables' set-up and the two extra barriers cost more than the shorter runs save (0.140 -> 0.156 ms:
+            // profiles/r06_ab_csc_lds_sorted_tiles.txt)
+            const bool forced = tiles_env && tiles_env[0] == '2';
+            const double avg_run = (double)E / ((double)(N > 0 ? N : 1) * (double)(cpg / nw));
+            if (tiles_on && (avg_run >= 10.0 || forced) && cap >= 8192 && (size_t)nw * (stride + stride / 4) * 4 <= (size_t)budget) {
+                const int tiles = n_graphs * (cpg / nw);
+                if (nw == 8) {
+                    PVS_CHECK_HIP(hipFuncSetAttribute((const void*)k_csc_place_tiles<8>, hipFuncAttributeMaxDynamicSharedMemorySize, budget));
+                    k_csc_place_tiles<8><<<tiles, 64 * 8, budget, stream>>>(col, n_graphs, N, E, node_ptr, edge_ptr, cpg, stride,
+                                                                           w.csc_cnt, colptr, cedge, status, cap);
+                } else {
+                    PVS_CHECK_HIP(hipFuncSetAttribute((const void*)k_csc_place_tiles<4>, hipFuncAttributeMaxDynamicSharedMemorySize, budget));
+                    k_csc_place_tiles<4><<<tiles, 64 * 4, budget, stream>>>(col, n_graphs, N, E, node_ptr, edge_ptr, cpg, stride,
+                                                                           w.csc_cnt, colptr, cedge, status, cap);
+                }
+            } else {
+                k_csc_pass<true><<<blocks, 64 * kCscWaves, lds, stream>>>(col, n_graphs, N, E, node_ptr, edge_ptr, cpg, stride,
+                                                                           w.csc_cnt, cedge, status);
+            }
             PVS_CHECK_LAUNCH();
         }
         return 0;

@@ -118,12 +118,14 @@ def test_forward_with_64_bit_offsets_equals_the_scalar_base_form(changes, monkey
             assert np.array_equal(np.asarray(x), np.asarray(y))
 
 
-def test_graph_preparation_of_more_graphs_than_a_grid_has_rows():
+@pytest.mark.parametrize('placement', ['2', '0'])
+def test_graph_preparation_of_more_graphs_than_a_grid_has_rows(placement, monkeypatch):
     """70,000 graphs in the reference loader's layout: the per-graph colptr kernel used one grid row (blockIdx.y) per
     graph and a launch cannot have more than 65,535. Same arrays as the general sort."""
     from pointvs_amd.graph import Batch, prepare_graph, runs_layout
     from pointvs_amd.synthetic import synthetic_graph
     from tests.test_gpu_baseline_parity import _replicate_on_device
+    monkeypatch.setenv('PVS_CSC_TILES', placement)
     items = [synthetic_graph(700 + k, n_nodes=6 + k % 5, n_lig=2, edge_radius=30.0) for k in range(70)]
     big = _replicate_on_device(Batch.from_data_list(items).to('cuda'), 1000)
     assert big.num_graphs == 70000

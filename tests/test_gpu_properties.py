@@ -959,13 +959,18 @@ def test_prepare_by_merging_sorted_runs_equals_the_sort():
     [(64, 8, 20.0)] * 70,                                           # many small complete graphs: chunks < one row
     [(4096, 30, 4.0), (100, 5, 5.0)],                               # the largest graph the counting path takes
     [(4500, 30, 4.0), (100, 5, 5.0)],                               # one node more than that: the radix sort
+    [(3000, 30, 14.0), (300, 10, 6.0)],                             # 1.4 M edges in one graph: tiles beyond the 16-bit LDS list
 ])
-def test_by_column_lists_by_counting_equal_the_sort(sizes):
+@pytest.mark.parametrize('placement', ['tiles', 'scatter'])
+def test_by_column_lists_by_counting_equal_the_sort(sizes, placement, monkeypatch):
     """Round 3: with a host bound on the graphs' sizes pvs_graph_prepare_runs builds colptr / cedge by a counting
     transpose per graph (graph_prepare.hip, k_csc_pass) instead of a radix sort of all edges by column. Same arrays
-    as the sort (stable: ascending sorted position inside a column, duplicate edges included), whatever the chunking."""
+    as the sort (stable: ascending sorted position inside a column, duplicate edges included), whatever the chunking.
+    Round 6: the placement pass through LDS-sorted tiles (k_csc_place_tiles; PVS_CSC_TILES=2 forces it where the
+    heuristic would not take it, 0 selects the direct scatter) - both array for array the sort's output."""
     from pointvs_amd.graph import Batch, prepare_graph, runs_layout
     from pointvs_amd.synthetic import synthetic_graph
+    monkeypatch.setenv('PVS_CSC_TILES', '2' if placement == 'tiles' else '0')
     items = [synthetic_graph(900 + k, n_nodes=n, n_lig=nl, edge_radius=r) for k, (n, nl, r) in enumerate(sizes)]
     batch = Batch.from_data_list(items).to('cuda')
     layout = runs_layout(batch)
