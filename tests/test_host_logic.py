@@ -549,3 +549,76 @@ def test_runs_layout_refuses_tables_that_do_not_match_the_edge_list():
     batch2 = Batch.from_data_list(items)
     batch2.x = batch2.x[:-1]                                 # node table no longer covers the nodes
     assert runs_layout(batch2) is None
+
+
+def test_layer_parameter_cache_is_validated_slot_by_slot_and_never_copied():
+    """the per-layer cache of the parameters' ctypes struct must (1) not travel with copy.deepcopy / pickle
+    (a struct of pointers cannot be pickled; EMA / SWA copies a model that has run), (2) notice a parameter replaced
+    INSIDE a leaf module, a replaced leaf module and a replaced container - none of which passes through the layer's
+    own __setattr__. The probes are plain dict look-ups, so all of this is host logic (the struct itself needs a GPU:
+    tests/test_gpu_host_contracts.py runs the same through the kernels)."""
+    import copy
+    import pickle
+    from pointvs_amd.egnn_satorras import EGNNLayer
+    layer = EGNNLayer(32, 32, 32, edges_in_d=3, edge_attention=True, node_attention=True, graphnorm=True,
+                      gated_residual=True, edge_residual=True)
+    params = layer._params()
+    probes = layer._slot_probes(params)
+    assert probes is not None and len(probes) == sum(p is not None for p in params) == 20
+
+    def still_valid(pr):
+        for mods, cont, seq, idx, leaf, name, p in pr:
+            if mods is None:
+                if leaf.get(name) is not p:
+                    return False
+            elif mods.get(cont) is not seq or seq._modules.get(idx) is not leaf or leaf._parameters.get(name) is not p:
+                return False
+        return True
+    assert still_valid(probes)
+    old = layer.node_mlp[0].weight
+    layer.node_mlp[0].weight = torch.nn.Parameter(old.detach().clone())          # nested parameter
+    assert not still_valid(probes)
+    probes = layer._slot_probes(layer._params())
+    layer.edge_mlp[2] = torch.nn.Linear(32, 32)                                   # leaf module
+    assert not still_valid(probes)
+    probes = layer._slot_probes(layer._params())
+    layer.coord_mlp = torch.nn.Sequential(*list(layer.coord_mlp))                 # container (same leaves)
+    assert not still_valid(probes)
+    probes = layer._slot_probes(layer._params())
+    layer.edge_gate_parameter = torch.nn.Parameter(torch.ones(1))                 # the layer's own parameter
+    assert not still_valid(probes)
+    # a weight that is not a registered parameter (parametrizations compute it on access): nothing to cache
+    torch.nn.utils.parametrizations.weight_norm(layer.node_mlp[3])
+    assert layer._slot_probes(layer._params()) is None
+
+    layer = EGNNLayer(32, 32, 32, edges_in_d=3)
+    layer.__dict__['_pcache'] = ('stands in for the ctypes struct', ctypes.c_void_p(1))
+    layer.__dict__['_att_src'] = lambda: torch.zeros(1)
+    twin = copy.deepcopy(layer)
+    assert '_pcache' not in twin.__dict__ and twin.att_val is None and '_pcache' in layer.__dict__
+    again = pickle.loads(pickle.dumps(layer))
+    assert '_pcache' not in again.__dict__ and [k for k, _ in again.named_parameters()] == [k for k, _ in layer.named_parameters()]
+
+
+def test_checkpoints_written_under_capture_hold_the_optimisers_own_form(tmp_path):
+    """while train_model(capture=True) runs, the replayer has every optimiser group flipped to capturable
+    with device step counters; a checkpoint written at an epoch end in between must carry the groups' OWN flags (and host
+    counters: tests/test_gpu_training_trajectory.py checks those on the device), like the reference's files."""
+    from pointvs_amd.egnn_satorras import SartorrasEGNN
+    from pointvs_amd.synthetic import CONFIGS
+    model = SartorrasEGNN(tmp_path, 2e-3, 1e-4, silent=True, **CONFIGS['cfg2']['model'])
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    model.optimiser.step()
+    plain = model._optimiser_state_for_checkpoint()
+    assert not any(g.get('capturable') for g in plain['param_groups'])
+    model._capturable_was = [g.get('capturable', False) for g in model.optimiser.param_groups]       # what _StepReplayer does
+    for g in model.optimiser.param_groups:
+        g['capturable'] = True
+    under = model._optimiser_state_for_checkpoint()
+    assert not any(g.get('capturable') for g in under['param_groups'])
+    assert all(g['capturable'] for g in model.optimiser.param_groups)             # the live optimiser is untouched
+    assert under['state'].keys() == plain['state'].keys()
+    model.save(tmp_path / 'ck.pt')
+    ck = torch.load(tmp_path / 'ck.pt', weights_only=False)
+    assert not any(g.get('capturable') for g in ck['optimiser_state_dict']['param_groups'])
