@@ -607,7 +607,7 @@ def secondary_configs(args, rank, world, dev):
 
 def training_bench(args, rank, world, dev):
     """One training (or --infer) configuration: returns the record on rank 0, None elsewhere."""
-    from pointvs_amd import _lib, graph as pgraph
+    from pointvs_amd import _lib, functional as PF, graph as pgraph
     from pointvs_amd.distributed import OverlappedGradAllReducer
     from pointvs_amd.egnn_satorras import SartorrasEGNN
     from pointvs_amd.synthetic import CONFIGS, synthetic_batch
@@ -678,7 +678,8 @@ def training_bench(args, rank, world, dev):
             pgraph.prefetch_graph(batch.edge_index, batch.edge_attr, n_nodes, layout=pgraph.runs_layout(batch))
         loss = model.get_loss(y_true, y_pred)
         model.optimiser.zero_grad()
-        loss.backward()
+        # (as the harness's backprop() calls it: loss.backward() with the root gradient 1 handed over instead of filled)
+        loss.backward(gradient=PF.unit_gradient(loss.device))
         if reducer is not None:
             reducer()
         if hasattr(model.optimiser, '_fusable'):      # pointvs_amd.optim.FusedClipAdam: clip + Adam in one launch

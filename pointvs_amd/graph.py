@@ -91,10 +91,17 @@ class PreparedGraph:
     def set_graph_ptr(self, node_ptr):
         """node_ptr: device int tensor [B + 1] of the batch's node offsets (PyG `ptr`). Records where each
         graph's edges start in the sorted list (PvsGraph.graph_eptr): the fp16-split edge backward ends its
-        tiles there. One small device gather, no host sync; optional (a batch of one graph needs none)."""
+        tiles there. One small device gather, no host sync; optional (a batch of one graph needs none; a batch
+        prepared from its 'generate_edges' layout has the table already: prepare_graph)."""
         if node_ptr is None or node_ptr.numel() <= 2 or self.c.graph_eptr:
             return
-        idx = node_ptr.to(device=self.t['rowptr'].device, dtype=torch.long)
+        idx = getattr(node_ptr, '_pvs_as_long', None)       # (cached on the tensor: a conversion launch per step otherwise)
+        if idx is None or idx.device != self.t['rowptr'].device:
+            idx = node_ptr.to(device=self.t['rowptr'].device, dtype=torch.long)
+            try:
+                node_ptr._pvs_as_long = idx
+            except AttributeError:
+                pass
         eptr = self.t['rowptr'].index_select(0, idx).contiguous()
         self.t['graph_eptr'] = eptr
         self.c.graph_eptr = _lib.ptr(eptr)

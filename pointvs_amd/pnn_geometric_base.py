@@ -42,7 +42,19 @@ class PNNGeometricBase(PointNeuralNetworkBase):
         if ptr is None:
             counts = torch.bincount(batch, minlength=n_graphs)
             ptr = torch.cat([counts.new_zeros(1), counts.cumsum(0)])
-        graph_ptr = ptr.to(device=feats.device, dtype=torch.int32).contiguous()
+        # (the node offsets as device int32: from the batch's cached layout tables where it has them, else converted
+        # ONCE per batch object - two conversions and a gather per step were three launches of ~4 us each)
+        layout = None if edges is None else runs_layout(graph, feats.device)
+        if layout is not None:
+            graph_ptr = layout[0]
+        else:
+            cached = graph.__dict__.get('_pvs_ptr32') if hasattr(graph, '__dict__') else None
+            if cached is not None and cached[0] is ptr and cached[1] == ptr._version and cached[2].device == feats.device:
+                graph_ptr = cached[2]
+            else:
+                graph_ptr = ptr.to(device=feats.device, dtype=torch.int32).contiguous()
+                if hasattr(graph, '__dict__'):
+                    graph.__dict__['_pvs_ptr32'] = (ptr, ptr._version, graph_ptr)
         pg = getattr(graph, 'prepared', None)     # built on the GPU (radius_graph.attach_radius_graph)
         dropping = self.training and float(getattr(self, 'dropout_p', 0.0) or 0.0) > 0.0
         if dropping:      # edge dropout ahead of the layer stack (egnn_satorras.py:320-323): a new edge list
@@ -54,7 +66,7 @@ class PNNGeometricBase(PointNeuralNetworkBase):
             edges, edge_attributes = self.edge_dropout(edges, edge_attributes)
             pg = prepared_for(edges, edge_attributes, n_nodes)
         elif pg is None:
-            pg = prepared_for(edges, edge_attributes, n_nodes, layout=runs_layout(graph, feats.device))
+            pg = prepared_for(edges, edge_attributes, n_nodes, layout=layout)     # (sets graph_eptr itself from a layout)
         pg.poll_status()
         pg.set_graph_ptr(graph_ptr)
         feats, _, _ = self.embed_prepared(pg, feats, coords, need_coords=False)

@@ -234,7 +234,10 @@ class PointNeuralNetworkBase(nn.Module):
         `log_interval` steps, so the GPU never waits for the host inside the loop)."""
         loss = self.get_loss(y_true, y_pred)
         self.optimiser.zero_grad()
-        loss.backward()
+        if loss.is_cuda and loss.dtype == torch.float32 and loss.dim() == 0:
+            loss.backward(gradient=PF.unit_gradient(loss.device))     # (= loss.backward() without the root fill)
+        else:
+            loss.backward()
         if self.grad_sync is not None:
             self.grad_sync()
         if isinstance(self.optimiser, FusedClipAdam):
