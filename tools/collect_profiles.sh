@@ -32,3 +32,5 @@ cp $src/real_shape_eager.json $dst/${tag}_real_shape_eager.json; cp $src/real_sh
 # the commit the counters were taken at (bench.py: roofline.limiter_commit; this script runs where .git is)
 for c in cfg2 cfg3; do f=$dst/${tag}_${c}_pmc_sq.txt; [ -f $f ] && ! grep -q '^commit:' $f && sed -i "1i commit: $(git rev-parse --short HEAD)" $f; done
 cp $src/tile_trace.txt $dst/${tag}_tile_trace_h32_backward.txt 2>/dev/null; cp $src/micro_glds_offset.txt $dst/${tag}_micro_glds_offset.txt 2>/dev/null
+cp $src/step_timeline_cfg2.txt $dst/${tag}_step_timeline_cfg2.txt 2>/dev/null; cp $src/step_timeline_cfg3.txt $dst/${tag}_step_timeline_cfg3.txt 2>/dev/null
+cp $src/launch_origins_cfg2.txt $dst/${tag}_launch_origins_cfg2.txt 2>/dev/null; cp $src/bench_cfg2_one_rank_rccl_ll.json $dst/${tag}_bench_cfg2_one_rank_rccl_ll.json 2>/dev/null

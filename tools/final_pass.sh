@@ -15,7 +15,9 @@ PVS_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 5 --warmup 2 2>/dev/nul
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg2 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/prof_cfg2.json 2> $out/prof_cfg2.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg3 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --config cfg3 > $out/prof_cfg3.json 2> $out/prof_cfg3.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg5 -- python3 bench.py --config cfg5 --steps 50 --warmup 5 --graph 0 --no-cpu-baseline > $out/prof_cfg5.json 2> $out/prof_cfg5.err
-# keep only the summaries (the traces are large)
+# one step's launches in order (round 6: kept for cfg2 and cfg3 too), then keep only the summaries (the traces are large)
+python3 tools/step_timeline.py $out/prof_cfg2 > $out/step_timeline_cfg2.txt 2>&1
+python3 tools/step_timeline.py $out/prof_cfg3 > $out/step_timeline_cfg3.txt 2>&1
 find $out -name '*kernel_trace.csv' -delete
 tools/measure_traffic.sh ${tag}_cfg2 > $out/traffic_cfg2.log 2>&1
 tools/measure_traffic.sh ${tag}_cfg5 --config cfg5 --steps 5 --graph 0 > $out/traffic_cfg5.log 2>&1
@@ -52,3 +54,7 @@ tools/micro/valu_issue_bench.bin sigmoid > $out/micro_sigmoid.txt 2>&1
 # the H = 32 backward phase by phase (needs the -DPVS_TILE_TRACE build: tools/variant_obj.sh trace edge_bwd_f16.hip "-DPVS_TILE_TRACE"), LDS-DMA addressing
 [ -f pointvs_amd/libpvs_egnn_trace.so ] && PVS_EGNN_LIB=pointvs_amd/libpvs_egnn_trace.so python3 tools/tile_trace.py 2>&1 | grep -v amdgpu.ids > $out/tile_trace.txt
 [ -x tools/micro/glds_offset_test.bin ] && tools/micro/glds_offset_test.bin > $out/micro_glds_offset.txt 2>&1
+
+# round 6 additions: which host operation launches the torch-side kernels of a step; the gloo two-rank line under an RCCL protocol flag (recorded only)
+python3 tools/launch_origins.py cfg2 2>&1 | grep -v "amdgpu.ids\|Warning\|_warn_once" > $out/launch_origins_cfg2.txt
+python3 bench.py --gpus 1 --force-dist --rccl-proto LL --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | line > $out/bench_cfg2_one_rank_rccl_ll.json
