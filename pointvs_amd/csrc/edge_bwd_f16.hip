@@ -831,7 +831,8 @@ int pvs_launch_edge_bwd_f16(hipStream_t s, int H, const PvsGraph& g, const PvsEd
         if (b < 1) b = 1;
         if (b > 256) b = 256;                      // one workgroup per CU (LDS)
         const long long waves = b * nw;
-        long long per_wave = ((long long)E + waves * 4096 - 1) / (waves * 4096);
+        const long long ce = pvs_chunk_edges(8192);     // (one chunk per wave at cfg2: edge_mfma_common.h)
+        long long per_wave = ((long long)E + waves * ce - 1) / (waves * ce);
         if (per_wave < 1) per_wave = 1;
         blocks = (int)b;
         n_chunks = (int)(waves * per_wave);

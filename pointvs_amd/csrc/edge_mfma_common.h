@@ -171,6 +171,9 @@ __device__ __forceinline__ int chunk_begin(const PvsGraph& g, int k, int n_chunk
     if (k <= 0) return e_lo;
     if (k >= n_chunks) return e_hi;
     const long long t = e_lo + (long long)k * (e_hi - e_lo) / n_chunks;
+#ifdef PVS_ABL_UNALIGNED_CHUNKS       // timing only (rows that straddle a boundary are summed wrongly): what perfectly equal chunks would give
+    return (int)t;
+#endif
     return max(e_lo, g.rowptr[g.row[t]]);
 }
 
@@ -845,6 +848,16 @@ inline int pvs_edges_per_wave() {
     return v;
 }
 
+// Edges per chunk above which a wave's share is cut into several chunks (PVS_CHUNK_EDGES overrides it: A/B only).
+// Chunk ends are row-aligned, so a wave's share is uneven by up to a row per chunk end (157 edges at cfg2) and the launch
+// waits for the largest share: FEWER, larger chunks per wave balance better (round 6, H = 32 backward at cfg2: two chunks
+// of 2.5 k edges per wave -> one of 5 k: -2.5 % per launch; perfectly equal shares - timing-only, -DPVS_ABL_UNALIGNED_CHUNKS
+// - would give -3.3 %: profiles/r06_ab_chunk_balance.txt).
+inline long long pvs_chunk_edges(long long dflt = 4096) {
+    static const long long v = [] { const char* e = getenv("PVS_CHUNK_EDGES"); return e ? atoll(e) : 0ll; }();
+    return v > 0 ? v : dflt;
+}
+
 void pick_grid(int E, int* blocks, int* n_chunks, int nw = kWaves, int max_blocks = 1024) {
     // fill the chip first: a wave gets >= pvs_edges_per_wave() edges where the range allows; chunks of <= ~4096 edges; every wave gets the same number of chunks
     const long long per = pvs_edges_per_wave();
@@ -852,7 +865,8 @@ void pick_grid(int E, int* blocks, int* n_chunks, int nw = kWaves, int max_block
     if (b < 1) b = 1;
     if (b > max_blocks) b = max_blocks;
     const long long waves = b * nw;
-    long long per_wave = ((long long)E + waves * 4096 - 1) / (waves * 4096);
+    const long long ce = pvs_chunk_edges();
+    long long per_wave = ((long long)E + waves * ce - 1) / (waves * ce);
     if (per_wave < 1) per_wave = 1;
     *blocks = (int)b;
     *n_chunks = (int)(waves * per_wave);
