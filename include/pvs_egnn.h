@@ -300,6 +300,37 @@ int pvs_egnn_layer_bwd(const PvsLayerDesc* desc, const PvsGraph* graph, const Pv
                        void* workspace, size_t workspace_bytes, pvs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The whole EGNNLayer stack of SartorrasEGNN.get_embeddings (egnn_satorras.py:325-328, `for layer in self.layers:
+ * feats, coords, edge_attributes, edge_messages = layer(...)`) as ONE call each way. The same launches as n_layers calls of
+ * pvs_egnn_layer_fwd / _bwd in a row (bit for bit the same results): what it removes is the host's share - one autograd
+ * node, one ctypes call and ~15 allocations per layer and direction - which is what bounds a training step at the
+ * reference's default shape (32 graphs of ~500 atoms, ~70 launches of a few microseconds: SURVEY.md §8f row 2).
+ * All layers share one hidden size; layers with PVS_EDGE_RESIDUAL are refused (their [E,H] messages travel from layer to
+ * layer: per-layer calls). Every layer's tensors sit in caller-owned buffers at the strides of PvsStackStrides (in
+ * floats, multiples of 4):
+ *   h_mid [n_layers-1][>= N*H], x_mid [n_layers-1][>= N*3]: outputs of layers 0 .. n_layers-2 (= inputs of 1 .. n_layers-1);
+ *   h_out [N,H], x_out [N,3]: outputs of the last layer; att [n_layers][>= max(E,1)] (NULL unless a layer has edge
+ *   attention), node_att [n_layers][>= N] (may be NULL), saved [n_layers][>= pvs_egnn_layer_saved_floats()].
+ * Backward: g_h_out [N,H]; g_x_out [N,3] or NULL; g_h0 [N,H]; g_x0 [N,3] or NULL to skip; grads [n_layers]
+ * (members NULL to skip, as in pvs_egnn_layer_bwd). Workspace: pvs_egnn_stack_workspace_bytes (the backward's holds the
+ * two ping-pong gradient rows between layers).
+ */
+typedef struct PvsStackStrides {
+    int64_t h_mid, x_mid, att, node_att, saved;
+} PvsStackStrides;
+size_t pvs_egnn_stack_workspace_bytes(const PvsLayerDesc* descs, int32_t n_layers, int32_t n_nodes, int32_t n_edges,
+                                      int32_t backward);
+int pvs_egnn_stack_fwd(const PvsLayerDesc* descs, const PvsLayerParams* params, int32_t n_layers,
+                       const PvsGraph* graph, const PvsStackStrides* strides, const float* h0, const float* x0,
+                       float* h_mid, float* x_mid, float* h_out, float* x_out, float* att, float* node_att,
+                       float* saved, void* workspace, size_t workspace_bytes, pvs_stream_t stream);
+int pvs_egnn_stack_bwd(const PvsLayerDesc* descs, const PvsLayerParams* params, int32_t n_layers,
+                       const PvsGraph* graph, const PvsStackStrides* strides, const float* h0, const float* x0,
+                       const float* h_mid, const float* x_mid, const float* att, const float* saved,
+                       const float* g_h_out, const float* g_x_out, float* g_h0, float* g_x0,
+                       const PvsLayerGrads* grads, void* workspace, size_t workspace_bytes, pvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The thin callers either side of the layer stack.
  * y = x W^T + b: PygLinearPass.forward (pnn_geometric_base.py:83-94) and each nn.Linear of the
  * feats_linear_layers head (egnn_satorras.py:304-316, egnn_multitask.py:141-146).

@@ -39,6 +39,10 @@ class PvsLayerGrads(C.Structure):
     _fields_ = [(name, C.c_void_p) for name in PARAM_FIELDS]
 
 
+class PvsStackStrides(C.Structure):
+    _fields_ = [(name, C.c_int64) for name in ('h_mid', 'x_mid', 'att', 'node_att', 'saved')]
+
+
 _PROTOTYPES = {
     'pvs_last_error': (C.c_char_p, []),
     'pvs_version': (C.c_int, []),
@@ -87,6 +91,12 @@ _PROTOTYPES = {
                                    [C.c_void_p, C.c_size_t, C.c_void_p]),
     'pvs_egnn_layer_bwd': (C.c_int, [C.POINTER(PvsLayerDesc), C.POINTER(PvsGraph),
                                      C.POINTER(PvsLayerParams)] + [C.c_void_p] * 11 +
+                           [C.POINTER(PvsLayerGrads), C.c_void_p, C.c_size_t, C.c_void_p]),
+    'pvs_egnn_stack_workspace_bytes': (C.c_size_t, [C.POINTER(PvsLayerDesc), C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'pvs_egnn_stack_fwd': (C.c_int, [C.POINTER(PvsLayerDesc), C.POINTER(PvsLayerParams), C.c_int32, C.POINTER(PvsGraph),
+                                     C.POINTER(PvsStackStrides)] + [C.c_void_p] * 9 + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    'pvs_egnn_stack_bwd': (C.c_int, [C.POINTER(PvsLayerDesc), C.POINTER(PvsLayerParams), C.c_int32, C.POINTER(PvsGraph),
+                                     C.POINTER(PvsStackStrides)] + [C.c_void_p] * 10 +
                            [C.POINTER(PvsLayerGrads), C.c_void_p, C.c_size_t, C.c_void_p]),
     'pvs_linear_fwd': (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p]),
     'pvs_linear_bwd_workspace_bytes': (C.c_size_t, [C.c_int32] * 3),

@@ -696,3 +696,117 @@ extern "C" int pvs_egnn_layer_bwd(const PvsLayerDesc* d, const PvsGraph* g, cons
     if (gn && gr.node_b1) PVS_TRY(pvs_copy_small(s, w.coefs + 3 * H, gr.node_b1, H));
     return 0;
 }
+
+// ---- the whole EGNNLayer stack as one call each way (include/pvs_egnn.h: pvs_egnn_stack_*) -------------------------------
+// SartorrasEGNN.get_embeddings loops `for layer in self.layers` (egnn_satorras.py:325-328); at the reference's default shape
+// (32 graphs of ~500 atoms, edge_radius 4 A) a training step is ~70 launches of a few microseconds and the HOST decides its
+// length: one autograd node and one C call per layer cost more than the layer's kernels. These two entry points sequence
+// the very same per-layer launches (pvs_egnn_layer_fwd / _bwd above, unchanged: results are bit for bit those of the
+// per-layer calls) over caller-owned buffers that hold every layer's tensors at fixed strides.
+namespace {
+
+int check_stack(const PvsLayerDesc* descs, const PvsLayerParams* params, int32_t n_layers, const PvsGraph* g,
+                const PvsStackStrides* st, const char* who) {
+    PVS_REQUIRE(descs && params && g && st, "%s: NULL descriptor / parameter / graph / stride table", who);
+    PVS_REQUIRE(n_layers >= 1 && n_layers <= 1024, "%s: n_layers %d out of range", who, n_layers);
+    const int H = descs[0].hidden;
+    for (int l = 0; l < n_layers; ++l) {
+        PVS_REQUIRE(descs[l].hidden == H, "%s: layer %d has hidden size %d, layer 0 has %d (one width per stack)", who, l,
+                    descs[l].hidden, H);
+        PVS_REQUIRE(!(descs[l].flags & PVS_EDGE_RESIDUAL),
+                    "%s: edge_residual layers hand [E,H] messages from layer to layer: use the per-layer calls", who);
+    }
+    const size_t N = (size_t)g->n_nodes, E = (size_t)(g->n_edges > 0 ? g->n_edges : 1);
+    PVS_REQUIRE(st->h_mid >= (int64_t)(N * H) && st->x_mid >= (int64_t)(3 * N) && st->att >= (int64_t)E &&
+                    st->node_att >= (int64_t)N &&
+                    st->saved >= (int64_t)pvs_egnn_layer_saved_floats(&descs[0], g->n_nodes, g->n_edges),
+                "%s: a stride is smaller than the tensor it separates", who);
+    PVS_REQUIRE(((st->h_mid | st->x_mid | st->att | st->node_att | st->saved) & 3) == 0,
+                "%s: strides must be multiples of 4 floats (16-byte rows)", who);
+    return 0;
+}
+
+struct StackBwdScratch {
+    float* gh[2];
+    float* gx[2];
+};
+
+size_t carve_stack_bwd(PvsArena& a, int N, int H, StackBwdScratch* s) {
+    StackBwdScratch t;
+    for (int k = 0; k < 2; ++k) {
+        t.gh[k] = a.take<float>((size_t)N * H);
+        t.gx[k] = a.take<float>(3 * (size_t)N);
+    }
+    if (s) *s = t;
+    return pvs_align_up(a.off, 256);
+}
+
+}  // namespace
+
+extern "C" size_t pvs_egnn_stack_workspace_bytes(const PvsLayerDesc* descs, int32_t n_layers, int32_t N, int32_t E,
+                                                 int32_t backward) {
+    if (!descs || n_layers < 1) return 0;
+    size_t layer = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const size_t b = pvs_egnn_layer_workspace_bytes(&descs[l], N, E, backward ? 1 : 0);
+        if (b > layer) layer = b;
+    }
+    if (!backward) return layer;
+    PvsArena a(nullptr, 0);
+    return carve_stack_bwd(a, N, descs[0].hidden, nullptr) + layer;
+}
+
+extern "C" int pvs_egnn_stack_fwd(const PvsLayerDesc* descs, const PvsLayerParams* params, int32_t n_layers,
+                                  const PvsGraph* g, const PvsStackStrides* st, const float* h0, const float* x0,
+                                  float* h_mid, float* x_mid, float* h_out, float* x_out, float* att, float* node_att,
+                                  float* saved, void* workspace, size_t workspace_bytes, pvs_stream_t stream) {
+    PVS_TRY(check_stack(descs, params, n_layers, g, st, "pvs_egnn_stack_fwd"));
+    PVS_REQUIRE(h0 && x0 && h_out && x_out && saved && (n_layers == 1 || (h_mid && x_mid)),
+                "pvs_egnn_stack_fwd: NULL tensor");
+    const float* h = h0;
+    const float* x = x0;
+    for (int l = 0; l < n_layers; ++l) {
+        const bool last = l == n_layers - 1;
+        float* ho = last ? h_out : h_mid + (size_t)l * st->h_mid;
+        float* xo = last ? x_out : x_mid + (size_t)l * st->x_mid;
+        PVS_REQUIRE(!(descs[l].flags & PVS_EDGE_ATTENTION) || att, "pvs_egnn_stack_fwd: att required (layer %d has edge attention)", l);
+        PVS_TRY(pvs_egnn_layer_fwd(&descs[l], g, &params[l], h, x, nullptr, ho, xo, nullptr,
+                                   att ? att + (size_t)l * st->att : nullptr,
+                                   ((descs[l].flags & PVS_NODE_ATTENTION) && node_att) ? node_att + (size_t)l * st->node_att : nullptr,
+                                   saved + (size_t)l * st->saved, workspace, workspace_bytes, stream));
+        h = ho;
+        x = xo;
+    }
+    return 0;
+}
+
+extern "C" int pvs_egnn_stack_bwd(const PvsLayerDesc* descs, const PvsLayerParams* params, int32_t n_layers,
+                                  const PvsGraph* g, const PvsStackStrides* st, const float* h0, const float* x0,
+                                  const float* h_mid, const float* x_mid, const float* att, const float* saved,
+                                  const float* g_h_out, const float* g_x_out, float* g_h0, float* g_x0,
+                                  const PvsLayerGrads* grads, void* workspace, size_t workspace_bytes,
+                                  pvs_stream_t stream) {
+    PVS_TRY(check_stack(descs, params, n_layers, g, st, "pvs_egnn_stack_bwd"));
+    PVS_REQUIRE(h0 && x0 && saved && g_h_out && g_h0 && grads && (n_layers == 1 || (h_mid && x_mid)),
+                "pvs_egnn_stack_bwd: NULL tensor");
+    PvsArena arena(workspace, workspace_bytes);
+    StackBwdScratch sc;
+    const size_t own = carve_stack_bwd(arena, g->n_nodes, descs[0].hidden, &sc);
+    PVS_REQUIRE(own <= workspace_bytes, "pvs_egnn_stack_bwd: workspace too small (%zu < %zu)", workspace_bytes, own);
+    void* layer_ws = (char*)workspace + own;
+    const size_t layer_ws_bytes = workspace_bytes - own;
+    const float* gh = g_h_out;
+    const float* gx = g_x_out;           // NULL: nothing reads the last layer's coordinates
+    for (int l = n_layers - 1; l >= 0; --l) {
+        const float* h = l ? h_mid + (size_t)(l - 1) * st->h_mid : h0;
+        const float* x = l ? x_mid + (size_t)(l - 1) * st->x_mid : x0;
+        float* gh_in = l ? sc.gh[l & 1] : g_h0;
+        float* gx_in = l ? sc.gx[l & 1] : g_x0;          // (layer 0: NULL when the caller's coordinates need no gradient)
+        PVS_TRY(pvs_egnn_layer_bwd(&descs[l], g, &params[l], h, x, nullptr, att ? att + (size_t)l * st->att : nullptr,
+                                   saved + (size_t)l * st->saved, gh, gx, nullptr, gh_in, gx_in, nullptr, &grads[l],
+                                   layer_ws, layer_ws_bytes, stream));
+        gh = gh_in;
+        gx = gx_in;
+    }
+    return 0;
+}

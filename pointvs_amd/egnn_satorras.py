@@ -578,6 +578,10 @@ class SartorrasEGNN(PNNGeometricBase):
             trace['h0'], trace['x0'] = feats, coords
         m_sorted = None
         egnn_layers = list(self.layers)[1:]
+        if not need_messages and egnn_layers:
+            plan = self._stack_plan(pg, egnn_layers, need_coords or trace is not None)
+            if plan is not None:
+                return self._embed_stack(pg, plan, egnn_layers, feats, coords, trace)
         for idx, layer in enumerate(egnn_layers):
             last = idx == len(egnn_layers) - 1
             need_m = (need_messages and last) or (self.edge_residual and not last)
@@ -587,6 +591,85 @@ class SartorrasEGNN(PNNGeometricBase):
             if trace is not None:
                 trace[f'h{idx + 1}'], trace[f'x{idx + 1}'] = feats, coords
         return feats, coords, m_sorted
+
+    # ---- the layer loop as one call each way (pvs_egnn_stack_fwd / _bwd) ----
+    # PVS_EGNN_STACK=0: always one autograd node and one C call per layer; =1: the one-call stack wherever it applies;
+    # unset: the stack wherever it applies, except in a multi-rank run on batches large enough that the device, not the
+    # host, sets the pace (there the per-layer nodes let the late layers' gradient bucket leave while the early layers'
+    # backward is still running: distributed.py).
+    _STACK_HOST_BOUND_EDGE_CHANNELS = 1 << 26
+
+    def _stack_plan(self, pg, egnn_layers, need_coords):
+        """The StackPlan for this call, or None where the per-layer path has to run: edge residual (messages travel
+        between layers), widths the kernels are not built for (padded / decomposed layers), parameters that are not plain
+        fp32 device tensors, layers of different width."""
+        mode = os.environ.get('PVS_EGNN_STACK', '')
+        if mode == '0' or os.environ.get('PVS_WIDE') == 'decomposed':
+            return None
+        hidden = egnn_layers[0].hidden_nf
+        for layer in egnn_layers:
+            if (not isinstance(layer, EGNNLayer) or layer.edge_residual or layer.hidden_nf != hidden
+                    or hidden not in (16, 32, 64) or layer.edges_in_d != egnn_layers[0].edges_in_d):
+                return None
+        if mode != '1' and pg.n_edges * hidden > self._STACK_HOST_BOUND_EDGE_CHANNELS \
+                and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            return None
+        last = egnn_layers[-1]
+        skip_coords = last.use_coords and not need_coords and not os.environ.get('PVS_EGNN_KEEP_DEAD_COORDS')
+        cached = self.__dict__.get('_stack_cache')
+        pstructs, param_tuples = [], []
+        for layer in egnn_layers:
+            params, pstruct = layer._params_cached()
+            if pstruct is None:
+                return None
+            pstructs.append(pstruct)
+            param_tuples.append(params)
+        if cached is not None and cached[0] == skip_coords and len(cached[1].pstructs) == len(pstructs) \
+                and all(a is b for a, b in zip(cached[1].pstructs, pstructs)):
+            return cached[1]
+        descs = [layer._desc() for layer in egnn_layers]
+        if skip_coords:
+            d = descs[-1]
+            descs[-1] = (d[0], d[1], d[2] & ~_lib.UPDATE_COORDS, d[3])
+        plan = PF.StackPlan(descs, param_tuples, pstructs)
+        plan.skip_coords = skip_coords
+        self.__dict__['_stack_cache'] = (skip_coords, plan)
+        return plan
+
+    def _embed_stack(self, pg, plan, egnn_layers, feats, coords, trace):
+        n, e, hid = pg.n_nodes, pg.n_edges, plan.hidden
+        h_out, x_out, h_mid, x_mid, att, natt = PF.egnn_stack(feats, coords, pg, plan)
+        nl = plan.n_layers
+
+        def h_of(k):       # output of layer k
+            return h_out if k == nl - 1 else h_mid[k, :n * hid].view(n, hid)
+
+        def x_of(k):
+            return x_out if k == nl - 1 else x_mid[k, :3 * n].view(n, 3)
+
+        for k, layer in enumerate(egnn_layers):
+            d = layer.__dict__
+            d['_att_src'] = None if not layer.edge_attention else (
+                lambda k=k: PF.rows_to_input_order(att[k, :e].detach().reshape(-1, 1), pg))
+            d['_natt_src'] = None if not layer.node_attention else (lambda k=k: natt[k, :n].detach().reshape(-1, 1))
+            if k == nl - 1 and plan.skip_coords:
+                def coords_on_demand(layer=layer, h=(feats if nl == 1 else h_of(nl - 2)).detach(),
+                                     x=(coords if nl == 1 else x_of(nl - 2)).detach()):
+                    with torch.no_grad():
+                        return layer.forward_prepared(pg, h, x, None, need_m=False)[1]
+                d['_coords_src'] = coords_on_demand
+            elif layer.use_coords:
+                d['_coords_src'] = lambda k=k: x_of(k).detach()
+            if trace is not None:
+                trace[f'h{k + 1}'], trace[f'x{k + 1}'] = h_of(k), x_of(k)
+        return h_out, x_out, None
+
+    def __getstate__(self):
+        state = super().__getstate__() if hasattr(super(), '__getstate__') else self.__dict__.copy()
+        state = dict(state)
+        state.pop('_stack_cache', None)      # (ctypes arrays of pointers: never pickled or deep-copied; rebuilt on use)
+        return state
 
     def get_embeddings(self, feats, edges, coords, edge_attributes, batch):
         """Reference signature (egnn_satorras.py:319-329): returns (feats, edge_messages) with

@@ -105,10 +105,8 @@ class _EGNNLayerFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         # absent outputs are None, not empty tensors (h.new_empty(0) cost 22 us apiece on the host: 0.4 ms per step of a
         # 6-layer model)
-        if att is not None:
-            ctx.mark_non_differentiable(att)
-        if node_att is not None:
-            ctx.mark_non_differentiable(node_att)
+        if att is not None or node_att is not None:       # (one call: a second call replaces the first one's list)
+            ctx.mark_non_differentiable(*[t for t in (att, node_att) if t is not None])
         return h_out, x_out, m_out, att, node_att
 
     @staticmethod
@@ -154,6 +152,172 @@ class _EGNNLayerFn(torch.autograd.Function):
 def egnn_layer(h, x, m_prev_sorted, pg, desc_tuple, need_m, params, pstruct=None):
     """Returns (h_out, x_out, m_sorted|None, att_sorted|None, node_att|None). pstruct: see _EGNNLayerFn.forward."""
     return _EGNNLayerFn.apply(h, x, m_prev_sorted, pg, desc_tuple, need_m, pstruct, *params)
+
+
+def _align(count, to=64):
+    return (int(count) + to - 1) // to * to
+
+
+class StackPlan:
+    """What the one-call layer stack (`pvs_egnn_stack_fwd/bwd`) needs about a model's EGNN layers, built once and kept
+    while the layers' parameter structs stay the same objects: the C arrays of descriptors and parameter structs, the flat
+    tuple of parameter tensors handed to autograd and, for each of them, (layer, slot of `_lib.PARAM_FIELDS`).
+    `pstructs` are the layers' own cached PvsLayerParams (EGNNLayer._params_cached): held here, so `is` against a layer's
+    current struct says whether any parameter has moved since."""
+
+    def __init__(self, desc_tuples, param_tuples, pstructs):
+        n = len(desc_tuples)
+        self.n_layers, self.hidden = n, desc_tuples[0][0]
+        self.desc_tuples, self.pstructs = tuple(desc_tuples), tuple(pstructs)
+        self.descs = (_lib.PvsLayerDesc * n)(*[_lib.PvsLayerDesc(*d) for d in desc_tuples])
+        self.params_c = (_lib.PvsLayerParams * n)(*pstructs)       # (copies of the structs: plain pointers)
+        self.any_eatt = any(d[2] & _lib.EDGE_ATTENTION for d in desc_tuples)
+        self.any_natt = any(d[2] & _lib.NODE_ATTENTION for d in desc_tuples)
+        self.index, flat = [], []
+        for layer, params in enumerate(param_tuples):
+            for slot, p in enumerate(params):
+                if p is not None:
+                    self.index.append((layer, slot))
+                    flat.append(p)
+        self.params = tuple(flat)
+        self._sizes, self._layouts = {}, {}
+
+    def grad_layout(self, last_coords_live):
+        """Where every parameter gradient of a backward sits in ONE flat buffer. Which gradients exist follows
+        _EGNNLayerFn.backward: a layer's coord_mlp only when its coordinates fed something (every layer but the last; the
+        last one when a gradient arrives for x_L), never the edge gate (no edge residual in a stack)."""
+        got = self._layouts.get(last_coords_live)
+        if got is None:
+            got = self._layouts[last_coords_live] = _GradLayout(self, last_coords_live)
+        return got
+
+    def sizes(self, n, e):
+        """(strides struct, forward workspace bytes, backward workspace bytes) for a graph of n nodes and e edges."""
+        got = self._sizes.get((n, e))
+        if got is None:
+            lib = _lib.lib()
+            saved = lib.pvs_egnn_layer_saved_floats(self.descs, n, e)
+            st = _lib.PvsStackStrides(_align(n * self.hidden), _align(3 * n), _align(max(e, 1)), _align(n), _align(saved))
+            got = (st, lib.pvs_egnn_stack_workspace_bytes(self.descs, self.n_layers, n, e, 0),
+                   lib.pvs_egnn_stack_workspace_bytes(self.descs, self.n_layers, n, e, 1))
+            if len(self._sizes) > 64:
+                self._sizes.clear()
+            self._sizes[(n, e)] = got
+        return got
+
+
+class _GradLayout:
+    """`sizes`: the split of the flat buffer (gradients and the pads that keep each one 16-byte aligned); `take`: per
+    parameter of `plan.params` (index into the split or -1 = no gradient, shape to view it as or None for 1-D);
+    `structs(base)`: the PvsLayerGrads array for a flat buffer at address `base` (kept per address: the caching allocator
+    alternates between a few)."""
+
+    def __init__(self, plan, last_coords_live):
+        fields, nl = _lib.PARAM_FIELDS, plan.n_layers
+        self.sizes, self.take, self._offsets, self._by_base = [], [], [], {}
+        off = 0
+        for (layer, slot), p in zip(plan.index, plan.params):
+            name = fields[slot]
+            on = True
+            if name in ('coord_w1', 'coord_b1', 'coord_w2'):
+                on = bool(plan.desc_tuples[layer][2] & _lib.UPDATE_COORDS) and (layer < nl - 1 or last_coords_live)
+            elif name == 'edge_gate':
+                on = False
+            if not on:
+                self.take.append((-1, None))
+                continue
+            k = p.numel()
+            self.take.append((len(self.sizes), None if p.dim() == 1 else tuple(p.shape)))
+            self.sizes.append(k)
+            self._offsets.append((layer, slot, 4 * off))
+            off += k
+            if k % 4:
+                self.sizes.append(4 - k % 4)
+                off += 4 - k % 4
+        self.total, self.n_layers, self.n_fields = off, nl, len(fields)
+
+    def structs(self, base):
+        got = self._by_base.get(base)
+        if got is None:
+            rows = [[None] * self.n_fields for _ in range(self.n_layers)]
+            for layer, slot, byte_off in self._offsets:
+                rows[layer][slot] = base + byte_off
+            got = (_lib.PvsLayerGrads * self.n_layers)(*[_lib.PvsLayerGrads(*r) for r in rows])
+            if len(self._by_base) > 32:
+                self._by_base.clear()
+            self._by_base[base] = got
+        return got
+
+
+class _EGNNStackFn(torch.autograd.Function):
+    """All EGNN layers of a model (the loop of SartorrasEGNN.get_embeddings, egnn_satorras.py:325-328) as ONE autograd
+    node over `pvs_egnn_stack_fwd/bwd`: the same launches as one `_EGNNLayerFn` per layer, bit for bit the same values
+    (tests/test_gpu_stack.py), a sixth of the host time for six layers. No edge residual (per-layer path)."""
+
+    @staticmethod
+    def forward(ctx, h0, x0, pg, plan, *params):
+        lib = _lib.lib()
+        h0, x0 = _f32c(h0), _f32c(x0)
+        _lib.require_hip(h0, x0)
+        n, e, hidden, nl = pg.n_nodes, pg.n_edges, plan.hidden, plan.n_layers
+        if h0.shape != (n, hidden) or x0.shape != (n, 3):
+            raise ValueError(f'h {tuple(h0.shape)} / coord {tuple(x0.shape)} do not match N={n}, H={hidden}')
+        if plan.desc_tuples[0][1] != pg.n_edge_attr:
+            raise ValueError(f'layers built with edges_in_d={plan.desc_tuples[0][1]} but edge_attr has '
+                             f'{pg.n_edge_attr} columns')
+        dev = h0.device
+        st, ws_bytes, _ = plan.sizes(n, e)
+        f32 = torch.float32
+        h_out, x_out = torch.empty_like(h0), torch.empty_like(x0)
+        h_mid = torch.empty((nl - 1, st.h_mid), dtype=f32, device=dev) if nl > 1 else None
+        x_mid = torch.empty((nl - 1, st.x_mid), dtype=f32, device=dev) if nl > 1 else None
+        att = torch.empty((nl, st.att), dtype=f32, device=dev) if plan.any_eatt else None
+        natt = torch.empty((nl, st.node_att), dtype=f32, device=dev) if plan.any_natt else None
+        saved = torch.empty((nl, st.saved), dtype=f32, device=dev)
+        ws = _ws(ws_bytes, dev)
+        rc = lib.pvs_egnn_stack_fwd(plan.descs, plan.params_c, nl, C.byref(pg.c), C.byref(st), _lib.ptr(h0), _lib.ptr(x0),
+                                    _lib.ptr(h_mid), _lib.ptr(x_mid), _lib.ptr(h_out), _lib.ptr(x_out), _lib.ptr(att),
+                                    _lib.ptr(natt), _lib.ptr(saved), _lib.ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, 'pvs_egnn_stack_fwd')
+        ctx.pg, ctx.plan = pg, plan
+        ctx.save_for_backward(h0, x0, h_mid, x_mid, att, saved, *params)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(*[t for t in (h_mid, x_mid, att, natt) if t is not None])
+        return h_out, x_out, h_mid, x_mid, att, natt
+
+    @staticmethod
+    def backward(ctx, g_h_out, g_x_out, *_unused):
+        lib = _lib.lib()
+        h0, x0, h_mid, x_mid, att, saved, *params = ctx.saved_tensors
+        pg, plan = ctx.pg, ctx.plan
+        n, e, nl = pg.n_nodes, pg.n_edges, plan.n_layers
+        dev = h0.device
+        g_h_out = torch.zeros_like(h0) if g_h_out is None else _f32c(g_h_out)
+        g_x_out = _f32c(g_x_out)        # None => nothing read the last layer's coordinates (SURVEY Q3)
+        g_h0 = torch.empty_like(h0)
+        g_x0 = torch.empty_like(x0) if ctx.needs_input_grad[1] else None
+        # ONE allocation for all parameter gradients, handed out as views (16-byte aligned): 78 allocations less per step
+        # of a 6-layer model, and the optimiser finds its pointer table again by one address instead of 78 that the
+        # caching allocator shuffles from step to step (FusedClipAdam._recent)
+        lay = plan.grad_layout(g_x_out is not None)
+        flat = torch.empty((lay.total,), dtype=torch.float32, device=dev)
+        parts = flat.split_with_sizes(lay.sizes)
+        grads = [None if k < 0 else (parts[k] if shape is None else parts[k].view(shape)) for k, shape in lay.take]
+        gstructs = lay.structs(flat.data_ptr())
+        st, _, ws_bytes = plan.sizes(n, e)
+        ws = _ws(ws_bytes, dev)
+        rc = lib.pvs_egnn_stack_bwd(plan.descs, plan.params_c, nl, C.byref(pg.c), C.byref(st), _lib.ptr(h0), _lib.ptr(x0),
+                                    _lib.ptr(h_mid), _lib.ptr(x_mid), _lib.ptr(att), _lib.ptr(saved), _lib.ptr(g_h_out),
+                                    _lib.ptr(g_x_out), _lib.ptr(g_h0), _lib.ptr(g_x0), gstructs, _lib.ptr(ws), ws_bytes,
+                                    _stream(dev))
+        _lib.check(rc, 'pvs_egnn_stack_bwd')
+        return (g_h0, g_x0, None, None, *grads)
+
+
+def egnn_stack(h0, x0, pg, plan):
+    """Returns (h_L, x_L, h_mid, x_mid, att, node_att): the last layer's outputs and the per-layer buffers (rows of
+    `plan.sizes(n, e)[0]` strides; None where no layer needs them) the side attributes are read from."""
+    return _EGNNStackFn.apply(h0, x0, pg, plan, *plan.params)
 
 
 class _LinearFn(torch.autograd.Function):

@@ -1,0 +1,185 @@
+"""The EGNN layer loop as ONE call each way (`pvs_egnn_stack_fwd / _bwd`, pointvs_amd/functional.py `_EGNNStackFn`) against
+one autograd node per layer (`PVS_EGNN_STACK=0`): the two sequence the very same launches, so logits, every gradient
+(and WHICH gradients are None), the per-layer side attributes and a few optimiser steps must agree BIT FOR BIT; and the
+stack against the fp64 oracle on its own. Reference loop: SartorrasEGNN.get_embeddings,
+/root/reference/point_vs/models/geometric/egnn_satorras.py:325-328."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from tests._golden import rel_err
+from tests.test_gpu_properties import BASE_KW, make_model, oracle_run, random_graph
+
+pytestmark = pytest.mark.gpu
+
+FLAG_SETS = {
+    'default3': dict(num_layers=3),
+    'one_layer': dict(num_layers=1),
+    'cfg3_like': dict(num_layers=4, k=64, edge_attention=True, node_attention=True, residual=True),
+    'test_kwargs': dict(num_layers=3, graphnorm=True, node_attention=True, edge_attention=True, softmax_attention=True,
+                        residual=True, normalize=True, tanh=True),
+    'rezero': dict(num_layers=3, residual=True, rezero=True, tanh=True),
+    'gated': dict(num_layers=2, residual=True, gated_residual=True, k=16),
+    'frozen_coords': dict(num_layers=3, update_coords=False, residual=True),
+    'perm_inv': dict(num_layers=2, permutation_invariance=True, normalize=True),
+}
+
+
+def _run(model, g, monkeypatch, stack, steps=1, dead_coords=False):
+    """`steps` training steps; returns logits of every step, the gradients of the LAST step, the side attributes."""
+    monkeypatch.setenv('PVS_EGNN_STACK', '1' if stack else '0')
+    if dead_coords:
+        monkeypatch.setenv('PVS_EGNN_KEEP_DEAD_COORDS', '1')
+    else:
+        monkeypatch.delenv('PVS_EGNN_KEEP_DEAD_COORDS', raising=False)
+    model.train()
+    logits = []
+    for _ in range(steps):
+        model.optimiser.zero_grad()
+        y = model(g).reshape(-1)
+        loss = model.get_loss(torch.ones_like(y), y)
+        loss.backward()
+        logits.append(y.detach().clone())
+        if steps > 1:
+            model.optimiser.step(clip_value=1.0)
+    grads = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in model.named_parameters()}
+    side = []
+    for layer in list(model.layers)[1:]:
+        side.append((layer.att_val, layer.node_att_val, layer.intermediate_coords))
+    return logits, grads, side
+
+
+def _same(a, b, what):
+    if a is None or b is None:
+        assert a is None and b is None, what
+    elif isinstance(a, np.ndarray):
+        assert a.shape == b.shape and np.array_equal(a, b), what
+    else:
+        assert torch.equal(a, b), what
+
+
+@pytest.mark.parametrize('dead_coords', [False, True])
+@pytest.mark.parametrize('name', sorted(FLAG_SETS))
+def test_stack_equals_the_per_layer_calls_bit_for_bit(name, dead_coords, monkeypatch):
+    model, _ = make_model(seed=5, **FLAG_SETS[name])
+    twin = copy.deepcopy(model)
+    g = random_graph(900, 26000, seed=3, n_graphs=3).to('cuda')
+    la, ga, sa = _run(model, g, monkeypatch, stack=False, dead_coords=dead_coords)
+    assert model.__dict__.get('_stack_cache') is None
+    lb, gb, sb = _run(twin, g, monkeypatch, stack=True, dead_coords=dead_coords)
+    assert twin.__dict__.get('_stack_cache') is not None, 'the one-call stack did not run'
+    _same(la[0], lb[0], 'logits')
+    # the stack's parameter gradients are views of ONE buffer, and autograd kept them as they came (no copies)
+    stores = {p.grad.untyped_storage().data_ptr() for n, p in twin.named_parameters()
+              if p.grad is not None and n.startswith('layers.') and not n.startswith('layers.0.')}
+    assert len(stores) == 1, stores
+    assert ga.keys() == gb.keys()
+    for pname in ga:
+        _same(ga[pname], gb[pname], f'grad {pname}')
+    # the last layer's coord_mlp never receives a gradient - on both paths
+    last = len(list(model.layers)) - 1
+    assert all(v is None for k, v in gb.items() if k.startswith(f'layers.{last}.coord_mlp'))
+    for k, (x, y) in enumerate(zip(sa, sb)):
+        for i, what in enumerate(('att_val', 'node_att_val', 'intermediate_coords')):
+            _same(x[i], y[i], f'layer {k + 1} {what}')
+
+
+def test_stack_training_steps_equal_the_per_layer_ones(monkeypatch):
+    """Four optimiser steps each way from the same initial state: the same logits at every step, bit for bit (the plan's
+    C arrays hold parameter ADDRESSES: an optimiser that updates in place must leave them valid)."""
+    model, _ = make_model(seed=9, num_layers=3, edge_attention=True, residual=True)
+    twin = copy.deepcopy(model)
+    g = random_graph(600, 15000, seed=8, n_graphs=4).to('cuda')
+    la, _, _ = _run(model, g, monkeypatch, stack=False, steps=4)
+    lb, _, _ = _run(twin, g, monkeypatch, stack=True, steps=4)
+    for a, b in zip(la, lb):
+        assert torch.equal(a, b)
+    assert not torch.equal(la[0], la[-1])
+
+
+def test_stack_follows_moved_and_replaced_parameters(monkeypatch):
+    """The cached plan is dropped when a layer's parameter struct is rebuilt: `.to()` round trips, a replaced nested
+    parameter, `load_state_dict(assign=True)`."""
+    monkeypatch.setenv('PVS_EGNN_STACK', '1')
+    model, _ = make_model(seed=2, num_layers=2)
+    g = random_graph(300, 5000, seed=4).to('cuda')
+    model.train()
+
+    def logits():
+        model.zero_grad()
+        y = model(g).reshape(-1)
+        model.get_loss(torch.ones_like(y), y).backward()
+        return y.detach().clone()
+
+    y0 = logits()
+    plan0 = model.__dict__['_stack_cache'][1]
+    assert torch.equal(logits(), y0) and model.__dict__['_stack_cache'][1] is plan0      # kept while nothing moves
+    lin = model.layers[2].edge_mlp[2]
+    lin.weight = torch.nn.Parameter(lin.weight.detach().clone() * 2.0)
+    y1 = logits()
+    assert not torch.equal(y1, y0) and model.__dict__['_stack_cache'][1] is not plan0
+    assert lin.weight.grad is not None and float(lin.weight.grad.abs().max()) > 0
+    other, _ = make_model(seed=2, num_layers=2)
+    model.load_state_dict({k: v.detach().clone() for k, v in other.state_dict().items()}, assign=True)
+    assert torch.equal(logits(), y0)
+    model.cpu().cuda()
+    assert torch.equal(logits(), y0)
+    clone = copy.deepcopy(model)
+    assert clone.__dict__.get('_stack_cache') is None
+
+
+@pytest.mark.parametrize('name', ['default3', 'cfg3_like', 'test_kwargs'])
+def test_stack_matches_the_fp64_oracle(name, monkeypatch):
+    """The stack against the oracle by itself (not only against the per-layer path)."""
+    monkeypatch.setenv('PVS_EGNN_STACK', '1')
+    changes = FLAG_SETS[name]
+    model, kw = make_model(seed=1, **changes)
+    g = random_graph(500, 12000, seed=6)
+    gg = copy.copy(g)
+    gg.__dict__ = dict(g.__dict__)
+    gg = gg.to('cuda')
+    model.zero_grad()
+    y = model(gg).reshape(-1)
+    model.get_loss(torch.ones_like(y), y).backward()
+    assert model.__dict__.get('_stack_cache') is not None
+    y_ref, _, g_ref = oracle_run(model, kw, g, dtype=torch.float64)
+    assert rel_err(y.detach().cpu().numpy(), y_ref.numpy()) < 1e-5
+    for pname, p in model.named_parameters():
+        if p.grad is None:
+            assert g_ref[pname] is None, pname
+        else:
+            assert rel_err(p.grad.cpu().numpy(), g_ref[pname].numpy()) < 1e-5, pname
+
+
+def test_stack_is_refused_where_messages_travel_between_layers(monkeypatch):
+    """edge_residual layers (and callers that want the edge messages) keep the per-layer path; the C entry point
+    itself refuses such a layer."""
+    import ctypes as C
+    from pointvs_amd import _lib
+    monkeypatch.setenv('PVS_EGNN_STACK', '1')
+    model, _ = make_model(seed=2, num_layers=2, edge_residual=True, residual=True)
+    g = random_graph(300, 5000, seed=4).to('cuda')
+    model(g)
+    assert model.__dict__.get('_stack_cache') is None
+    descs = (_lib.PvsLayerDesc * 1)(_lib.PvsLayerDesc(32, 3, _lib.EDGE_RESIDUAL | _lib.UPDATE_COORDS, 0))
+    params = (_lib.PvsLayerParams * 1)()
+    graph = _lib.PvsGraph()
+    graph.n_nodes, graph.n_edges = 8, 8
+    st = _lib.PvsStackStrides(256, 64, 64, 64, 2048)
+    rc = _lib.lib().pvs_egnn_stack_fwd(descs, params, 1, C.byref(graph), C.byref(st), *([None] * 9), None, 0, None)
+    assert rc != 0 and b'edge_residual' in _lib.lib().pvs_last_error()
+
+
+def test_stack_runs_under_no_grad_and_in_eval(monkeypatch):
+    model, _ = make_model(seed=4, num_layers=3, edge_attention=True)
+    g = random_graph(400, 9000, seed=2, n_graphs=2).to('cuda')
+    model.eval()
+    with torch.no_grad():
+        monkeypatch.setenv('PVS_EGNN_STACK', '0')
+        a = model(g).clone()
+        monkeypatch.setenv('PVS_EGNN_STACK', '1')
+        b = model(g).clone()
+    assert torch.equal(a, b)
+    assert BASE_KW['k'] == 32
