@@ -821,6 +821,9 @@ def training_bench(args, rank, world, dev):
                        'scaling_note': scaling_note(args, world, strong),
                        'last_layer_coord_update': 'skipped (dead)' if args.skip_dead_coords else 'evaluated',
                        'launch': 'hipGraph replay of the whole step' if use_graph else 'eager',
+                       'layer_calls': ('one call each way for the whole layer stack (pvs_egnn_stack_fwd / _bwd)'
+                                       if model.__dict__.get('_stack_cache') is not None else
+                                       'one call each way per layer (pvs_egnn_layer_fwd / _bwd)'),
                        'inputs': (f'host ({args.host_inputs}) batch copied to the device inside every step'
                                   if args.host_inputs else 'resident in HBM'),
                        'graph_prepare': ('radius graph built on the GPU from the coordinates' if args.build_graph else

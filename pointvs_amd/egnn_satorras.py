@@ -594,9 +594,11 @@ class SartorrasEGNN(PNNGeometricBase):
 
     # ---- the layer loop as one call each way (pvs_egnn_stack_fwd / _bwd) ----
     # PVS_EGNN_STACK=0: always one autograd node and one C call per layer; =1: the one-call stack wherever it applies;
-    # unset: the stack wherever it applies, except in a multi-rank run on batches large enough that the device, not the
-    # host, sets the pace (there the per-layer nodes let the late layers' gradient bucket leave while the early layers'
-    # backward is still running: distributed.py).
+    # unset: the stack where the HOST sets the pace - batches of up to 2^26 edge-channels (E x hidden; the reference's
+    # default shape has 6 x 10^6, a BASELINE batch 3 x 10^8). Above that the device is several times slower than the host
+    # either way (profiles/r06_ab_layer_stack.txt: cfg2 / cfg3 within 0.5 % of each other) and the per-layer nodes stay:
+    # they let a multi-rank run send the late layers' gradient bucket while the early layers' backward is still running
+    # (distributed.py), and they free each layer's saved tensors as the backward passes it.
     _STACK_HOST_BOUND_EDGE_CHANNELS = 1 << 26
 
     def _stack_plan(self, pg, egnn_layers, need_coords):
@@ -611,9 +613,7 @@ class SartorrasEGNN(PNNGeometricBase):
             if (not isinstance(layer, EGNNLayer) or layer.edge_residual or layer.hidden_nf != hidden
                     or hidden not in (16, 32, 64) or layer.edges_in_d != egnn_layers[0].edges_in_d):
                 return None
-        if mode != '1' and pg.n_edges * hidden > self._STACK_HOST_BOUND_EDGE_CHANNELS \
-                and torch.distributed.is_available() and torch.distributed.is_initialized() \
-                and torch.distributed.get_world_size() > 1:
+        if mode != '1' and pg.n_edges * hidden > self._STACK_HOST_BOUND_EDGE_CHANNELS:
             return None
         last = egnn_layers[-1]
         skip_coords = last.use_coords and not need_coords and not os.environ.get('PVS_EGNN_KEEP_DEAD_COORDS')

@@ -183,3 +183,20 @@ def test_stack_runs_under_no_grad_and_in_eval(monkeypatch):
         b = model(g).clone()
     assert torch.equal(a, b)
     assert BASE_KW['k'] == 32
+
+
+@pytest.mark.parametrize('hidden', [32, 64])
+@pytest.mark.parametrize('kind', ['none', 'sum', 'rezero', 'gated'])
+def test_every_backward_instantiation_is_reproducible_and_close_to_the_exact_family(hidden, kind):
+    """Round 6, fuzz seed 116: the H = 32 backward for GATED edge residual without attention (then the run-time kind 4 with
+    lazy scales and pair arithmetic) returned g_h / g_x / edge_mlp gradients 1e-3 ... 1e-1 off that changed from run to run
+    - the golden cases of that flag set run a few tiles only, the fuzz seeds of the suite never drew it on a large graph.
+    Every instantiation (edge-residual kind x attention off / sigmoid / softmax, both widths) on a multi-tile graph with
+    random upstream gradients for h, x AND the messages: two runs must agree bit for bit, and the split-product kernels
+    must stay within 1e-5 (measured: 1.3e-6) of the exact-fp32-MFMA family per tensor, relative to the tensor's largest
+    entry. Reference: the edge-residual block and attention gate of EGNNLayer.forward, egnn_satorras.py:137-146,194-202."""
+    from tools.backward_instantiations_probe import probe
+    for att in (None, 'sigmoid', 'softmax'):
+        rep, ex = probe(hidden, kind, att)
+        assert rep[0] == 0.0, (hidden, kind, att, 'run to run', rep)
+        assert ex[0] < 1e-5, (hidden, kind, att, 'against the exact family', ex)

@@ -42,6 +42,9 @@ FAMILIES = {
     'h32_att': dict(edge_attention=True, node_attention=True, residual=True),     # <0,true>
     'h32_edgeres': dict(edge_residual=True, tanh=True),                    # <1,false>
     'h32_edgeres_att': dict(edge_residual=True, edge_attention=True),
+    'h32_edgeres_rezero': dict(edge_residual=True, residual=True, rezero=True),         # <2,false>
+    'h32_edgeres_gated': dict(edge_residual=True, residual=True, gated_residual=True),  # the gated kind without attention
+    'h32_edgeres_gated_att': dict(edge_residual=True, residual=True, gated_residual=True, edge_attention=True),   # <3,true>
     'h32_softmax_gn': dict(edge_attention=True, softmax_attention=True, graphnorm=True, node_attention=True,
                            residual=True),
     'h64': dict(k=64),                                                     # k_edge_bwd_h64<0,false>
