@@ -2,7 +2,7 @@
 softmax, H = 32 and 64) on a multi-tile graph with random upstream gradients: run twice (bitwise reproducibility) and against
 the exact-fp32-MFMA family (PVS_EGNN_BF16X3=0) of the same library. Prints the worst per-tensor distance of each; the GPU
 test tests/test_gpu_stack.py::test_every_backward_instantiation_is_reproducible_and_close_to_the_exact_family holds the same
-numbers to bounds.   usage (GPU box): python tools/backward_instantiations_probe.py [hidden sizes, default 32 64]"""
+numbers to bounds.   usage (GPU box): python tools/backward_instantiations_probe.py [--big] [hidden sizes, default 32 64]"""
 import os
 import sys
 from pathlib import Path
@@ -69,9 +69,13 @@ def probe(hidden, kind, att, n=1814, e_draw=45376, n_graphs=4, seed=116):
 
 
 if __name__ == '__main__':
-    for hidden in [int(v) for v in sys.argv[1:]] or [32, 64]:
+    # --big: one graph of 20,000 nodes and 3,000,000 edges - every wave of a full grid walks ~45 tiles (the default graph
+    # gives a wave two)
+    big = '--big' in sys.argv
+    shape = dict(n=20000, e_draw=3000000, n_graphs=1) if big else {}
+    for hidden in [int(v) for v in sys.argv[1:] if v != '--big'] or [32, 64]:
         for kind in ('none', 'sum', 'rezero', 'gated'):
             for att in (None, 'sigmoid', 'softmax'):
-                rep, ex = probe(hidden, kind, att)
+                rep, ex = probe(hidden, kind, att, **shape)
                 print(f'H={hidden} residual kind {kind:7s} attention {str(att):8s} run-to-run {rep[0]:8.1e} {rep[1]:24s} '
                       f'vs exact family {ex[0]:8.1e} {ex[1]}', flush=True)
