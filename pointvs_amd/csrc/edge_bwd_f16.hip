@@ -868,7 +868,7 @@ int pvs_launch_edge_bwd_f16(hipStream_t s, int H, const PvsGraph& g, const PvsEd
     else if (eres && rezero) PVS_BWD_F16_LAUNCH(2, false);
     else if (eres && gated && eatt) PVS_BWD_F16_LAUNCH(3, true);
     // Gated residual without attention runs the COMPILE-TIME kind 3 since round 6. Until then it ran kind 4 (the kind read
-    // from the flags at run time: 18 spilled VGPRs against 23, -9 % per launch) - and kind 4 with BOTH the lazy scales and
+    // from the flags at run time: 11 spilled VGPRs against 13) - and kind 4 with BOTH the lazy scales and
     // the pair arithmetic compiled in gave g_z2-derived outputs (g_h, g_x, the edge_mlp gradients) that were 1e-3 ... 1e-1 off
     // and changed from run to run, while g_m_prev and the coordinate branch stayed right; either feature off, or kind 3,
     // and it is bit-reproducible and within 1e-6 of the exact family (profiles/r06_gated_residual_backward_defect.txt:
