@@ -1,0 +1,84 @@
+"""A wider fuzz than the suite's kernel-family one (tests/test_gpu_properties.py): random layer flags, WIDTHS 16 ... 128
+(incl. the zero-padded 24 / 48 / 96 and the fused 128), 1-4 layers, plain and multitask models, 1-5 graphs, edge lists with
+isolated nodes and E not a multiple of the tile - every seed runs the default kernels TWICE (logits and every gradient must
+agree bit for bit) and is held to the fp64 ORACLE (max|gpu - ref| <= 1e-5 max(1, max|ref|) per tensor, the suite's bound),
+with None-gradients in the same places. Round 6: 24 new seeds of the narrower fuzz found a defect no test had reached
+(profiles/r06_gated_residual_backward_defect.txt); this tool is the next net.
+usage (GPU box): python tools/fuzz_oracle.py [first_seed] [n_seeds]"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from tests import test_gpu_properties as t  # noqa: E402
+from tests._golden import rel_err  # noqa: E402
+
+TOL = 1e-5
+
+
+def draw(seed):
+    rng = np.random.default_rng(777000 + seed)
+    flags = dict(
+        k=int(rng.choice([16, 24, 32, 32, 48, 64, 64, 96, 128])), num_layers=int(rng.integers(1, 5)),
+        residual=bool(rng.integers(2)), edge_residual=bool(rng.integers(2)),
+        edge_attention=bool(rng.integers(2)), node_attention=bool(rng.integers(2)),
+        normalize=bool(rng.integers(2)), tanh=bool(rng.integers(2)), graphnorm=bool(rng.integers(3) == 0),
+        update_coords=bool(rng.integers(4) > 0), permutation_invariance=bool(rng.integers(4) == 0),
+        attention_activation_fn=str(rng.choice(['sigmoid', 'tanh', 'relu', 'silu'])))
+    if flags['edge_attention'] and rng.integers(3) == 0:
+        flags['softmax_attention'] = True
+    variant = int(rng.integers(3))
+    if variant == 1:
+        flags['gated_residual'] = True
+    elif variant == 2:
+        flags['rezero'] = True
+    if rng.integers(4) == 0:
+        flags['multi_fc'] = True
+    n = int(rng.integers(40, 3000))
+    e = int(rng.integers(1, 60)) * n + int(rng.integers(0, 31))
+    if flags['k'] > 64:
+        e = min(e, 40000)         # (the CPU oracle at 128 channels)
+    return flags, n, min(e, 120000), int(rng.integers(1, 6))
+
+
+def run_seed(seed):
+    flags, n, e, n_graphs = draw(seed)
+    model, kw = t.make_model(seed=seed, **flags)
+    g = t.random_graph(n, e, seed=seed, n_graphs=n_graphs)
+    y1, g1 = t.gpu_run(model, g)
+    y2, g2 = t.gpu_run(model, g)
+    problems = []
+    if not np.array_equal(y1, y2):
+        problems.append('logits differ between two runs')
+    for name in g1:
+        a, b = g1[name], g2[name]
+        if (a is None) != (b is None) or (a is not None and not np.array_equal(a, b)):
+            problems.append(f'{name} differs between two runs')
+    y_ref, _, g_ref = t.oracle_run(model, kw, g, dtype=torch.float64)
+    worst = (rel_err(y1, y_ref.numpy()), 'logits')
+    for name, ref in g_ref.items():
+        if (ref is None) != (g1[name] is None):
+            problems.append(f'{name}: None on one side only')
+        elif ref is not None:
+            worst = max(worst, (rel_err(g1[name], ref.numpy()), name))
+    if worst[0] >= TOL:
+        problems.append(f'against the fp64 oracle: {worst[0]:.2e} at {worst[1]}')
+    return flags, n, e, n_graphs, worst, problems
+
+
+if __name__ == '__main__':
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    bad, t0, worst_all = 0, time.time(), (0.0, '', -1)
+    for seed in range(first, first + count):
+        flags, n, e, n_graphs, worst, problems = run_seed(seed)
+        worst_all = max(worst_all, (worst[0], worst[1], seed))
+        if problems:
+            bad += 1
+            print('FAIL', seed, problems[:4], flags, 'n', n, 'e', e, 'graphs', n_graphs, flush=True)
+    print(f'done: {count} seeds from {first}, failures: {bad}, worst distance to the oracle {worst_all[0]:.2e} '
+          f'({worst_all[1]}, seed {worst_all[2]}), {time.time() - t0:.0f} s')
