@@ -585,8 +585,10 @@ def secondary_configs(args, rank, world, dev):
     import copy
     import gc
     sec = {}
+    # (round 6: also the reference's own default shape - NOT a BASELINE configuration, the launch-bound regime - eager)
     for name, changes in (('cfg3', dict(config='cfg3', steps=10, warmup=3, batch=32, graph=0)),
-                          ('cfg5', dict(config='cfg5', sweep=12800, warmup=1, batch=128, graph=1))):
+                          ('cfg5', dict(config='cfg5', sweep=12800, warmup=1, batch=128, graph=1)),
+                          ('real4A', dict(config='real4A', steps=200, warmup=30, batch=32, graph=0))):
         gc.collect()
         torch.cuda.empty_cache()
         a = copy.copy(args)
@@ -599,6 +601,7 @@ def secondary_configs(args, rank, world, dev):
         roof = rec['roofline']
         sec[name] = {'metric': rec['metric'], 'value': rec['value'], 'unit': rec['unit'], 'steps': rec['steps'],
                      'warmup': rec['warmup'], 'ms_per_step': rec['ms_per_step'], 'workload': rec['config']['workload'],
+                     'layer_calls': rec['config'].get('layer_calls'),
                      'roofline': {k: roof.get(k) for k in ('kernel', 'bound', 'frac', 'achieved', 'avg_launch_ms',
                                                            'avg_launch_ms_full_work', 'frac_full_work', 'launches',
                                                            'algorithmic_bytes_per_launch', 'kernel_ms_per_step')}}

@@ -1,9 +1,11 @@
 """A wider fuzz than the suite's kernel-family one (tests/test_gpu_properties.py): random layer flags, WIDTHS 16 ... 128
 (incl. the zero-padded 24 / 48 / 96 and the fused 128), 1-4 layers, plain and multitask models, 1-5 graphs, edge lists with
 isolated nodes and E not a multiple of the tile - every seed runs the default kernels TWICE (logits and every gradient must
-agree bit for bit) and is held to the fp64 ORACLE (max|gpu - ref| <= 1e-5 max(1, max|ref|) per tensor, the suite's bound),
-with None-gradients in the same places. Round 6: 24 new seeds of the narrower fuzz found a defect no test had reached
-(profiles/r06_gated_residual_backward_defect.txt); this tool is the next net.
+agree bit for bit) and is held to the fp64 ORACLE (max|gpu - ref| <= 1e-5 max(1, max|ref|) per tensor; a tensor beyond that
+must still meet the suite's strict bound, which knows the fp32 oracle's own noise), with None-gradients in the same places.
+Round 6: 24 new seeds of the narrower fuzz found a defect no test had reached (profiles/r06_gated_residual_backward_defect.txt);
+this tool is the next net (650 seeds at its introduction: no failure; three flagged by a first, cruder criterion were two deep
+stacks inside the strict bound and one overflowing model whose NaN logits do not compare equal to themselves).
 usage (GPU box): python tools/fuzz_oracle.py [first_seed] [n_seeds]"""
 import sys
 import time
@@ -45,40 +47,66 @@ def draw(seed):
     return flags, n, min(e, 120000), int(rng.integers(1, 6))
 
 
+def _same_bits(a, b):
+    return (a is None and b is None) or (a is not None and b is not None and a.shape == b.shape
+                                         and np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes())
+
+
 def run_seed(seed):
+    """Returns (flags, n, e, graphs, (worst distance to the oracle, tensor), problems, degenerate). A seed whose fp64
+    reference is not finite or beyond 1e30 (four residual-free layers without tanh can overflow) is reported as degenerate
+    and only held to reproducibility. A tensor farther than 1e-5 max(1, max|ref|) from the fp64 oracle is a problem only
+    if it also breaks the suite's STRICT bound (tests/_golden.py: 1e-5 of the tensor's own magnitude + 4x the fp32
+    ORACLE's own distance from the fp64 value): deep stacks amplify fp32 rounding in every implementation."""
     flags, n, e, n_graphs = draw(seed)
     model, kw = t.make_model(seed=seed, **flags)
     g = t.random_graph(n, e, seed=seed, n_graphs=n_graphs)
     y1, g1 = t.gpu_run(model, g)
     y2, g2 = t.gpu_run(model, g)
     problems = []
-    if not np.array_equal(y1, y2):
+    if not _same_bits(y1, y2):
         problems.append('logits differ between two runs')
     for name in g1:
-        a, b = g1[name], g2[name]
-        if (a is None) != (b is None) or (a is not None and not np.array_equal(a, b)):
+        if not _same_bits(g1[name], g2[name]):
             problems.append(f'{name} differs between two runs')
     y_ref, _, g_ref = t.oracle_run(model, kw, g, dtype=torch.float64)
+    refs = [y_ref.numpy()] + [v.numpy() for v in g_ref.values() if v is not None]
+    if not all(np.all(np.isfinite(r)) and float(np.abs(r).max(initial=0.0)) < 1e30 for r in refs):
+        return flags, n, e, n_graphs, (0.0, 'degenerate'), problems, True
+    g32 = None
     worst = (rel_err(y1, y_ref.numpy()), 'logits')
+    far = [] if worst[0] < TOL else ['logits']
     for name, ref in g_ref.items():
         if (ref is None) != (g1[name] is None):
             problems.append(f'{name}: None on one side only')
         elif ref is not None:
-            worst = max(worst, (rel_err(g1[name], ref.numpy()), name))
-    if worst[0] >= TOL:
-        problems.append(f'against the fp64 oracle: {worst[0]:.2e} at {worst[1]}')
-    return flags, n, e, n_graphs, worst, problems
+            d = rel_err(g1[name], ref.numpy())
+            worst = max(worst, (d, name))
+            if not d < TOL:
+                far.append(name)
+    if far:
+        from tests._golden import grad_floor, strict_margin
+        y32, _, g32 = t.oracle_run(model, kw, g, dtype=torch.float32)
+        floor = grad_floor({k: (None if v is None else v.numpy()) for k, v in g_ref.items()})
+        for name in far:
+            got, r64, r32 = ((y1, y_ref, y32) if name == 'logits' else (g1[name], g_ref[name], g32[name]))
+            err, bound = strict_margin(got, r64.numpy(), r32.numpy(), floor)
+            if not err <= bound:
+                problems.append(f'{name}: {rel_err(got, r64.numpy()):.2e} from the fp64 oracle and outside the strict bound '
+                                f'({err:.2e} > {bound:.2e})')
+    return flags, n, e, n_graphs, worst, problems, False
 
 
 if __name__ == '__main__':
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-    bad, t0, worst_all = 0, time.time(), (0.0, '', -1)
+    bad, degenerate, t0, worst_all = 0, 0, time.time(), (0.0, '', -1)
     for seed in range(first, first + count):
-        flags, n, e, n_graphs, worst, problems = run_seed(seed)
+        flags, n, e, n_graphs, worst, problems, deg = run_seed(seed)
+        degenerate += deg
         worst_all = max(worst_all, (worst[0], worst[1], seed))
         if problems:
             bad += 1
             print('FAIL', seed, problems[:4], flags, 'n', n, 'e', e, 'graphs', n_graphs, flush=True)
-    print(f'done: {count} seeds from {first}, failures: {bad}, worst distance to the oracle {worst_all[0]:.2e} '
+    print(f'done: {count} seeds from {first}, failures: {bad}, degenerate (non-finite reference) {degenerate}, worst distance to the oracle {worst_all[0]:.2e} '
           f'({worst_all[1]}, seed {worst_all[2]}), {time.time() - t0:.0f} s')
