@@ -200,3 +200,34 @@ def test_every_backward_instantiation_is_reproducible_and_close_to_the_exact_fam
         rep, ex = probe(hidden, kind, att)
         assert rep[0] == 0.0, (hidden, kind, att, 'run to run', rep)
         assert ex[0] < 1e-5, (hidden, kind, att, 'against the exact family', ex)
+
+
+@pytest.mark.parametrize('placement', ['edge_first_node_final', 'edge_final_only', 'node_first_only'])
+@pytest.mark.parametrize('task', ['classification', 'regression'])
+def test_stack_with_layers_of_different_flags_multitask(placement, task, monkeypatch, tmp_path):
+    """MultitaskSatorrasEGNN places the attention gates per layer (`*_first_only` / `*_final_only`,
+    egnn_multitask.py:14-42): one stack then holds layers WITH and WITHOUT an attention gate (the per-layer `att` /
+    `node_att` rows exist for all of them, only the gated layers' are written and read), and the head is the task's. Same
+    bits as the per-layer calls, both tasks."""
+    from pointvs_amd.egnn_multitask import MultitaskSatorrasEGNN
+    extra = {'edge_first_node_final': dict(edge_attention=True, edge_attention_first_only=True, node_attention=True,
+                                           node_attention_final_only=True),
+             'edge_final_only': dict(edge_attention=True, edge_attention_final_only=True),
+             'node_first_only': dict(node_attention=True, node_attention_first_only=True)}[placement]
+    kw = dict(BASE_KW, num_layers=3, residual=True, model_task=task, **extra)
+    torch.manual_seed(11)
+    model = MultitaskSatorrasEGNN(tmp_path / 'm', 2e-3, 1e-4, silent=True, **kw).cuda()
+    twin = copy.deepcopy(model)
+    flags = [(layer.edge_attention, layer.node_attention) for layer in list(model.layers)[1:]]
+    assert len(set(flags)) > 1, flags
+    g = random_graph(700, 16000, seed=13, n_graphs=3).to('cuda')
+    la, ga, sa = _run(model, g, monkeypatch, stack=False)
+    lb, gb, sb = _run(twin, g, monkeypatch, stack=True)
+    assert twin.__dict__.get('_stack_cache') is not None
+    _same(la[0], lb[0], 'logits')
+    for pname in ga:
+        _same(ga[pname], gb[pname], f'grad {pname}')
+    for k, (x, y) in enumerate(zip(sa, sb)):
+        for i, what in enumerate(('att_val', 'node_att_val', 'intermediate_coords')):
+            _same(x[i], y[i], f'layer {k + 1} {what}')
+        assert (x[0] is not None) == flags[k][0] and (x[1] is not None) == flags[k][1]
