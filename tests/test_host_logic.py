@@ -622,3 +622,51 @@ def test_checkpoints_written_under_capture_hold_the_optimisers_own_form(tmp_path
     model.save(tmp_path / 'ck.pt')
     ck = torch.load(tmp_path / 'ck.pt', weights_only=False)
     assert not any(g.get('capturable') for g in ck['optimiser_state_dict']['param_groups'])
+
+
+def test_stack_plan_lays_the_gradients_of_all_layers_out_in_one_buffer():
+    """functional.StackPlan / _GradLayout (the one-call layer stack, pvs_egnn_stack_bwd): every live parameter gradient gets a
+    16-byte aligned range of ONE buffer in the order of `plan.params`; which gradients exist follows the per-layer path -
+    a layer's coord_mlp only when its coordinates fed something (every layer but the last, and the last one only when a
+    gradient arrives for its coordinates), the edge gate never (no edge residual in a stack). Pure host logic."""
+    import copy
+    from pointvs_amd import _lib
+    from pointvs_amd import functional as PF
+    from pointvs_amd.egnn_satorras import EGNNLayer
+    from pointvs_amd.optim import FusedClipAdam
+    torch.manual_seed(0)
+    layers = [EGNNLayer(32, 32, 32, edges_in_d=3, edge_attention=True, node_attention=(k == 1), residual=True, rezero=True)
+              for k in range(3)]
+    descs = [l._desc() for l in layers]
+    params = [l._params() for l in layers]
+    plan = PF.StackPlan(descs, params, [_lib.PvsLayerParams() for _ in layers])
+    assert plan.n_layers == 3 and plan.hidden == 32 and plan.any_eatt and plan.any_natt
+    assert len(plan.params) == sum(p is not None for ps in params for p in ps) == len(plan.index)
+    fields = _lib.PARAM_FIELDS
+    for live_last in (False, True):
+        lay = plan.grad_layout(live_last)
+        assert lay is plan.grad_layout(live_last)
+        taken, cursor = [], 0
+        sizes = list(lay.sizes)
+        for (layer, slot), p, (k, shape) in zip(plan.index, plan.params, lay.take):
+            name = fields[slot]
+            dead = (name.startswith('coord_') and layer == 2 and not live_last) or name == 'edge_gate'
+            assert (k < 0) == dead, (layer, name, k)
+            if k >= 0:
+                assert sizes[k] == p.numel() and (shape is None) == (p.dim() == 1) and (shape is None or shape == tuple(p.shape))
+                taken.append(k)
+        assert taken == sorted(taken)
+        # every gradient starts at a multiple of 4 floats; the pads are the entries nobody takes
+        for k, size in enumerate(sizes):
+            if k in taken:
+                assert cursor % 4 == 0, (k, cursor)
+            cursor += size
+        assert cursor == lay.total
+        structs = lay.structs(4096)
+        assert structs is lay.structs(4096) and len(structs) == 3
+        assert structs[0].edge_w1 == 4096 and structs[2].edge_gate is None
+        assert (structs[2].coord_w1 is None) == (not live_last)
+    # an optimiser copy (EMA / snapshot of a whole model) starts with its own empty upload ring and no work list
+    opt = FusedClipAdam([torch.nn.Parameter(torch.zeros(3))], lr=1e-3)
+    twin = copy.deepcopy(opt)
+    assert twin._ring == [] and twin._fast is None and twin._recent == {}
