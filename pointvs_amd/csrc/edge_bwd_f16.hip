@@ -876,7 +876,11 @@ int pvs_launch_edge_bwd_f16(hipStream_t s, int H, const PvsGraph& g, const PvsEd
     // instantiation was not found (no asm-related hazard in its ISA, spills outside the tile loop); the kind-4 code path is
     // no longer instantiated. tools/backward_instantiations_probe.py and the GPU test of the same name run all 24
     // instantiations of the H = 32 / 64 backward twice on a multi-tile graph.
+#ifdef PVS_GATED_KIND4          // (A/B only: the defective run-time kind, for whoever looks for the cause; never shipped)
+    else if (eres && gated) PVS_BWD_F16_LAUNCH(4, false);
+#else
     else if (eres && gated) PVS_BWD_F16_LAUNCH(3, false);
+#endif
     else if (eres && eatt) PVS_BWD_F16_LAUNCH(1, true);
     else if (eres) PVS_BWD_F16_LAUNCH(1, false);
     else if (eatt) PVS_BWD_F16_LAUNCH(0, true);
