@@ -1,4 +1,4 @@
-"""Every instantiation of the edge backward (edge-residual kind none / sum / rezero / gated x edge attention off / sigmoid /
+"""Every instantiation of the edge forward and backward (edge-residual kind none / sum / rezero / gated x edge attention off / sigmoid /
 softmax, H = 32 and 64) on a multi-tile graph with random upstream gradients: run twice (bitwise reproducibility) and against
 the exact-fp32-MFMA family (PVS_EGNN_BF16X3=0) of the same library. Prints the worst per-tensor distance of each; the GPU
 test tests/test_gpu_stack.py::test_every_backward_instantiation_is_reproducible_and_close_to_the_exact_family holds the same
@@ -50,7 +50,7 @@ def probe(hidden, kind, att, n=1814, e_draw=45376, n_graphs=4, seed=116):
             layer.zero_grad()
             ho, xo, mo = layer.forward_prepared(pg, hh, xx, mm if kind != 'none' else None, need_m=True)
             (ho * gh).sum().add((xo * gx).sum()).add((mo * gm).sum()).backward()
-            out = {'g_h': hh.grad, 'g_x': xx.grad}
+            out = {'h_out': ho, 'x_out': xo, 'm_out': mo, 'g_h': hh.grad, 'g_x': xx.grad}
             if kind != 'none':
                 out['g_m_prev'] = mm.grad
             out.update({'g_' + k: p.grad for k, p in layer.named_parameters() if p.grad is not None})
