@@ -718,16 +718,48 @@ def training_bench(args, rank, world, dev):
         dom_group = 'edge_fwd' if args.infer else 'edge_bwd'
         lib.pvs_profile_reset()
         lib.pvs_profile_enable(0 if use_graph else 1 << (prof_ids[dom_group] + 1))
+        # (as train_model does, point_neural_network_base.long_lived_heap_frozen: Python's first full collection walks the
+        # ~170,000 objects `import torch` leaves behind - 60-170 ms, once, wherever the allocation count puts it: in a
+        # 0.1 s timed region that is luck, not throughput. PVS_GC_FREEZE=0 leaves the collector alone.)
+        import gc
+        freeze = os.environ.get('PVS_GC_FREEZE') != '0'
+        if freeze:
+            gc.collect()
+            gc.freeze()
         torch.cuda.synchronize(dev)
         if distributed:
             dist.barrier()
+        gc_log, step_host = [], []
+        tracing = bool(os.environ.get('PVS_BENCH_TRACE_STEPS'))      # (diagnostic: host time of every timed step and every
+        if tracing:                                                  # collector pause of a millisecond or more, to stderr)
+            gc.callbacks.append(lambda phase, info: gc_log.append((phase, info.get('generation'), time.perf_counter())))
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            loss = step()
+            if tracing:
+                ts = time.perf_counter()
+                loss = step()
+                step_host.append((time.perf_counter() - ts) * 1e3)
+            else:
+                loss = step()
+        t_host = time.perf_counter()
         torch.cuda.synchronize(dev)
         if distributed:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        if tracing:
+            gc.callbacks.pop()
+            print(f'host ms per timed step: median {sorted(step_host)[len(step_host) // 2]:.3f}, the slowest '
+                  f'{sorted(((round(v, 2), k) for k, v in enumerate(step_host)), reverse=True)[:6]}, host loop '
+                  f'{(t_host - t0) * 1e3:.1f} ms of {elapsed * 1e3:.1f} ms', file=sys.stderr)
+            starts = {}
+            for phase, gen, t in gc_log:
+                if phase == 'start':
+                    starts[gen] = t
+                elif gen in starts and (t - starts[gen]) > 1e-3:
+                    print(f'  gc generation {gen}: {(t - starts[gen]) * 1e3:.1f} ms at +{(starts[gen] - t0) * 1e3:.1f} ms',
+                          file=sys.stderr)
+        if freeze:
+            gc.unfreeze()
         lib.pvs_profile_enable(0)
         dom_live = None if use_graph else _kernel_ms(lib, dom_group)      # (total ms, launches) of the timed region
         dom_each = [] if use_graph else _kernel_each(lib, dom_group)
@@ -824,6 +856,8 @@ def training_bench(args, rank, world, dev):
                        'scaling_note': scaling_note(args, world, strong),
                        'last_layer_coord_update': 'skipped (dead)' if args.skip_dead_coords else 'evaluated',
                        'launch': 'hipGraph replay of the whole step' if use_graph else 'eager',
+                       'host_gc': ('heap frozen (gc.freeze) for the timed region, as train_model does' if freeze else
+                                   'Python collector left alone (PVS_GC_FREEZE=0)'),
                        'layer_calls': ('one call each way for the whole layer stack (pvs_egnn_stack_fwd / _bwd)'
                                        if model.__dict__.get('_stack_cache') is not None else
                                        'one call each way per layer (pvs_egnn_layer_fwd / _bwd)'),

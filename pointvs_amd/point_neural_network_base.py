@@ -8,6 +8,8 @@ Mirrors the constructor, loss, optimiser step and checkpoint format of
 Progress bars, wandb and the predictions-file writer are outside the hot-path scope and reduced to
 plain logging.
 """
+import contextlib
+import gc
 import itertools
 import math
 import os
@@ -34,6 +36,25 @@ def _rank_world():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
 
+
+
+@contextlib.contextmanager
+def long_lived_heap_frozen():
+    """`import torch` alone leaves ~170,000 container objects on the heap, and Python's first full (generation-2)
+    collection walks all of them: 60-170 ms on the host, once, some tens of steps into a run (later ones are rare: they
+    wait for a quarter as many NEW long-lived objects). Nothing for the reference's loop; a hundred steps' worth where a
+    step takes ~1 ms (found in round 6: `PVS_BENCH_TRACE_STEPS=1 python bench.py --config real4A` prints the pause).
+    gc.freeze() moves what exists now - modules, the model, the loader - out of the collector's sight for the duration of
+    the loop; young objects are collected as before. PVS_GC_FREEZE=0: off."""
+    if os.environ.get('PVS_GC_FREEZE') == '0':
+        yield
+        return
+    gc.collect()
+    gc.freeze()
+    try:
+        yield
+    finally:
+        gc.unfreeze()
 
 class _StepReplayer:
     """train_model(capture=True): whole training steps (graph preparation, forward, loss, backward, clip + Adam) as
@@ -288,12 +309,13 @@ class PointNeuralNetworkBase(nn.Module):
         if capture:
             replayer = _StepReplayer(self)
             try:
-                with torch.cuda.stream(replayer.stream):
+                with torch.cuda.stream(replayer.stream), long_lived_heap_frozen():
                     return self._train_epochs(data_loader, init_epoch, epochs, epoch_end_validation_set, top1_on_end,
                                               replayer)
             finally:
                 replayer.close()
-        return self._train_epochs(data_loader, init_epoch, epochs, epoch_end_validation_set, top1_on_end, None)
+        with long_lived_heap_frozen():
+            return self._train_epochs(data_loader, init_epoch, epochs, epoch_end_validation_set, top1_on_end, None)
 
     def _train_epochs(self, data_loader, init_epoch, epochs, epoch_end_validation_set, top1_on_end, replayer):
         losses = []

@@ -346,6 +346,9 @@ class ScreeningSweep:
             sigmoid = getattr(self.model, 'model_task', 'classification') == 'classification'
         writer = PredictionsWriter(predictions_file, 'regression', flush_every=10) if predictions_file else None
         out = {}
+        from .point_neural_network_base import long_lived_heap_frozen
+        frozen = long_lived_heap_frozen()       # (no full-heap collection pause inside the sweep: see its docstring)
+        frozen.__enter__()
         try:
             for name, lig_feats, poses in ligands:
                 n_poses, n_lig = int(poses.shape[0]), int(poses.shape[1])
@@ -372,6 +375,7 @@ class ScreeningSweep:
                 out[name] = torch.cat(scores, 0)
                 screen.check()
         finally:
+            frozen.__exit__(None, None, None)
             if writer is not None:
                 writer.close()
         return out
