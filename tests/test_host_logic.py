@@ -670,3 +670,22 @@ def test_stack_plan_lays_the_gradients_of_all_layers_out_in_one_buffer():
     opt = FusedClipAdam([torch.nn.Parameter(torch.zeros(3))], lr=1e-3)
     twin = copy.deepcopy(opt)
     assert twin._ring == [] and twin._fast is None and twin._recent == {}
+
+
+def test_training_loops_run_with_the_long_lived_heap_frozen(monkeypatch):
+    """point_neural_network_base.long_lived_heap_frozen (train_model, ScreeningSweep.run, bench.py's timed region): what
+    exists when the loop starts is moved out of the collector's sight (no 60-170 ms full collection over torch's ~170,000
+    import-time objects inside the loop), and handed back afterwards; PVS_GC_FREEZE=0 leaves the collector alone."""
+    import gc
+    from pointvs_amd.point_neural_network_base import long_lived_heap_frozen
+    before = gc.get_freeze_count()
+    with long_lived_heap_frozen():
+        inside = gc.get_freeze_count()
+        assert inside > before + 10000          # (torch's modules alone are far more)
+        junk = [[k] for k in range(1000)]       # young objects are still collected: the collector stays enabled
+        assert gc.isenabled()
+        del junk
+    assert gc.get_freeze_count() == 0 or gc.get_freeze_count() <= before
+    monkeypatch.setenv('PVS_GC_FREEZE', '0')
+    with long_lived_heap_frozen():
+        assert gc.get_freeze_count() <= before
