@@ -625,13 +625,15 @@ class SartorrasEGNN(PNNGeometricBase):
                 return None
             pstructs.append(pstruct)
             param_tuples.append(params)
-        if cached is not None and cached[0] == skip_coords and len(cached[1].pstructs) == len(pstructs) \
-                and all(a is b for a, b in zip(cached[1].pstructs, pstructs)):
-            return cached[1]
+        # (the descriptors are re-derived every call, like the per-layer path does: a flag flipped on a built layer -
+        # `layer.edge_attention = False` - must not meet a stale plan; ~2 us per layer)
         descs = [layer._desc() for layer in egnn_layers]
         if skip_coords:
             d = descs[-1]
             descs[-1] = (d[0], d[1], d[2] & ~_lib.UPDATE_COORDS, d[3])
+        if cached is not None and cached[0] == skip_coords and len(cached[1].pstructs) == len(pstructs) \
+                and all(a is b for a, b in zip(cached[1].pstructs, pstructs)) and cached[1].desc_tuples == tuple(descs):
+            return cached[1]
         plan = PF.StackPlan(descs, param_tuples, pstructs)
         plan.skip_coords = skip_coords
         self.__dict__['_stack_cache'] = (skip_coords, plan)
