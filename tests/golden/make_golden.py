@@ -337,6 +337,20 @@ def main():
     run_case('c6_multitask_att_placement_mirrored_g4', g4, MultitaskSatorrasEGNN,
              var(k=64, num_layers=3, edge_attention=True, node_attention=True,
                  edge_attention_first_only=True, node_attention_final_only=True), task='regression')
+    # C7 (round 6): the edge-residual kinds WITHOUT edge attention at 32 and 64 channels on a graph of several hundred
+    # 32-edge tiles. Until round 6 the only gated-edge-residual cases were c3_edgeres_gated_g5 (16 channels: the generic
+    # kernels) and c3_all_on_k32_g5 (with attention), and every fixture graph was a few tiles - the H = 32 backward for
+    # gated edge residual without attention was wrong on larger graphs and no case could see it
+    # (profiles/r06_gated_residual_backward_defect.txt).
+    g6 = Batch.from_data_list([synthetic_ball_graph(400, 20, 6.0, seed=21)])
+    run_case('c7_k32_edgeres_gated_g6', g6, SartorrasEGNN,
+             var(k=32, edge_residual=True, residual=True, gated_residual=True, num_layers=3), with_adam=True)
+    run_case('c7_k32_edgeres_rezero_g6', g6, SartorrasEGNN,
+             var(k=32, edge_residual=True, residual=True, rezero=True, num_layers=3))
+    run_case('c7_k32_edgeres_sum_tanh_g6', g6, SartorrasEGNN,
+             var(k=32, edge_residual=True, tanh=True, normalize=True, num_layers=3))
+    run_case('c7_k64_edgeres_gated_g6', g6, SartorrasEGNN,
+             var(k=64, edge_residual=True, residual=True, gated_residual=True, num_layers=3))
 
 
 if __name__ == '__main__':
