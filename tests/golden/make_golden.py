@@ -351,6 +351,15 @@ def main():
              var(k=32, edge_residual=True, tanh=True, normalize=True, num_layers=3))
     run_case('c7_k64_edgeres_gated_g6', g6, SartorrasEGNN,
              var(k=64, edge_residual=True, residual=True, gated_residual=True, num_layers=3))
+    # ... and the attention instantiations on the same graph (until round 6 only on fixture graphs of a few tiles)
+    run_case('c7_k32_sigatt_residual_g6', g6, SartorrasEGNN,
+             var(k=32, edge_attention=True, node_attention=True, residual=True, num_layers=3))
+    run_case('c7_k32_softmax_edgeres_rezero_g6', g6, SartorrasEGNN,
+             var(k=32, edge_attention=True, softmax_attention=True, edge_residual=True, residual=True, rezero=True,
+                 normalize=True, num_layers=3))
+    run_case('c7_k64_tanhatt_edgeres_gated_g6', g6, SartorrasEGNN,
+             var(k=64, edge_attention=True, node_attention=True, attention_activation_fn='tanh', edge_residual=True,
+                 residual=True, gated_residual=True, tanh=True, num_layers=3))
 
 
 if __name__ == '__main__':
