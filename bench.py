@@ -724,7 +724,6 @@ def training_bench(args, rank, world, dev):
         import gc
         freeze = os.environ.get('PVS_GC_FREEZE') != '0'
         if freeze:
-            gc.collect()
             gc.freeze()
         torch.cuda.synchronize(dev)
         if distributed:

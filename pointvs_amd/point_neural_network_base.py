@@ -46,15 +46,22 @@ def long_lived_heap_frozen():
     step takes ~1 ms (found in round 6: `PVS_BENCH_TRACE_STEPS=1 python bench.py --config real4A` prints the pause).
     gc.freeze() moves what exists now - modules, the model, the loader - out of the collector's sight for the duration of
     the loop; young objects are collected as before. PVS_GC_FREEZE=0: off."""
-    if os.environ.get('PVS_GC_FREEZE') == '0':
+    global _FROZEN_DEPTH
+    if os.environ.get('PVS_GC_FREEZE') == '0' or _FROZEN_DEPTH:      # (nested: validation inside a training run)
         yield
         return
-    gc.collect()
+    # (no gc.collect() first: a full collection is the very pause this avoids, and ScreeningSweep.run enters here once per
+    # sweep inside callers' timed regions; cycles that are garbage right now stay until the loop ends)
     gc.freeze()
+    _FROZEN_DEPTH = 1
     try:
         yield
     finally:
+        _FROZEN_DEPTH = 0
         gc.unfreeze()
+
+
+_FROZEN_DEPTH = 0
 
 class _StepReplayer:
     """train_model(capture=True): whole training steps (graph preparation, forward, loss, backward, clip + Adam) as
@@ -372,7 +379,7 @@ class PointNeuralNetworkBase(nn.Module):
         part = predictions_file if world == 1 else rank_part(predictions_file, rank)
         self.eval()
         self.val_iter = 0
-        with PredictionsWriter(part, self.model_task, flush_every=self.log_interval) as writer:
+        with PredictionsWriter(part, self.model_task, flush_every=self.log_interval) as writer, long_lived_heap_frozen():
             for self.batch, graph in enumerate(data_loader):
                 self.val_iter += 1
                 y_pred, y_true, ligands, receptors = self.unpack_input_data_and_predict(graph)

@@ -689,3 +689,15 @@ def test_training_loops_run_with_the_long_lived_heap_frozen(monkeypatch):
     monkeypatch.setenv('PVS_GC_FREEZE', '0')
     with long_lived_heap_frozen():
         assert gc.get_freeze_count() <= before
+
+
+def test_frozen_heap_nests():
+    """Validation at the end of an epoch runs inside a training run: the inner loop must not thaw the outer one's heap."""
+    import gc
+    from pointvs_amd.point_neural_network_base import long_lived_heap_frozen
+    with long_lived_heap_frozen():
+        outer = gc.get_freeze_count()
+        with long_lived_heap_frozen():
+            assert gc.get_freeze_count() == outer
+        assert gc.get_freeze_count() == outer > 0
+    assert gc.get_freeze_count() == 0
