@@ -43,8 +43,8 @@ python3 tools/allreduce_microbench.py 2>/dev/null | line > $out/allreduce_one_ra
 python3 tools/dynamic_range_probe.py 2>/dev/null | grep -v amdgpu.ids > $out/dynamic_range.txt
 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_parity.py -q -m gpu > $out/parity.log 2>&1; cp gpurun_out/parity_margins.txt $out/parity_margins.txt
 # round 5 additions: the launch-bound shape (the reference's CLI defaults), eager and captured, with one step's timeline
-python3 bench.py --config real4A --steps 50 --warmup 10 --graph 0 --no-cpu-baseline 2>/dev/null | line > $out/real_shape_eager.json
-python3 bench.py --config real4A --steps 50 --warmup 10 --graph 1 --no-cpu-baseline 2>/dev/null | line > $out/real_shape_graph.json
+python3 bench.py --config real4A --steps 200 --warmup 30 --graph 0 --no-cpu-baseline 2>/dev/null | line > $out/real_shape_eager.json
+python3 bench.py --config real4A --steps 200 --warmup 30 --graph 1 --no-cpu-baseline 2>/dev/null | line > $out/real_shape_graph.json
 rocprofv3 --kernel-trace --output-format csv -d $out/trace_real4A -- python3 bench.py --config real4A --steps 3 --warmup 2 --graph 0 --no-cpu-baseline > /dev/null 2>&1
 python3 tools/step_timeline.py $out/trace_real4A > $out/step_timeline_real4A.txt 2>&1
 find $out/trace_real4A -name '*.csv' -size +1M -delete
