@@ -647,7 +647,11 @@ k_edge_bwd_f16(PvsGraph g, PvsEdgeW w, uint32_t flags, int att_act, PvsEdgeBwdIO
                         mp[0][r] = gmv;
                     }
                 }
+#ifdef PVS_MASK_GZ2          // (A/B only: what the lanes past a tile's end hold - profiles/r06_gated_residual_backward_defect.txt)
+                g_z2[r] = valid ? gnew * dz2[r] : 0.f;
+#else
                 g_z2[r] = gnew * dz2[r];
+#endif
             }
             if constexpr (ERES) {
                 if (valid) store_x<1>(io.g_m_prev + (size_t)e * H, hh, mp);
