@@ -382,15 +382,18 @@ typedef struct PvsAdamEntry {
     float* exp_avg_sq;
     int64_t numel;
 } PvsAdamEntry;
-int pvs_adam_clip_step(const PvsAdamEntry* table, int32_t n_tensors, float lr, float beta1, float beta2,
-                       float eps, float weight_decay, float bias_correction1, float bias_correction2,
+int pvs_adam_clip_step(const PvsAdamEntry* table, int32_t n_tensors, double lr, double beta1, double beta2,
+                       float eps, float weight_decay, double bias_correction1, double bias_correction2,
                        float clip, pvs_stream_t stream);
-/* The same with the step count on the DEVICE: `step` points at one fp32 value, the number of this step (>= 1; the
+/* (lr, the betas and the bias corrections as DOUBLES since round 6: lr / bias_correction1, sqrt(bias_correction2), 1 - beta1
+ * and 1 - beta2 are formed in double and rounded once, as torch forms the scalars it hands to lerp_ / addcmul_ / addcdiv_;
+ * 1.f - 0.999f is 1.3e-5 below float(0.001).)
+ * The same with the step count on the DEVICE: `step` points at one fp32 value, the number of this step (>= 1; the
  * caller advances it on the stream before the call), from which the kernel forms both bias corrections (in double, from the betas as doubles: `1 - beta ** step` as the host
- * form's caller evaluates it in Python; the update itself uses the betas rounded to fp32 like the host form). This is what
+ * form's caller evaluates it in Python: bit for bit the host form's update). This is what
  * torch.optim.Adam(capturable=True) does (adam.py `_multi_tensor_adam`, capturable branch: step tensors on the device) so
  * that a captured training step can be replayed; nothing about the launch depends on host state that changes per step. */
-int pvs_adam_clip_step_dev(const PvsAdamEntry* table, int32_t n_tensors, float lr, double beta1, double beta2,
+int pvs_adam_clip_step_dev(const PvsAdamEntry* table, int32_t n_tensors, double lr, double beta1, double beta2,
                            float eps, float weight_decay, const float* step, float clip, pvs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -114,8 +114,9 @@ _PROTOTYPES = {
                                          C.c_size_t, C.c_void_p]),
     'pvs_segment_reduce_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
-    'pvs_adam_clip_step': (C.c_int, [C.c_void_p, C.c_int32] + [C.c_float] * 8 + [C.c_void_p]),
-    'pvs_adam_clip_step_dev': (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float,
+    'pvs_adam_clip_step': (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_float, C.c_float,
+                                     C.c_double, C.c_double, C.c_float, C.c_void_p]),
+    'pvs_adam_clip_step_dev': (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_float, C.c_float,
                                          C.c_void_p, C.c_float, C.c_void_p]),
     'pvs_profile_enable': (C.c_int, [C.c_int]),
     'pvs_profile_reset': (C.c_int, []),

@@ -445,26 +445,28 @@ int pvs_sum_vec(hipStream_t s, const float* v, int n, float* out) {
 namespace {
 // STEP_DEV: the step count is a float on the device (torch's capturable Adam keeps it there, so that a captured step can be
 // replayed): every workgroup forms the two bias corrections from it - in double, as the host form does in Python.
+// step_size = lr / (1 - beta1^step), bc2_sqrt = sqrt(1 - beta2^step), omb1 = 1 - beta1, omb2 = 1 - beta2: formed in DOUBLE
+// and rounded once, as torch's Adam forms them (Python floats handed to lerp_ / addcmul_ / addcdiv_ as scalars: adam.py
+// `_single_tensor_adam`). Until round 6 the kernel took 1 - beta in fp32 - 1.f - 0.999f is 1.3e-5 below float(0.001) - and
+// exp_avg_sq ran 1.3e-5 (relative) below torch's, the updates 6e-6 (tools/fuzz_adam.py found it with gradients of 30).
 template <bool STEP_DEV>
 __global__ void __launch_bounds__(256)
-k_adam_clip(const PvsAdamEntry* __restrict__ table, float lr, float beta1, float beta2, float eps, float wd,
-            float bc1, float bc2, float clip, const float* __restrict__ step_dev, double beta1_d, double beta2_d) {
+k_adam_clip(const PvsAdamEntry* __restrict__ table, float step_size, float beta2, float omb1, float omb2, float eps, float wd,
+            float bc2_sqrt, float clip, const float* __restrict__ step_dev, double lr_d, double beta1_d, double beta2_d) {
     if constexpr (STEP_DEV) {
         __shared__ float bc[2];
         if (threadIdx.x == 0) {      // (from the betas as the caller holds them - doubles in Python - like `1 - beta ** step` there)
             // (a counter below 1 - a state restored by hand, a step skipped - would make both corrections 0 and the
             // update a division by zero: treated as the first step)
             const double t = fmax((double)step_dev[0], 1.0);
-            bc[0] = (float)(1.0 - pow(beta1_d, t));
-            bc[1] = (float)(1.0 - pow(beta2_d, t));
+            bc[0] = (float)(lr_d / (1.0 - pow(beta1_d, t)));
+            bc[1] = (float)sqrt(1.0 - pow(beta2_d, t));
         }
         __syncthreads();
-        bc1 = bc[0];
-        bc2 = bc[1];
+        step_size = bc[0];
+        bc2_sqrt = bc[1];
     }
     const PvsAdamEntry e = table[blockIdx.y];
-    const float step_size = lr / bc1;
-    const float bc2_sqrt = sqrtf(bc2);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < e.numel;
          i += (long long)gridDim.x * blockDim.x) {
         float g = e.grad[i];
@@ -475,9 +477,9 @@ k_adam_clip(const PvsAdamEntry* __restrict__ table, float lr, float beta1, float
         const float p = e.param[i];
         if (wd != 0.f) g = __fadd_rn(g, __fmul_rn(wd, p));                        // grad.add(param, alpha=wd)
         float m = e.exp_avg[i];
-        m = __fadd_rn(m, __fmul_rn(1.f - beta1, __fsub_rn(g, m)));               // lerp_(grad, 1 - beta1)
+        m = __fadd_rn(m, __fmul_rn(omb1, __fsub_rn(g, m)));                      // lerp_(grad, 1 - beta1)
         float v = __fmul_rn(e.exp_avg_sq[i], beta2);
-        v = __fadd_rn(v, __fmul_rn(__fmul_rn(1.f - beta2, g), g));               // addcmul_(g, g, value = 1 - beta2)
+        v = __fadd_rn(v, __fmul_rn(__fmul_rn(omb2, g), g));                      // addcmul_(g, g, value = 1 - beta2)
         const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), bc2_sqrt), eps);
         e.exp_avg[i] = m;
         e.exp_avg_sq[i] = v;
@@ -486,22 +488,24 @@ k_adam_clip(const PvsAdamEntry* __restrict__ table, float lr, float beta1, float
 }
 }  // namespace
 
-extern "C" int pvs_adam_clip_step(const PvsAdamEntry* table, int32_t n, float lr, float beta1, float beta2,
-                                  float eps, float wd, float bc1, float bc2, float clip, pvs_stream_t stream) {
+extern "C" int pvs_adam_clip_step(const PvsAdamEntry* table, int32_t n, double lr, double beta1, double beta2,
+                                  float eps, float wd, double bc1, double bc2, float clip, pvs_stream_t stream) {
     PVS_REQUIRE(table && n >= 0, "pvs_adam_clip_step: bad arguments");
-    PVS_REQUIRE(bc1 > 0.f && bc2 > 0.f, "pvs_adam_clip_step: bias corrections must be positive (step >= 1)");
+    PVS_REQUIRE(bc1 > 0.0 && bc2 > 0.0, "pvs_adam_clip_step: bias corrections must be positive (step >= 1)");
     if (n == 0) return 0;
-    k_adam_clip<false><<<dim3(8, n), 256, 0, (hipStream_t)stream>>>(table, lr, beta1, beta2, eps, wd, bc1, bc2, clip, nullptr, 0.0, 0.0);
+    k_adam_clip<false><<<dim3(8, n), 256, 0, (hipStream_t)stream>>>(table, (float)(lr / bc1), (float)beta2, (float)(1.0 - beta1),
+                                                                    (float)(1.0 - beta2), eps, wd, (float)sqrt(bc2), clip,
+                                                                    nullptr, 0.0, 0.0, 0.0);
     PVS_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int pvs_adam_clip_step_dev(const PvsAdamEntry* table, int32_t n, float lr, double beta1, double beta2,
+extern "C" int pvs_adam_clip_step_dev(const PvsAdamEntry* table, int32_t n, double lr, double beta1, double beta2,
                                       float eps, float wd, const float* step, float clip, pvs_stream_t stream) {
     PVS_REQUIRE(table && step && n >= 0, "pvs_adam_clip_step_dev: bad arguments");
     if (n == 0) return 0;
-    k_adam_clip<true><<<dim3(8, n), 256, 0, (hipStream_t)stream>>>(table, lr, (float)beta1, (float)beta2, eps, wd, 1.f, 1.f, clip, step,
-                                                                   beta1, beta2);
+    k_adam_clip<true><<<dim3(8, n), 256, 0, (hipStream_t)stream>>>(table, 0.f, (float)beta2, (float)(1.0 - beta1),
+                                                                   (float)(1.0 - beta2), eps, wd, 1.f, clip, step, lr, beta1, beta2);
     PVS_CHECK_LAUNCH();
     return 0;
 }
