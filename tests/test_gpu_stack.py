@@ -231,3 +231,29 @@ def test_stack_with_layers_of_different_flags_multitask(placement, task, monkeyp
         for i, what in enumerate(('att_val', 'node_att_val', 'intermediate_coords')):
             _same(x[i], y[i], f'layer {k + 1} {what}')
         assert (x[0] is not None) == flags[k][0] and (x[1] is not None) == flags[k][1]
+
+
+def test_fused_adam_forms_its_scalar_factors_as_torch_does():
+    """torch's Adam hands lerp_ / addcmul_ / addcdiv_ the scalars 1 - beta1, 1 - beta2, lr / bias_correction1 and
+    sqrt(bias_correction2) formed in DOUBLE (adam.py `_single_tensor_adam`). Until round 6 the fused kernel formed 1 - beta in
+    fp32: 1.f - 0.999f is 1.3e-5 below float(0.001), and with it every second moment (tools/fuzz_adam.py found it; the older
+    optimiser test's moments are ~1e-3 under a max(1, .)-relative bound). Gradients of 30 over eight steps, lr 0.1: second
+    moments and parameters relative to THEIR OWN magnitude. Reference: the optimiser step of backprop(),
+    /root/reference/point_vs/models/point_neural_network_base.py:421-422."""
+    from pointvs_amd.optim import FusedClipAdam
+    torch.manual_seed(0)
+    shapes = [(32, 68), (32,), (1, 32), (1,)]
+    a = [torch.nn.Parameter(torch.randn(s, device='cuda')) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa = FusedClipAdam(a, lr=0.1, weight_decay=1e-2)
+    ob = torch.optim.Adam(b, lr=0.1, weight_decay=1e-2)
+    for step in range(8):
+        for k, (pa, pb) in enumerate(zip(a, b)):
+            g = torch.randn(pa.shape, generator=torch.Generator().manual_seed(100 * step + k)).cuda() * 30
+            pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for (pa, pb), sa, sb in zip(zip(a, b), oa.state.values(), ob.state.values()):
+        for got, ref in ((sa['exp_avg_sq'], sb['exp_avg_sq']), (sa['exp_avg'], sb['exp_avg']), (pa, pb)):
+            err = float((got.detach() - ref.detach()).abs().max() / ref.detach().abs().max())
+            assert err < 2e-6, err          # (1.3e-5 / 6e-6 with 1 - beta in fp32; ~2e-7 now)
