@@ -124,10 +124,22 @@ def test_forward_backward_match_reference(name):
             assert g64[pname] is None, pname
             continue
         got = p.grad.detach().cpu().numpy()
-        if pname in c.grads:
-            assert rel_err(got, c.grads[pname]) < TOL, f'grad {pname} vs reference fp32'
         ref64 = g64[pname].numpy()
-        assert rel_err(got, ref64) < TOL, f'grad {pname} vs fp64 oracle'
+        if (pname in c.grads and not rel_err(got, c.grads[pname]) < TOL) or not rel_err(got, ref64) < TOL:
+            # (round 6: this check failed ONCE in sixteen runs of the whole suite - c3_all_on_k32_g5, never alone, never in
+            # 1500 repeats under a concurrent GPU load - and the message said too little: say how far off, and whether a
+            # second evaluation of the same step on the same inputs gives the same bits)
+            first = {n: q.grad.detach().clone() for n, q in model.named_parameters() if q.grad is not None}
+            model.zero_grad()
+            y2, _, _, _ = model.unpack_input_data_and_predict(make_batch(c))
+            model.get_loss(c.y_true.cuda(), y2).backward()
+            moved = sorted(n for n, q in model.named_parameters() if q.grad is not None and not torch.equal(q.grad, first[n]))
+            raise AssertionError(
+                f'grad {pname}: {rel_err(got, ref64):.3e} from the fp64 oracle'
+                + (f', {rel_err(got, c.grads[pname]):.3e} from the reference fp32' if pname in c.grads else '')
+                + f' (bound {TOL}); a second evaluation of the step '
+                + ('gave the same bits' if not moved else f'gave OTHER bits in {moved[:6]}: '
+                   f'now {rel_err(p.grad.detach().cpu().numpy(), ref64):.3e} from the fp64 oracle'))
         samples = [g32[pname].numpy()] + [gp[pname].numpy() for gp in g32p]
         if pname in c.grads:
             samples.append(c.grads[pname])

@@ -45,6 +45,9 @@ FAMILIES = {
     'h32_edgeres_rezero': dict(edge_residual=True, residual=True, rezero=True),         # <2,false>
     'h32_edgeres_gated': dict(edge_residual=True, residual=True, gated_residual=True),  # the gated kind without attention
     'h32_edgeres_gated_att': dict(edge_residual=True, residual=True, gated_residual=True, edge_attention=True),   # <3,true>
+    # (golden case c3_all_on_k32_g5's flag set: it failed ONCE in eight runs of the whole GPU suite in round 6 and never alone)
+    'h32_all_on': dict(num_layers=3, residual=True, gated_residual=True, edge_residual=True, edge_attention=True,
+                       node_attention=True, normalize=True, tanh=True, graphnorm=True),
     'h32_softmax_gn': dict(edge_attention=True, softmax_attention=True, graphnorm=True, node_attention=True,
                            residual=True),
     'h64': dict(k=64),                                                     # k_edge_bwd_h64<0,false>
