@@ -54,7 +54,11 @@ def test_forward_backward_match_reference(name):
                                      c.y_true, dtype=torch.float32, trace=t32)
     # two more samples of the reference arithmetic's fp32 noise: the same evaluation with the edges in another order
     g32p, t32p = [], []
-    for perm in edge_permutations(c.edge_index.shape[1]):
+    # (SIX more orders since round 6, two before: on a many-core host the oracle's fp32 sums are threaded and every sample
+    # is a random draw; with three draws in all, the noise-dominated bound of a tiny tensor dipped under the GPU's - always
+    # identical - error about once in twenty-five fresh processes: c3_all_on_k32_g5 `layers.1.att_mlp.0.weight`, error
+    # 1.011e-09 every time, bound 7.8e-10 ... 3.3e-09. More draws can only raise the bound's maximum; profiles/r06_fuzz_campaign.txt)
+    for perm in edge_permutations(c.edge_index.shape[1], count=6):
         tp = {}
         _, _, gp = orc.forward_backward(c.sd, c.cfg, c.x, c.pos, c.edge_index[:, perm], c.edge_attr[perm], c.batch,
                                         c.y_true, dtype=torch.float32, trace=tp)
