@@ -63,6 +63,14 @@ def oracle_run(model, kw, g, dtype=torch.float32):
                                 torch.ones(int(g.batch.max()) + 1), dtype=dtype)
 
 
+def oracle_fp32_draws(model, kw, g, draws=3):
+    """{parameter: [fp32 gradient of `draws` oracle evaluations]}: on a many-core host the oracle's CPU sums are threaded and
+    every evaluation is ONE draw of the reference arithmetic's rounding noise; a strict bound formed from a single draw is a
+    random variable (round 6: profiles/r06_fuzz_campaign.txt, the golden case that failed once in 25-60 fresh processes)."""
+    runs = [oracle_run(model, kw, g, dtype=torch.float32)[2] for _ in range(draws)]
+    return {k: (None if runs[0][k] is None else [r[k].numpy() for r in runs]) for k in runs[0]}
+
+
 def gpu_run(model, g):
     import copy
     gg = copy.copy(g)
@@ -95,7 +103,7 @@ def test_ragged_graphs_match_oracle(name, flags):
     g = random_graph(n, e, seed=sum(name.encode()) % 1000)
     y, grads = gpu_run(model, g)
     y_ref, _, g_ref = oracle_run(model, kw, g, dtype=torch.float64)
-    _, _, g_ref32 = oracle_run(model, kw, g, dtype=torch.float32)
+    g_ref32 = oracle_fp32_draws(model, kw, g)
     assert rel_err(y, y_ref.numpy()) < TOL
     log = CaseLog(f'ragged_{name}_{flags}')
     floor = grad_floor({k: (None if v is None else v.numpy()) for k, v in g_ref.items()})
@@ -105,7 +113,7 @@ def test_ragged_graphs_match_oracle(name, flags):
         else:
             assert rel_err(gr, g_ref[pname].numpy()) < TOL, pname
             # (strict per-tensor form, tests/_golden.py: a small gradient tensor is compared at its own magnitude)
-            assert_strict(gr, g_ref[pname].numpy(), g_ref32[pname].numpy(), f'{log.case} grad {pname}', floor=floor, log=log)
+            assert_strict(gr, g_ref[pname].numpy(), g_ref32[pname], f'{log.case} grad {pname}', floor=floor, log=log)
     log.finish()
 
 
@@ -160,7 +168,7 @@ def _check_wide(k, flags):
     g = random_graph(300, 6000, seed=21, n_graphs=3)
     y, grads = gpu_run(model, g)
     y_ref, _, g_ref = oracle_run(model, kw, g, dtype=torch.float64)
-    _, _, g_ref32 = oracle_run(model, kw, g, dtype=torch.float32)
+    g_ref32 = oracle_fp32_draws(model, kw, g)
     assert rel_err(y, y_ref.numpy()) < TOL
     log = CaseLog(f'wide_{k}_{flags}')
     floor = grad_floor({k: (None if v is None else v.numpy()) for k, v in g_ref.items()})
@@ -170,7 +178,7 @@ def _check_wide(k, flags):
         else:
             assert rel_err(gr, g_ref[pname].numpy()) < TOL, pname
             # (strict per-tensor form, tests/_golden.py: a small gradient tensor is compared at its own magnitude)
-            assert_strict(gr, g_ref[pname].numpy(), g_ref32[pname].numpy(), f'{log.case} grad {pname}', floor=floor, log=log)
+            assert_strict(gr, g_ref[pname].numpy(), g_ref32[pname], f'{log.case} grad {pname}', floor=floor, log=log)
     log.finish()
     if flags == 'att_res':
         n_edges = int(g.edge_index.shape[1])
